@@ -1,0 +1,43 @@
+# Builds libcholamd.so (C host code + HIP kernels for gfx950), the mmat-compatible CLI and the
+# CPU oracle (test infrastructure).  No cmake needed: gcc for the C host code, hipcc for HIP.
+HIPCC   ?= /opt/rocm/bin/hipcc
+CC      ?= gcc
+ARCH    ?= gfx950
+CSRC    := cholesky_amd/csrc
+OUT     := cholesky_amd/lib
+BIN     := cholesky_amd/bin
+CFLAGS  := -O2 -fPIC -Wall -Wextra -std=gnu11 -Iinclude -I$(CSRC)
+HIPFLAGS:= -O3 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall
+
+HOST_OBJS := $(OUT)/chol_ingest.o $(OUT)/chol_symbolic.o $(OUT)/chol_schedule.o
+HIP_OBJS  := $(OUT)/chol_kernels.o $(OUT)/chol_api.o
+
+all: $(OUT)/libcholamd.so $(BIN)/cholamd_mmat oracle
+
+$(OUT)/%.o: $(CSRC)/%.c $(CSRC)/chol_plan.h include/cholamd.h
+	@mkdir -p $(OUT)
+	$(CC) $(CFLAGS) -c $< -o $@
+
+$(OUT)/chol_kernels.o: $(CSRC)/chol_kernels.hip $(CSRC)/chol_plan.h $(CSRC)/chol_kernels.h
+	@mkdir -p $(OUT)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OUT)/chol_api.o: $(CSRC)/chol_api.cpp $(CSRC)/chol_plan.h $(CSRC)/chol_kernels.h include/cholamd.h
+	@mkdir -p $(OUT)
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(OUT)/libcholamd.so: $(HOST_OBJS) $(HIP_OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^
+
+$(BIN)/cholamd_mmat: $(CSRC)/mmat_main.c $(OUT)/libcholamd.so include/cholamd.h
+	@mkdir -p $(BIN)
+	$(CC) $(CFLAGS) -o $@ $< -L$(OUT) -lcholamd -Wl,-rpath,'$$ORIGIN/../lib' -lm
+
+oracle:
+	$(MAKE) -s -C oracle
+
+clean:
+	rm -rf $(OUT) $(BIN)
+	$(MAKE) -s -C oracle clean
+
+.PHONY: all oracle clean

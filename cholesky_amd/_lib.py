@@ -1,0 +1,130 @@
+"""ctypes binding of libcholamd.so (include/cholamd.h).  No compute happens in Python.
+
+The shared library is built in-tree by `make` (or `__graft_entry__.build()`); importing this module
+without it raises -- there is no Python/CPU fallback for the numeric path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcholamd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cholamd.h")
+
+
+class Filled(C.Structure):
+    """fspace Filled (blas.rg:55-61)."""
+    _fields_ = [("filled", C.c_int), ("sep_x", C.c_int), ("sep_y", C.c_int), ("interval", C.c_int), ("cluster", C.c_int),
+                ("lo_x", C.c_int), ("lo_y", C.c_int), ("hi_x", C.c_int), ("hi_y", C.c_int)]
+
+
+class Op(C.Structure):
+    _fields_ = [("op", C.c_int), ("level", C.c_int), ("m", C.c_int), ("n", C.c_int), ("k", C.c_int),
+                ("a_sx", C.c_int), ("a_sy", C.c_int), ("a_z", C.c_int), ("b_sx", C.c_int), ("b_sy", C.c_int), ("b_z", C.c_int),
+                ("c_sx", C.c_int), ("c_sy", C.c_int), ("c_z", C.c_int)]
+
+
+class Region(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("ld", C.c_int), ("lo_x", C.c_int), ("lo_y", C.c_int), ("hi_x", C.c_int), ("hi_y", C.c_int)]
+
+
+class SepInfo(C.Structure):
+    _fields_ = [("levels", C.c_int), ("num_separators", C.c_int)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `make` (or __graft_entry__.build()) first; "
+                          "cholesky_amd has no fallback path without its HIP library")
+    L = C.CDLL(LIB_PATH)
+    vp, ci, cd, i64 = C.c_void_p, C.c_int, C.c_double, C.c_int64
+    L.cholamd_last_error.restype = C.c_char_p
+    L.cholamd_version.restype = C.c_char_p
+    L.cholamd_read_separators.argtypes = [C.c_char_p, ci, vp, vp, C.POINTER(SepInfo)]
+    L.cholamd_read_clusters.argtypes = [C.c_char_p, vp, vp, vp, i64, C.POINTER(i64)]
+    L.cholamd_read_matrix.argtypes = [C.c_char_p, ci, vp, vp, vp]
+    L.cholamd_read_vector.argtypes = [C.c_char_p, ci, vp]
+    L.cholamd_write_solution.argtypes = [C.c_char_p, vp, ci, ci]
+    L.cholamd_plan_create.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(vp)]
+    L.cholamd_plan_create_from_arrays.argtypes = [ci, ci, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, C.c_char_p, C.POINTER(vp)]
+    L.cholamd_plan_destroy.argtypes = [vp]
+    for f in ("n", "nz", "levels", "num_separators", "max_int_size", "num_blocks"):
+        getattr(L, "cholamd_plan_" + f).argtypes = [vp]
+    for f in ("arena_doubles", "dropped_entries", "num_ops", "nnz_a", "nnz_l", "alg_bytes"):
+        fn = getattr(L, "cholamd_plan_" + f)
+        fn.argtypes = [vp]
+        fn.restype = i64
+    L.cholamd_plan_nnz_tiles.argtypes = [vp]
+    L.cholamd_plan_nnz_tiles.restype = i64
+    L.cholamd_plan_fmin.argtypes = [vp]
+    L.cholamd_plan_fmin.restype = cd
+    L.cholamd_plan_banner.argtypes = [vp]
+    L.cholamd_plan_banner.restype = C.c_char_p
+    for f in ("perm", "sep_sizes", "sep_offsets", "tree", "blocks", "ops"):
+        getattr(L, "cholamd_plan_" + f).argtypes = [vp, vp]
+    L.cholamd_plan_snapshot_count.argtypes = [vp, ci]
+    L.cholamd_plan_snapshot_count.restype = i64
+    L.cholamd_plan_snapshot.argtypes = [vp, ci, vp]
+    L.cholamd_plan_counts.argtypes = [vp, ci, vp, vp]
+    L.cholamd_plan_flops.argtypes = [vp]
+    L.cholamd_plan_flops.restype = cd
+    L.cholamd_plan_fill_host.argtypes = [vp, vp]
+    L.cholamd_plan_arena_to_dense.argtypes = [vp, vp, vp]
+    L.cholamd_plan_write_matrix.argtypes = [vp, vp, C.c_char_p, ci]
+    L.cholamd_plan_write_debug_log.argtypes = [vp, vp]
+    L.cholamd_device_create.argtypes = [vp, ci, C.POINTER(vp)]
+    L.cholamd_device_destroy.argtypes = [vp]
+    L.cholamd_device_set_partition.argtypes = [vp, ci, ci]
+    L.cholamd_device_alloc.argtypes = [vp, i64, C.POINTER(vp)]
+    L.cholamd_device_free.argtypes = [vp, vp]
+    L.cholamd_device_upload.argtypes = [vp, vp, vp, i64, vp]
+    L.cholamd_device_download.argtypes = [vp, vp, vp, i64, vp]
+    L.cholamd_device_sync.argtypes = [vp, vp]
+    L.cholamd_device_fill.argtypes = [vp, vp, vp]
+    L.cholamd_factor.argtypes = [vp, vp, vp]
+    L.cholamd_factor_levels.argtypes = [vp, vp, ci, ci, vp]
+    L.cholamd_factor_info.argtypes = [vp, C.POINTER(ci)]
+    L.cholamd_solve.argtypes = [vp, vp, vp, vp, vp]
+    L.cholamd_device_set_timing.argtypes = [vp, ci]
+    L.cholamd_device_get_timing.argtypes = [vp, vp, vp]
+    RP, FP = C.POINTER(Region), C.POINTER(Filled)
+    L.cholamd_fused_dpotrf.argtypes = [RP, FP, ci, ci, ci, ci, vp]
+    L.cholamd_fused_dtrsm.argtypes = [RP, RP, FP, ci, FP, ci, ci, ci, ci, vp]
+    L.cholamd_fused_dsyrk.argtypes = [RP, RP, RP, FP, ci, FP, ci, FP, ci, ci, ci, ci, ci, vp]
+    L.cholamd_fused_dgemm.argtypes = [RP, RP, RP, FP, ci, FP, ci, FP, ci, ci, ci, ci, ci, vp]
+    L.cholamd_LAPACKE_dpotrf.argtypes = [ci, C.c_char, ci, vp, ci]
+    L.cholamd_cblas_dtrsm.argtypes = [ci, ci, ci, ci, ci, ci, ci, cd, vp, ci, vp, ci]
+    L.cholamd_cblas_dtrsm.restype = None
+    L.cholamd_cblas_dgemm.argtypes = [ci, ci, ci, ci, ci, ci, cd, vp, ci, vp, ci, cd, vp, ci]
+    L.cholamd_cblas_dgemm.restype = None
+    L.cholamd_cblas_dsyrk.argtypes = [ci, ci, ci, ci, ci, cd, vp, ci, cd, vp, ci]
+    L.cholamd_cblas_dsyrk.restype = None
+    L.cholamd_cblas_dtrsv.argtypes = [ci, ci, ci, ci, ci, vp, ci, vp, ci]
+    L.cholamd_cblas_dtrsv.restype = None
+    L.cholamd_cblas_dgemv.argtypes = [ci, ci, ci, ci, cd, vp, ci, vp, ci, cd, vp, ci]
+    L.cholamd_cblas_dgemv.restype = None
+    L.cholamd_openblas_set_num_threads.argtypes = [ci]
+    L.cholamd_openblas_set_num_threads.restype = None
+    L.cholamd_dpotrf_dev.argtypes = [ci, vp, ci, vp, vp]
+    L.cholamd_dtrsm_dev.argtypes = [ci, ci, vp, ci, vp, ci, vp]
+    L.cholamd_dgemm_dev.argtypes = [ci, ci, ci, vp, ci, vp, ci, vp, ci, vp]
+    L.cholamd_dsyrk_dev.argtypes = [ci, ci, vp, ci, vp, ci, vp]
+    L.cholamd_dtrsv_dev.argtypes = [ci, ci, vp, ci, vp, vp]
+    L.cholamd_dgemv_dev.argtypes = [ci, ci, ci, vp, ci, vp, vp, vp]
+    _lib = L
+    return L
+
+
+class CholamdError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().cholamd_last_error().decode(errors="replace")
+        raise CholamdError(f"{what} failed with code {rc}: {msg}")

@@ -1,0 +1,782 @@
+// C ABI glue of libcholamd: device objects, the level schedule, the task-level (fused_*) and the
+// BLAS-level entry points.  Compiled with hipcc; everything exported is extern "C" (include/cholamd.h).
+// There is no CPU fallback: every compute entry point needs a HIP device and fails loudly otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "chol_kernels.h"
+#include "chol_plan.h"
+#include "cholamd.h"
+
+#define HIPCHK(call)                                                                                  \
+  do {                                                                                                \
+    hipError_t e_ = (call);                                                                           \
+    if (e_ != hipSuccess) {                                                                           \
+      chol_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);     \
+      return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? CHOLAMD_ERR_NO_DEVICE : CHOLAMD_ERR_HIP; \
+    }                                                                                                 \
+  } while (0)
+
+struct level_dev {
+  int n_potrf = 0, n_trsm = 0, n_task = 0, n_src = 0;
+  chol_potrf_desc *potrf = nullptr;
+  chol_trsm_desc *trsm = nullptr;
+  chol_upd_task *task = nullptr;
+  chol_upd_src *src = nullptr;
+};
+struct solve_dev {
+  int n_trsv = 0, n_grp = 0, n_fw = 0, n_bw = 0;
+  chol_trsv_desc *trsv = nullptr;
+  chol_gemv_desc *fw = nullptr, *bw = nullptr;
+  int *grp_start = nullptr, *grp_rows = nullptr, *bw_start = nullptr;
+};
+struct timed_launch { hipEvent_t a, b; int kind; };
+
+struct cholamd_device {
+  const cholamd_plan *plan = nullptr;
+  int dev = 0, rank = 0, world = 1;
+  std::vector<level_dev> lv;
+  std::vector<solve_dev> sv;
+  bool solve_ready = false;
+  double *ws = nullptr;
+  int *info = nullptr;      // [0] first failing column, [1] separator
+  int64_t *a_dst = nullptr; double *a_val = nullptr; int *perm = nullptr; double *ytmp = nullptr;
+  bool timing = false;
+  std::vector<timed_launch> tl;
+  std::vector<hipEvent_t> pool;
+};
+
+static int no_device_error()
+{
+  chol_set_error("no usable HIP device (libcholamd has no CPU fallback)");
+  return CHOLAMD_ERR_NO_DEVICE;
+}
+
+extern "C" int cholamd_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+template <class T> static int upload_vec(T **dptr, const T *h, size_t n)
+{
+  *dptr = nullptr;
+  if (n == 0) return 0;
+  HIPCHK(hipMalloc((void **)dptr, n * sizeof(T)));
+  HIPCHK(hipMemcpy(*dptr, h, n * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static void free_levels(cholamd_device *d)
+{
+  for (auto &l : d->lv) { (void)hipFree(l.potrf); (void)hipFree(l.trsm); (void)hipFree(l.task); (void)hipFree(l.src); }
+  d->lv.clear();
+}
+
+static int build_levels(cholamd_device *d)
+{
+  free_levels(d);
+  const int L = d->plan->levels;
+  d->lv.resize(L);
+  for (int lvl = 0; lvl < L; lvl++) {
+    chol_level_work w;
+    int rc = chol_build_level_work(d->plan, lvl, d->rank, d->world, &w);
+    if (rc) return rc;
+    level_dev &l = d->lv[lvl];
+    l.n_potrf = w.n_potrf; l.n_trsm = w.n_trsm; l.n_task = w.n_task; l.n_src = w.n_src;
+    rc = upload_vec(&l.potrf, w.potrf, (size_t)w.n_potrf);
+    if (!rc) rc = upload_vec(&l.trsm, w.trsm, (size_t)w.n_trsm);
+    if (!rc) rc = upload_vec(&l.task, w.task, (size_t)w.n_task);
+    if (!rc) rc = upload_vec(&l.src, w.src, (size_t)w.n_src);
+    chol_level_work_free(&w);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int cholamd_device_create(const cholamd_plan *plan, int device_id, cholamd_device **out)
+{
+  *out = nullptr;
+  if (!plan) { chol_set_error("null plan"); return CHOLAMD_ERR_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return no_device_error();
+  if (device_id < 0 || device_id >= ndev) { chol_set_error("device %d out of range (%d devices)", device_id, ndev); return CHOLAMD_ERR_NO_DEVICE; }
+  HIPCHK(hipSetDevice(device_id));
+  cholamd_device *d = new cholamd_device();
+  d->plan = plan; d->dev = device_id;
+  int rc = build_levels(d);
+  if (!rc) {
+    hipError_t e = hipMalloc((void **)&d->ws, (size_t)(plan->ws_doubles > 0 ? plan->ws_doubles : 1) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&d->info, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(d->info, 0, 2 * sizeof(int));
+    if (e != hipSuccess) { chol_set_error("hipMalloc: %s", hipGetErrorString(e)); rc = CHOLAMD_ERR_HIP; }
+  }
+  if (!rc) rc = upload_vec(&d->a_dst, plan->a_dst, (size_t)plan->nnz_a);
+  if (!rc) rc = upload_vec(&d->a_val, plan->a_val, (size_t)plan->nnz_a);
+  if (!rc) rc = upload_vec(&d->perm, plan->perm, (size_t)plan->n);
+  if (rc) { cholamd_device_destroy(d); return rc; }
+  *out = d;
+  return 0;
+}
+
+extern "C" void cholamd_device_destroy(cholamd_device *d)
+{
+  if (!d) return;
+  (void)hipSetDevice(d->dev);
+  free_levels(d);
+  for (auto &s : d->sv) { (void)hipFree(s.trsv); (void)hipFree(s.fw); (void)hipFree(s.bw); (void)hipFree(s.grp_start); (void)hipFree(s.grp_rows); (void)hipFree(s.bw_start); }
+  (void)hipFree(d->ws); (void)hipFree(d->info); (void)hipFree(d->a_dst); (void)hipFree(d->a_val); (void)hipFree(d->perm); (void)hipFree(d->ytmp);
+  for (auto &t : d->tl) { d->pool.push_back(t.a); d->pool.push_back(t.b); }
+  for (auto e : d->pool) (void)hipEventDestroy(e);
+  delete d;
+}
+
+extern "C" int cholamd_device_set_partition(cholamd_device *d, int rank, int world)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  if (world < 1 || (world & (world - 1)) || rank < 0 || rank >= world || chol_split_level(world) > d->plan->levels - 1) {
+    chol_set_error("bad partition: rank %d of %d for a %d-level tree", rank, world, d->plan->levels);
+    return CHOLAMD_ERR_ARG;
+  }
+  d->rank = rank; d->world = world;
+  return build_levels(d);
+}
+
+extern "C" int cholamd_device_alloc(cholamd_device *d, int64_t doubles, double **dptr)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  HIPCHK(hipMalloc((void **)dptr, (size_t)doubles * sizeof(double)));
+  return 0;
+}
+extern "C" int cholamd_device_free(cholamd_device *d, double *dptr)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  HIPCHK(hipFree(dptr));
+  return 0;
+}
+extern "C" int cholamd_device_upload(cholamd_device *d, double *d_dst, const double *h_src, int64_t doubles, void *stream)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  HIPCHK(hipMemcpyAsync(d_dst, h_src, (size_t)doubles * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+extern "C" int cholamd_device_download(cholamd_device *d, double *h_dst, const double *d_src, int64_t doubles, void *stream)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  HIPCHK(hipMemcpyAsync(h_dst, d_src, (size_t)doubles * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+extern "C" int cholamd_device_sync(cholamd_device *d, void *stream)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int cholamd_device_fill(cholamd_device *d, double *d_arena, void *stream)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipMemsetAsync(d_arena, 0, (size_t)d->plan->arena * sizeof(double), st));
+  HIPCHK((hipError_t)chol_launch_scatter(d_arena, d->a_dst, d->a_val, d->plan->nnz_a, st));
+  return 0;
+}
+
+// ---- timing helpers -------------------------------------------------------------------------
+static hipEvent_t get_event(cholamd_device *d)
+{
+  if (!d->pool.empty()) { hipEvent_t e = d->pool.back(); d->pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+struct scoped_timer {
+  cholamd_device *d; hipStream_t st; int kind; hipEvent_t a{}, b{}; bool on;
+  scoped_timer(cholamd_device *d_, hipStream_t st_, int kind_, bool active) : d(d_), st(st_), kind(kind_), on(d_->timing && active)
+  {
+    if (on) { a = get_event(d); b = get_event(d); (void)hipEventRecord(a, st); }
+  }
+  ~scoped_timer()
+  {
+    if (on) { (void)hipEventRecord(b, st); d->tl.push_back({ a, b, kind }); }
+  }
+};
+
+extern "C" int cholamd_device_set_timing(cholamd_device *d, int on)
+{
+  d->timing = on != 0;
+  for (auto &t : d->tl) { d->pool.push_back(t.a); d->pool.push_back(t.b); }
+  d->tl.clear();
+  return 0;
+}
+extern "C" int cholamd_device_get_timing(cholamd_device *d, float ms_by_kind[4], int launches_by_kind[4])
+{
+  HIPCHK(hipSetDevice(d->dev));
+  for (int k = 0; k < 4; k++) { ms_by_kind[k] = 0.f; launches_by_kind[k] = 0; }
+  for (auto &t : d->tl) {
+    HIPCHK(hipEventSynchronize(t.b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, t.a, t.b));
+    ms_by_kind[t.kind] += ms; launches_by_kind[t.kind]++;
+    d->pool.push_back(t.a); d->pool.push_back(t.b);
+  }
+  d->tl.clear();
+  return 0;
+}
+
+// ---- the hot path ---------------------------------------------------------------------------
+extern "C" int cholamd_factor_levels(cholamd_device *d, double *d_arena, int level_hi, int level_lo, void *stream)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  hipStream_t st = (hipStream_t)stream;
+  const int L = d->plan->levels;
+  if (level_hi >= L) level_hi = L - 1;
+  if (level_lo < 0) level_lo = 0;
+  if (level_hi == L - 1) HIPCHK(hipMemsetAsync(d->info, 0, 2 * sizeof(int), st));
+  for (int lvl = level_hi; lvl >= level_lo; lvl--) { // mmat.rg:1227
+    const level_dev &l = d->lv[lvl];
+    { scoped_timer t(d, st, 0, l.n_potrf > 0); HIPCHK((hipError_t)chol_launch_potrf(d_arena, d->ws, l.potrf, l.n_potrf, d->info, st)); }
+    { scoped_timer t(d, st, 1, l.n_trsm > 0); HIPCHK((hipError_t)chol_launch_trsm(d_arena, d->ws, l.trsm, l.n_trsm, st)); }
+    { scoped_timer t(d, st, 2, l.n_task > 0); HIPCHK((hipError_t)chol_launch_update(d_arena, l.task, l.src, l.n_task, st)); }
+  }
+  return 0;
+}
+extern "C" int cholamd_factor(cholamd_device *d, double *d_arena, void *stream)
+{
+  return cholamd_factor_levels(d, d_arena, d->plan->levels - 1, 0, stream);
+}
+extern "C" int cholamd_factor_info(cholamd_device *d, int *sep_out)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  int h[2] = { 0, 0 };
+  HIPCHK(hipMemcpy(h, d->info, sizeof h, hipMemcpyDeviceToHost));
+  if (sep_out) *sep_out = h[1];
+  return h[0];
+}
+
+// ---- solve ----------------------------------------------------------------------------------
+static int build_solve(cholamd_device *d)
+{
+  const int L = d->plan->levels;
+  d->sv.resize(L);
+  for (int lvl = 0; lvl < L; lvl++) {
+    chol_solve_level w;
+    int rc = chol_build_solve_level(d->plan, lvl, &w);
+    if (rc) return rc;
+    solve_dev &s = d->sv[lvl];
+    s.n_trsv = w.n_trsv; s.n_grp = w.n_grp; s.n_fw = w.n_fw; s.n_bw = w.n_bw;
+    rc = upload_vec(&s.trsv, w.trsv, (size_t)w.n_trsv);
+    if (!rc) rc = upload_vec(&s.fw, w.fw, (size_t)w.n_fw);
+    if (!rc) rc = upload_vec(&s.bw, w.bw, (size_t)w.n_bw);
+    if (!rc) rc = upload_vec(&s.grp_start, w.grp_start, (size_t)w.n_grp + 1);
+    if (!rc) rc = upload_vec(&s.grp_rows, w.grp_rows, (size_t)2 * w.n_grp);
+    if (!rc) rc = upload_vec(&s.bw_start, w.bw_start, (size_t)w.n_trsv + 1);
+    chol_solve_level_free(&w);
+    if (rc) return rc;
+  }
+  HIPCHK(hipMalloc((void **)&d->ytmp, (size_t)d->plan->n * sizeof(double)));
+  d->solve_ready = true;
+  return 0;
+}
+
+extern "C" int cholamd_solve(cholamd_device *d, const double *d_arena, const double *d_b, double *d_x, void *stream)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  if (d->world != 1) { chol_set_error("cholamd_solve needs the complete factor on one device (partition world must be 1)"); return CHOLAMD_ERR_ARG; }
+  if (!d->solve_ready) { int rc = build_solve(d); if (rc) return rc; }
+  hipStream_t st = (hipStream_t)stream;
+  const int L = d->plan->levels, n = d->plan->n;
+  double *y = d->ytmp;
+  HIPCHK((hipError_t)chol_launch_permute(d_b, d->perm, y, n, 0, st));
+  for (int lvl = L - 1; lvl >= 0; lvl--) { // forward, mmat.rg:1395-1435
+    const solve_dev &s = d->sv[lvl];
+    HIPCHK((hipError_t)chol_launch_trsv_fwd(d_arena, s.trsv, s.n_trsv, y, st));
+    HIPCHK((hipError_t)chol_launch_gemv_fwd(d_arena, s.fw, s.grp_start, s.grp_rows, s.n_grp, y, st));
+  }
+  for (int lvl = 0; lvl < L; lvl++) { // backward, mmat.rg:1438-1479
+    const solve_dev &s = d->sv[lvl];
+    HIPCHK((hipError_t)chol_launch_bwd(d_arena, s.trsv, s.bw, s.bw_start, s.n_trsv, y, st));
+  }
+  HIPCHK((hipError_t)chol_launch_permute(y, d->perm, d_x, n, 1, st));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// L-A / L-B: stand-alone batched launches with pointer-valued descriptors (base = nullptr)
+// ---------------------------------------------------------------------------------------------
+static inline int64_t poff(const void *p) { return (int64_t)((uintptr_t)p / sizeof(double)); }
+
+struct scratch { // per-call device scratch, freed at scope exit after the stream has been synchronised
+  std::vector<void *> ptrs;
+  ~scratch() { for (void *p : ptrs) (void)hipFree(p); }
+  template <class T> int put(T **dptr, const T *h, size_t n, hipStream_t st)
+  {
+    *dptr = nullptr;
+    if (n == 0) return 0;
+    HIPCHK(hipMalloc((void **)dptr, n * sizeof(T)));
+    ptrs.push_back(*dptr);
+    HIPCHK(hipMemcpyAsync(*dptr, h, n * sizeof(T), hipMemcpyHostToDevice, st));
+    return 0;
+  }
+  template <class T> int get(T **dptr, size_t n)
+  {
+    HIPCHK(hipMalloc((void **)dptr, (n ? n : 1) * sizeof(T)));
+    ptrs.push_back(*dptr);
+    return 0;
+  }
+};
+
+static int check_ptr(const void *p, const char *what)
+{
+  if (!p || ((uintptr_t)p & 7)) { chol_set_error("%s must be a non-null, 8-byte aligned pointer", what); return CHOLAMD_ERR_ARG; }
+  return 0;
+}
+static int have_device()
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return no_device_error();
+  return 0;
+}
+
+static void add_update_tasks(std::vector<chol_upd_task> &tasks, int src_begin, int src_end, double *c, int ldc, int m, int n, bool syrk)
+{
+  const int tr = (m + 15) / 16, tc = (n + 15) / 16;
+  for (int a = 0; a < tr; a++)
+    for (int b = 0; b < tc; b++) {
+      if (syrk && b > a) continue;
+      chol_upd_task t;
+      std::memset(&t, 0, sizeof t);
+      t.c_off = poff(c) + a * 16 + (int64_t)b * 16 * ldc;
+      t.ldc = ldc;
+      t.mv = (short)(m - a * 16 < 16 ? m - a * 16 : 16);
+      t.nv = (short)(n - b * 16 < 16 ? n - b * 16 : 16);
+      t.lower = (syrk && a == b);
+      t.src_begin = src_begin; t.src_end = src_end; t.ar = a * 16; t.br = b * 16;
+      tasks.push_back(t);
+    }
+}
+
+static int run_updates(std::vector<chol_upd_task> &tasks, std::vector<chol_upd_src> &srcs, hipStream_t st)
+{
+  if (tasks.empty()) return 0;
+  scratch sc;
+  chol_upd_task *dt; chol_upd_src *ds;
+  int rc = sc.put(&dt, tasks.data(), tasks.size(), st);
+  if (!rc) rc = sc.put(&ds, srcs.data(), srcs.size(), st);
+  if (rc) return rc;
+  HIPCHK((hipError_t)chol_launch_update(nullptr, dt, ds, (int)tasks.size(), st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+// B tiles (rows m_i of width n) <- B L^-T for one pivot L (n x n, ld ldl)
+static int run_trsm(const double *Lp, int n, int ldl, const std::vector<chol_trsm_desc> &rows, hipStream_t st)
+{
+  if (rows.empty() || n == 0) return 0;
+  scratch sc;
+  double *W; chol_trsm_desc *dd;
+  const size_t nb = (size_t)(n + CHOL_NB - 1) / CHOL_NB;
+  int rc = sc.get(&W, nb * CHOL_NB * CHOL_NB);
+  if (rc) return rc;
+  HIPCHK((hipError_t)chol_launch_dinv(Lp, n, ldl, W, st));
+  std::vector<chol_trsm_desc> v;
+  for (const auto &r : rows)
+    for (int r0 = 0; r0 < r.m; r0 += CHOL_TRSM_ROWS) {
+      chol_trsm_desc t = r;
+      t.l_off = poff(Lp); t.dinv_off = poff(W); t.b_off = r.b_off + r0;
+      t.m = r.m - r0 < CHOL_TRSM_ROWS ? r.m - r0 : CHOL_TRSM_ROWS;
+      v.push_back(t);
+    }
+  rc = sc.put(&dd, v.data(), v.size(), st);
+  if (rc) return rc;
+  HIPCHK((hipError_t)chol_launch_trsm(nullptr, nullptr, dd, (int)v.size(), st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+static int run_potrf(const std::vector<chol_potrf_desc> &v, hipStream_t st, int *info_out, int *sep_out)
+{
+  if (info_out) *info_out = 0;
+  if (v.empty()) return 0;
+  scratch sc;
+  size_t wsz = 0;
+  std::vector<chol_potrf_desc> dv = v;
+  for (auto &p : dv) { p.dinv_off = (int64_t)wsz; wsz += (size_t)((p.n + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB; }
+  double *W; int *info; chol_potrf_desc *dd;
+  int rc = sc.get(&W, wsz);
+  if (!rc) rc = sc.get(&info, (size_t)2);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(info, 0, 2 * sizeof(int), st));
+  rc = sc.put(&dd, dv.data(), dv.size(), st);
+  if (rc) return rc;
+  HIPCHK((hipError_t)chol_launch_potrf(nullptr, W, dd, (int)dv.size(), info, st));
+  int h[2] = { 0, 0 };
+  HIPCHK(hipMemcpyAsync(h, info, sizeof h, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (info_out) *info_out = h[0];
+  if (sep_out) *sep_out = h[1];
+  return 0;
+}
+
+// ---- L-B: fused leaf tasks -------------------------------------------------------------------
+static double *tile_ptr(const cholamd_region *r, const cholamd_filled *f)
+{ // get_raw_ptr_2d, blas.rg:35-43
+  return r->ptr + (f->lo_x - r->lo_x) + (int64_t)(f->lo_y - r->lo_y) * r->ld;
+}
+static int region_ok(const cholamd_region *r, const char *name)
+{
+  if (!r) { chol_set_error("region %s is null", name); return CHOLAMD_ERR_ARG; }
+  return check_ptr(r->ptr, name);
+}
+static int tile_inside(const cholamd_region *r, const cholamd_filled *f)
+{
+  if (f->lo_x < r->lo_x || f->lo_y < r->lo_y || f->hi_x > r->hi_x || f->hi_y > r->hi_y) {
+    chol_set_error("tile (%d,%d,%d) lies outside its region", f->sep_x, f->sep_y, f->cluster);
+    return CHOLAMD_ERR_ARG;
+  }
+  return 0;
+}
+
+extern "C" int cholamd_fused_dpotrf(const cholamd_region *rA, const cholamd_filled *fa, int nA, int level, int interval, int debug, void *stream)
+{
+  int rc = have_device();
+  if (!rc) rc = region_ok(rA, "rA");
+  if (rc) return rc;
+  std::vector<chol_potrf_desc> v;
+  for (int i = 0; i < nA; i++) {
+    if ((rc = tile_inside(rA, &fa[i]))) return rc;
+    const int m = fa[i].hi_x - fa[i].lo_x + 1;
+    if (debug)
+      printf("POTRF: {'A': (%d, %d, %d), 'A_Lo': (%d, %d), 'A_Hi': (%d, %d), 'SizeA': (%d, %d), 'Block': (%d, %d), 'Level': %d, 'Interval': %d}\n",
+             fa[i].sep_x, fa[i].sep_y, fa[i].cluster, fa[i].lo_x, fa[i].lo_y, fa[i].hi_x, fa[i].hi_y, m, fa[i].hi_y - fa[i].lo_y + 1,
+             fa[i].sep_x, fa[i].sep_y, level, interval);
+    if (m == 0) continue; // blas.rg:68
+    chol_potrf_desc p = { poff(tile_ptr(rA, &fa[i])), 0, m, rA->ld, fa[i].sep_x, 0 };
+    v.push_back(p);
+  }
+  int info = 0;
+  rc = run_potrf(v, (hipStream_t)stream, &info, nullptr);
+  return rc ? rc : info;
+}
+
+extern "C" int cholamd_fused_dtrsm(const cholamd_region *rA, const cholamd_region *rB, const cholamd_filled *fa, int nA,
+                                   const cholamd_filled *fb, int nB, int level, int interval, int debug, void *stream)
+{
+  int rc = have_device();
+  if (!rc) rc = region_ok(rA, "rA");
+  if (!rc) rc = region_ok(rB, "rB");
+  if (rc) return rc;
+  for (int i = 0; i < nA; i++) {
+    if ((rc = tile_inside(rA, &fa[i]))) return rc;
+    const double *Lp = tile_ptr(rA, &fa[i]);
+    std::vector<chol_trsm_desc> rows;
+    int n = 0;
+    for (int j = 0; j < nB; j++) {
+      if ((rc = tile_inside(rB, &fb[j]))) return rc;
+      const int m = fb[j].hi_x - fb[j].lo_x + 1;
+      n = fb[j].hi_y - fb[j].lo_y + 1;
+      if (debug)
+        printf("TRSM: {'A': (%d, %d, %d), 'A_Lo': (%d, %d), 'A_Hi': (%d, %d), 'SizeA': (%d, %d), 'B': (%d, %d, %d), 'B_Lo': (%d, %d), 'B_Hi': (%d, %d), 'SizeB': (%d, %d), 'Block': (%d, %d), 'Level': %d, 'Interval': %d}\n",
+               fa[i].sep_x, fa[i].sep_y, fa[i].cluster, fa[i].lo_x, fa[i].lo_y, fa[i].hi_x, fa[i].hi_y, fa[i].hi_x - fa[i].lo_x + 1, fa[i].hi_y - fa[i].lo_y + 1,
+               fb[j].sep_x, fb[j].sep_y, fb[j].cluster, fb[j].lo_x, fb[j].lo_y, fb[j].hi_x, fb[j].hi_y, m, n, fb[j].sep_x, fb[j].sep_y, level, interval);
+      if (n != fa[i].hi_x - fa[i].lo_x + 1) { chol_set_error("TRSM: B tile width %d != pivot size %d", n, fa[i].hi_x - fa[i].lo_x + 1); return CHOLAMD_ERR_ARG; }
+      chol_trsm_desc t = { 0, 0, poff(tile_ptr(rB, &fb[j])), n, rA->ld, m, rB->ld };
+      rows.push_back(t);
+    }
+    if ((rc = run_trsm(Lp, n, rA->ld, rows, (hipStream_t)stream))) return rc;
+  }
+  return 0;
+}
+
+static int fused_update(const cholamd_region *rA, const cholamd_region *rB, const cholamd_region *rC,
+                        const cholamd_filled *fa, int nA, const cholamd_filled *fb, int nB, const cholamd_filled *fc, int nC,
+                        int ccs, int level, int interval, int debug, void *stream, bool is_syrk)
+{
+  int rc = have_device();
+  if (!rc) rc = region_ok(rA, "rA");
+  if (!rc) rc = region_ok(rB, "rB");
+  if (!rc) rc = region_ok(rC, "rC");
+  if (rc) return rc;
+  std::vector<chol_upd_task> tasks;
+  std::vector<chol_upd_src> srcs;
+  for (int i = 0; i < nA; i++) {
+    const cholamd_filled &a = fa[i];
+    if ((rc = tile_inside(rA, &a))) return rc;
+    const int row = a.cluster, sAx = a.hi_x - a.lo_x + 1, sAy = a.hi_y - a.lo_y + 1;
+    for (int j = 0; j < nB; j++) {
+      const cholamd_filled &b = fb[j];
+      if ((rc = tile_inside(rB, &b))) return rc;
+      const int col = b.cluster, sBx = b.hi_x - b.lo_x + 1;
+      const int cz = row * ccs + col;
+      const cholamd_filled *c = nullptr;
+      for (int k = 0; k < nC; k++) // the reference's linear search, blas.rg:385-392 / 468-475
+        if (fc[k].sep_x == a.sep_x && fc[k].sep_y == b.sep_x && fc[k].cluster == cz) { c = &fc[k]; break; }
+      if (!c) continue;
+      if ((rc = tile_inside(rC, c))) return rc;
+      const int sCx = c->hi_x - c->lo_x + 1, sCy = c->hi_y - c->lo_y + 1;
+      if (sCx <= 0 || sCy <= 0) continue;
+      if (is_syrk && col > row) continue;
+      if (debug)
+        printf("GEMM: {'A': (%d, %d, %d), 'A_Lo': (%d, %d), 'A_Hi': (%d, %d), 'sizeA': (%d, %d), 'B': (%d, %d, %d), 'B_Lo': (%d, %d), 'B_Hi': (%d, %d), 'sizeB': (%d, %d), 'C': (%d, %d, %d), 'C_Lo': (%d, %d), 'C_Hi': (%d, %d), 'sizeC': (%d, %d), 'Block': (%d, %d), 'Level': %d, 'Interval': %d}\n",
+               a.sep_x, a.sep_y, a.cluster, a.lo_x, a.lo_y, a.hi_x, a.hi_y, sAx, sAy, b.sep_x, b.sep_y, b.cluster, b.lo_x, b.lo_y, b.hi_x, b.hi_y, sBx, b.hi_y - b.lo_y + 1,
+               c->sep_x, c->sep_y, c->cluster, c->lo_x, c->lo_y, c->hi_x, c->hi_y, sCx, sCy, c->sep_x, c->sep_y, level, interval);
+      const bool syrk = is_syrk && col == row;
+      chol_upd_src s = { poff(tile_ptr(rA, &a)), poff(tile_ptr(rB, &b)), rA->ld, rB->ld, sAy, 0 };
+      srcs.push_back(s);
+      // distinct (a, b) pairs address distinct C tiles inside one fused task, so one source per task group
+      add_update_tasks(tasks, (int)srcs.size() - 1, (int)srcs.size(), tile_ptr(rC, c), rC->ld, syrk ? sCx : sAx, syrk ? sCx : sBx, syrk);
+    }
+  }
+  return run_updates(tasks, srcs, (hipStream_t)stream);
+}
+
+extern "C" int cholamd_fused_dsyrk(const cholamd_region *rA, const cholamd_region *rB, const cholamd_region *rC,
+                                   const cholamd_filled *fa, int nA, const cholamd_filled *fb, int nB, const cholamd_filled *fc, int nC,
+                                   int ccs, int level, int interval, int debug, void *stream)
+{
+  return fused_update(rA, rB, rC, fa, nA, fb, nB, fc, nC, ccs, level, interval, debug, stream, true);
+}
+extern "C" int cholamd_fused_dgemm(const cholamd_region *rA, const cholamd_region *rB, const cholamd_region *rC,
+                                   const cholamd_filled *fa, int nA, const cholamd_filled *fb, int nB, const cholamd_filled *fc, int nC,
+                                   int ccs, int level, int interval, int debug, void *stream)
+{
+  return fused_update(rA, rB, rC, fa, nA, fb, nB, fc, nC, ccs, level, interval, debug, stream, false);
+}
+
+// ---- L-A: device-pointer BLAS ----------------------------------------------------------------
+extern "C" int cholamd_dpotrf_dev(int n, double *d_a, int lda, int *d_info, void *stream)
+{
+  int rc = have_device();
+  if (rc) return rc;
+  if (n < 0 || lda < (n > 1 ? n : 1)) { chol_set_error("dpotrf: bad n/lda"); return CHOLAMD_ERR_ARG; }
+  if (n == 0) return 0;
+  if ((rc = check_ptr(d_a, "a"))) return rc;
+  std::vector<chol_potrf_desc> v(1);
+  v[0] = { poff(d_a), 0, n, lda, 0, 0 };
+  int info = 0;
+  rc = run_potrf(v, (hipStream_t)stream, &info, nullptr);
+  if (rc) return rc;
+  if (d_info) HIPCHK(hipMemcpy(d_info, &info, sizeof(int), hipMemcpyHostToDevice));
+  return info;
+}
+extern "C" int cholamd_dtrsm_dev(int m, int n, const double *d_a, int lda, double *d_b, int ldb, void *stream)
+{
+  int rc = have_device();
+  if (rc) return rc;
+  if (m < 0 || n < 0 || lda < (n > 1 ? n : 1) || ldb < (m > 1 ? m : 1)) { chol_set_error("dtrsm: bad sizes"); return CHOLAMD_ERR_ARG; }
+  if (m == 0 || n == 0) return 0;
+  if ((rc = check_ptr(d_a, "a")) || (rc = check_ptr(d_b, "b"))) return rc;
+  std::vector<chol_trsm_desc> rows(1);
+  rows[0] = { 0, 0, poff(d_b), n, lda, m, ldb };
+  return run_trsm(d_a, n, lda, rows, (hipStream_t)stream);
+}
+extern "C" int cholamd_dgemm_dev(int m, int n, int k, const double *d_a, int lda, const double *d_b, int ldb, double *d_c, int ldc, void *stream)
+{
+  int rc = have_device();
+  if (rc) return rc;
+  if (m < 0 || n < 0 || k < 0 || lda < (m > 1 ? m : 1) || ldb < (n > 1 ? n : 1) || ldc < (m > 1 ? m : 1)) { chol_set_error("dgemm: bad sizes"); return CHOLAMD_ERR_ARG; }
+  if (m == 0 || n == 0 || k == 0) return 0;
+  if ((rc = check_ptr(d_a, "a")) || (rc = check_ptr(d_b, "b")) || (rc = check_ptr(d_c, "c"))) return rc;
+  std::vector<chol_upd_task> tasks;
+  std::vector<chol_upd_src> srcs(1);
+  srcs[0] = { poff(d_a), poff(d_b), lda, ldb, k, 0 };
+  add_update_tasks(tasks, 0, 1, d_c, ldc, m, n, false);
+  return run_updates(tasks, srcs, (hipStream_t)stream);
+}
+extern "C" int cholamd_dsyrk_dev(int n, int k, const double *d_a, int lda, double *d_c, int ldc, void *stream)
+{
+  int rc = have_device();
+  if (rc) return rc;
+  if (n < 0 || k < 0 || lda < (n > 1 ? n : 1) || ldc < (n > 1 ? n : 1)) { chol_set_error("dsyrk: bad sizes"); return CHOLAMD_ERR_ARG; }
+  if (n == 0 || k == 0) return 0;
+  if ((rc = check_ptr(d_a, "a")) || (rc = check_ptr(d_c, "c"))) return rc;
+  std::vector<chol_upd_task> tasks;
+  std::vector<chol_upd_src> srcs(1);
+  srcs[0] = { poff(d_a), poff(d_a), lda, lda, k, 0 };
+  add_update_tasks(tasks, 0, 1, d_c, ldc, n, n, true);
+  return run_updates(tasks, srcs, (hipStream_t)stream);
+}
+extern "C" int cholamd_dtrsv_dev(int trans, int n, const double *d_a, int lda, double *d_x, void *stream)
+{
+  int rc = have_device();
+  if (rc) return rc;
+  if (n < 0 || lda < (n > 1 ? n : 1) || (trans != CholamdNoTrans && trans != CholamdTrans)) { chol_set_error("dtrsv: bad arguments"); return CHOLAMD_ERR_ARG; }
+  if (n == 0) return 0;
+  if ((rc = check_ptr(d_a, "a")) || (rc = check_ptr(d_x, "x"))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  scratch sc;
+  chol_trsv_desc t = { poff(d_a), n, lda, 0, 0 };
+  chol_trsv_desc *dt;
+  if ((rc = sc.put(&dt, &t, 1, st))) return rc;
+  if (trans == CholamdNoTrans) {
+    HIPCHK((hipError_t)chol_launch_trsv_fwd(nullptr, dt, 1, d_x, st));
+  } else {
+    int zero2[2] = { 0, 0 };
+    int *ds;
+    if ((rc = sc.put(&ds, zero2, 2, st))) return rc;
+    HIPCHK((hipError_t)chol_launch_bwd(nullptr, dt, nullptr, ds, 1, d_x, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+extern "C" int cholamd_dgemv_dev(int trans, int m, int n, const double *d_a, int lda, const double *d_x, double *d_y, void *stream)
+{
+  int rc = have_device();
+  if (rc) return rc;
+  if (m < 0 || n < 0 || lda < (m > 1 ? m : 1) || (trans != CholamdNoTrans && trans != CholamdTrans)) { chol_set_error("dgemv: bad arguments"); return CHOLAMD_ERR_ARG; }
+  if (m == 0 || n == 0) return 0;
+  if ((rc = check_ptr(d_a, "a")) || (rc = check_ptr(d_x, "x")) || (rc = check_ptr(d_y, "y"))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  scratch sc;
+  if (trans == CholamdNoTrans) { // y(m) -= A x(n): the forward kernel with pointer-valued offsets
+    std::vector<chol_gemv_desc> g;
+    std::vector<int> gs, gr;
+    for (int row0 = 0; row0 < m; row0 += 256) {
+      gs.push_back((int)g.size());
+      gr.push_back(row0); gr.push_back(0);
+      chol_gemv_desc d = { poff(d_a), m, n, lda, 0, 0 };
+      g.push_back(d);
+    }
+    gs.push_back((int)g.size());
+    // vectors are addressed relative to y: x_off = x - y in doubles
+    for (auto &d : g) d.x_off = (int)(poff(d_x) - poff(d_y));
+    chol_gemv_desc *dg; int *dgs, *dgr;
+    if ((rc = sc.put(&dg, g.data(), g.size(), st)) || (rc = sc.put(&dgs, gs.data(), gs.size(), st)) || (rc = sc.put(&dgr, gr.data(), gr.size(), st))) return rc;
+    if (poff(d_x) - poff(d_y) != (int64_t)(int)(poff(d_x) - poff(d_y))) { chol_set_error("dgemv: x and y too far apart"); return CHOLAMD_ERR_ARG; }
+    HIPCHK((hipError_t)chol_launch_gemv_fwd(nullptr, dg, dgs, dgr, (int)gs.size() - 1, d_y, st));
+  } else { // y(n) -= A^T x(m): the backward kernel with an empty triangle (n = 0) does only the gather
+    chol_trsv_desc t = { 0, 0, 1, 0, 0 };
+    chol_gemv_desc d = { poff(d_a), m, n, lda, (int)(poff(d_x) - poff(d_y)), 0 };
+    if (poff(d_x) - poff(d_y) != (int64_t)d.x_off) { chol_set_error("dgemv: x and y too far apart"); return CHOLAMD_ERR_ARG; }
+    int start[2] = { 0, 1 };
+    chol_trsv_desc *dt; chol_gemv_desc *dg; int *ds;
+    if ((rc = sc.put(&dt, &t, 1, st)) || (rc = sc.put(&dg, &d, 1, st)) || (rc = sc.put(&ds, start, 2, st))) return rc;
+    HIPCHK((hipError_t)chol_launch_bwd(nullptr, dt, dg, ds, 1, d_y, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+// ---- L-A: host-pointer CBLAS / LAPACKE replacements -------------------------------------------
+static thread_local int g_blas_status = 0;
+extern "C" int cholamd_blas_status(void) { return g_blas_status; }
+extern "C" void cholamd_openblas_set_num_threads(int) {} // mmat.rg:1057: parallelism is the GPU's
+
+struct host_mat { // a host matrix mirrored on the device for the duration of one call
+  double *d = nullptr; double *h = nullptr; int rows = 0, cols = 0, ld = 0; bool writeback = false;
+  int up(const double *hp, int r, int c, int ldh, bool wb)
+  {
+    h = const_cast<double *>(hp); rows = r; cols = c; ld = ldh; writeback = wb;
+    if (r == 0 || c == 0) return 0;
+    HIPCHK(hipMalloc((void **)&d, (size_t)ld * cols * sizeof(double)));
+    HIPCHK(hipMemcpy(d, h, ((size_t)ld * (cols - 1) + rows) * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+  }
+  int down()
+  {
+    if (d && writeback) HIPCHK(hipMemcpy2D(h, (size_t)ld * sizeof(double), d, (size_t)ld * sizeof(double), (size_t)rows * sizeof(double), cols, hipMemcpyDeviceToHost));
+    return 0;
+  }
+  ~host_mat() { if (d) (void)hipFree(d); }
+};
+
+extern "C" int cholamd_LAPACKE_dpotrf(int layout, char uplo, int n, double *a, int lda)
+{
+  g_blas_status = 0;
+  if (layout != CholamdColMajor || (uplo != 'L' && uplo != 'l')) { chol_set_error("LAPACKE_dpotrf: only ColMajor/'L' (blas.rg:71)"); return g_blas_status = CHOLAMD_ERR_ARG; }
+  int rc = have_device();
+  if (rc) return g_blas_status = rc;
+  if (n == 0) return 0;
+  host_mat A;
+  if ((rc = A.up(a, n, n, lda, true))) return g_blas_status = rc;
+  int info = cholamd_dpotrf_dev(n, A.d, lda, nullptr, nullptr);
+  if (info < 0) return g_blas_status = info;
+  if ((rc = A.down())) return g_blas_status = rc;
+  return info;
+}
+extern "C" void cholamd_cblas_dtrsm(int layout, int side, int uplo, int transa, int diag, int m, int n, double alpha,
+                                    const double *a, int lda, double *b, int ldb)
+{
+  g_blas_status = 0;
+  if (layout != CholamdColMajor || side != CholamdRight || uplo != CholamdLower || transa != CholamdTrans || diag != CholamdNonUnit || alpha != 1.0) {
+    chol_set_error("cblas_dtrsm: only ColMajor/Right/Lower/Trans/NonUnit/alpha=1 (blas.rg:99)");
+    g_blas_status = CHOLAMD_ERR_ARG; return;
+  }
+  int rc = have_device();
+  if (rc) { g_blas_status = rc; return; }
+  host_mat A, B;
+  if ((rc = A.up(a, n, n, lda, false)) || (rc = B.up(b, m, n, ldb, true))) { g_blas_status = rc; return; }
+  if ((rc = cholamd_dtrsm_dev(m, n, A.d, lda, B.d, ldb, nullptr)) || (rc = B.down())) g_blas_status = rc;
+}
+extern "C" void cholamd_cblas_dgemm(int layout, int transa, int transb, int m, int n, int k, double alpha, const double *a, int lda,
+                                    const double *b, int ldb, double beta, double *c, int ldc)
+{
+  g_blas_status = 0;
+  if (layout != CholamdColMajor || transa != CholamdNoTrans || transb != CholamdTrans || alpha != -1.0 || beta != 1.0) {
+    chol_set_error("cblas_dgemm: only ColMajor/NoTrans/Trans/alpha=-1/beta=1 (blas.rg:139)");
+    g_blas_status = CHOLAMD_ERR_ARG; return;
+  }
+  int rc = have_device();
+  if (rc) { g_blas_status = rc; return; }
+  host_mat A, B, C;
+  if ((rc = A.up(a, m, k, lda, false)) || (rc = B.up(b, n, k, ldb, false)) || (rc = C.up(c, m, n, ldc, true))) { g_blas_status = rc; return; }
+  if ((rc = cholamd_dgemm_dev(m, n, k, A.d, lda, B.d, ldb, C.d, ldc, nullptr)) || (rc = C.down())) g_blas_status = rc;
+}
+extern "C" void cholamd_cblas_dsyrk(int layout, int uplo, int trans, int n, int k, double alpha, const double *a, int lda,
+                                    double beta, double *c, int ldc)
+{
+  g_blas_status = 0;
+  if (layout != CholamdColMajor || uplo != CholamdLower || trans != CholamdNoTrans || alpha != -1.0 || beta != 1.0) {
+    chol_set_error("cblas_dsyrk: only ColMajor/Lower/NoTrans/alpha=-1/beta=1 (blas.rg:187)");
+    g_blas_status = CHOLAMD_ERR_ARG; return;
+  }
+  int rc = have_device();
+  if (rc) { g_blas_status = rc; return; }
+  host_mat A, C;
+  if ((rc = A.up(a, n, k, lda, false)) || (rc = C.up(c, n, n, ldc, true))) { g_blas_status = rc; return; }
+  if ((rc = cholamd_dsyrk_dev(n, k, A.d, lda, C.d, ldc, nullptr)) || (rc = C.down())) g_blas_status = rc;
+}
+extern "C" void cholamd_cblas_dtrsv(int layout, int uplo, int transa, int diag, int n, const double *a, int lda, double *x, int incx)
+{
+  g_blas_status = 0;
+  if (layout != CholamdColMajor || uplo != CholamdLower || diag != CholamdNonUnit || incx != 1 || (transa != CholamdNoTrans && transa != CholamdTrans)) {
+    chol_set_error("cblas_dtrsv: only ColMajor/Lower/NonUnit/incx=1 (blas.rg:226)");
+    g_blas_status = CHOLAMD_ERR_ARG; return;
+  }
+  int rc = have_device();
+  if (rc) { g_blas_status = rc; return; }
+  host_mat A, X;
+  if ((rc = A.up(a, n, n, lda, false)) || (rc = X.up(x, n, 1, n > 1 ? n : 1, true))) { g_blas_status = rc; return; }
+  if ((rc = cholamd_dtrsv_dev(transa, n, A.d, lda, X.d, nullptr)) || (rc = X.down())) g_blas_status = rc;
+}
+extern "C" void cholamd_cblas_dgemv(int layout, int trans, int m, int n, double alpha, const double *a, int lda, const double *x, int incx,
+                                    double beta, double *y, int incy)
+{
+  g_blas_status = 0;
+  if (layout != CholamdColMajor || alpha != -1.0 || beta != 1.0 || incx != 1 || incy != 1 || (trans != CholamdNoTrans && trans != CholamdTrans)) {
+    chol_set_error("cblas_dgemv: only ColMajor/alpha=-1/beta=1/inc=1 (blas.rg:263)");
+    g_blas_status = CHOLAMD_ERR_ARG; return;
+  }
+  int rc = have_device();
+  if (rc) { g_blas_status = rc; return; }
+  const int lx = trans == CholamdNoTrans ? n : m, ly = trans == CholamdNoTrans ? m : n;
+  if (m == 0 || n == 0) return;
+  // x and y share one device buffer so that 32-bit relative offsets always suffice
+  double *xy = nullptr;
+  if (hipMalloc((void **)&xy, (size_t)(lx + ly) * sizeof(double)) != hipSuccess) { g_blas_status = CHOLAMD_ERR_HIP; return; }
+  host_mat A;
+  rc = A.up(a, m, n, lda, false);
+  if (!rc && hipMemcpy(xy, x, (size_t)lx * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = CHOLAMD_ERR_HIP;
+  if (!rc && hipMemcpy(xy + lx, y, (size_t)ly * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = CHOLAMD_ERR_HIP;
+  if (!rc) rc = cholamd_dgemv_dev(trans, m, n, A.d, lda, xy, xy + lx, nullptr);
+  if (!rc && hipMemcpy(y, xy + lx, (size_t)ly * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = CHOLAMD_ERR_HIP;
+  (void)hipFree(xy);
+  g_blas_status = rc;
+}

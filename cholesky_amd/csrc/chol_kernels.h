@@ -1,0 +1,22 @@
+/* Launchers of the HIP kernels in chol_kernels.hip (internal). */
+#ifndef CHOL_KERNELS_H
+#define CHOL_KERNELS_H
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include "chol_plan.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+int chol_launch_scatter(double *arena, const int64_t *dst, const double *val, int64_t nnz, hipStream_t st);
+int chol_launch_potrf(double *base, double *ws, const chol_potrf_desc *descs, int n, int *info, hipStream_t st);
+int chol_launch_dinv(const double *L, int n, int ldl, double *W, hipStream_t st);
+int chol_launch_trsm(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st);
+int chol_launch_update(double *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st);
+int chol_launch_permute(const double *in, const int *perm, double *out, int n, int inverse, hipStream_t st);
+int chol_launch_trsv_fwd(const double *base, const chol_trsv_desc *descs, int n, double *y, hipStream_t st);
+int chol_launch_gemv_fwd(const double *base, const chol_gemv_desc *descs, const int *grp_start, const int *grp_rows, int ngroups, double *y, hipStream_t st);
+int chol_launch_bwd(const double *base, const chol_trsv_desc *descs, const chol_gemv_desc *gd, const int *gstart, int n, double *y, hipStream_t st);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,140 @@
+/* Internal host-side data model of libcholamd (not installed; the public ABI is include/cholamd.h).
+ *
+ * Storage layout (the MI355X-first replacement of the mapper's per-block instances,
+ * cholesky.cc:65-73): ONE contiguous fp64 arena holding one column-major PANEL per separator s.
+ * Panel(s) has the separator's own columns (n_s of them) and the rows of s followed by the rows
+ * of every ancestor of s in increasing permuted position (parent, grand-parent, ..., root), so
+ * block (anc, s) of the reference is the row slice [row_off(anc) .. +n_anc) of panel(s) with the
+ * panel's leading dimension.  Panels are laid out by ascending label, hence the panels of the top
+ * of the tree (root last) form a contiguous tail of the arena -- the extend-add exchange buffer of
+ * the multi-GPU driver.
+ */
+#ifndef CHOL_PLAN_H
+#define CHOL_PLAN_H
+
+#include <stdint.h>
+#include "cholamd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHOL_NB 32 /* diagonal-block width of the blocked POTRF/TRSM kernels */
+
+typedef struct {
+  int n_int;    /* number of intervals */
+  int *len;     /* boundary-list length per interval */
+  int **raw;    /* boundary lists as in the file (interval t>0 indexes interval t-1) */
+  int **start;  /* resolved to dof offsets inside the separator: start[t][i], i < len[t] */
+} chol_clusters;
+
+typedef struct {
+  int r, c;                       /* labels */
+  int lo_x, lo_y, hi_x, hi_y;     /* permuted coords, inclusive */
+  int rows, cols, ld;
+  int64_t off;                    /* arena offset (doubles) of element (lo_x, lo_y) */
+} chol_block;
+
+/* device-side work descriptors (shared with the kernels; plain ints / int64 offsets in doubles
+ * relative to a base pointer passed at launch) */
+typedef struct {
+  int64_t a_off;      /* diagonal block */
+  int64_t dinv_off;   /* workspace offset of this separator's inverted diagonal NBxNB blocks */
+  int n, lda;
+  int sep;            /* label (for info reporting) */
+  int pad;
+} chol_potrf_desc;
+
+typedef struct {
+  int64_t l_off;      /* pivot block (n x n, ld ldl) */
+  int64_t dinv_off;
+  int64_t b_off;      /* first row of this row chunk inside the panel */
+  int n, ldl, m, ldb; /* m rows (<= CHOL_TRSM_ROWS) */
+} chol_trsm_desc;
+
+#define CHOL_TRSM_ROWS 32
+
+typedef struct {
+  int64_t a_off, b_off; /* first row of the A tile rows / B tile rows used by this task */
+  int lda, ldb, k, pad;
+} chol_upd_src;
+
+typedef struct {
+  int64_t c_off;      /* top-left element of this 16x16 (or smaller) output sub-tile */
+  int ldc;
+  short mv, nv;       /* valid rows / cols (<= 16) */
+  int lower;          /* 1: diagonal sub-tile of a SYRK target, store only row >= col */
+  int src_begin, src_end;
+  int ar, br;         /* row offset of this sub-tile inside the A tile rows / B tile rows */
+  int pad;
+} chol_upd_task;
+
+typedef struct {
+  int level;
+  int n_potrf; chol_potrf_desc *potrf;
+  int n_trsm; chol_trsm_desc *trsm;
+  int n_task; chol_upd_task *task;
+  int n_src; chol_upd_src *src;
+} chol_level_work;
+
+/* solve-phase descriptors */
+typedef struct {
+  int64_t a_off; int n, lda; int x_off; int sep;
+} chol_trsv_desc;
+typedef struct {
+  int64_t a_off; int m, n, lda; int x_off, y_off; /* y(m) -= A x(n)  or  y(n) -= A^T x(m) */
+} chol_gemv_desc;
+
+struct cholamd_plan {
+  int n, nz_file, levels, nsep, max_int_size;
+  char banner[160];
+  MM_typecode typecode;
+  int *perm;        /* dof at permuted position */
+  int *iperm;       /* permuted position of dof */
+  int *sep_of_pos;  /* label per permuted position */
+  int *sep_size, *sep_off;        /* index 1..nsep */
+  int *tree;                      /* heap index 1..nsep -> label */
+  int *heap_of, *level_of;        /* label -> heap index / tree level */
+  chol_clusters *cl;              /* index 1..nsep */
+  int nblk; chol_block *blk;
+  int *blk_index;                 /* (nsep+1)^2 -> index into blk or -1 */
+  int64_t *panel_off; int *panel_ld, *panel_rows; /* per label */
+  int64_t arena;                  /* doubles */
+  int64_t ws_doubles;             /* workspace (inverted diagonal blocks) */
+  int64_t *dinv_off;              /* per label */
+  /* tril(A) mapped into the arena */
+  int64_t nnz_a, dropped; int64_t *a_dst; double *a_val;
+  /* fill snapshots per interval label */
+  int64_t *snap_n; cholamd_filled **snap;
+  /* reference-order BLAS call list */
+  int64_t nops, cap_ops; cholamd_op *ops;
+  int64_t calls[16][4]; double flops[16][4];
+  int64_t nnz_l;      /* exact scalar-symbolic nnz(L) of P A P^T */
+  int64_t nnz_tiles;  /* area of the filled tiles the schedule touches (>= nnz_l) */
+  double fmin;        /* sum_j colcount_j^2, the lower bound F_min of SURVEY 8d */
+};
+
+/* chol_symbolic.c */
+int chol_plan_finish(struct cholamd_plan *p, int nz, const int *a_row, const int *a_col, const double *a_val);
+const chol_block *chol_plan_block(const struct cholamd_plan *p, int r, int c);
+int chol_ntiles(const struct cholamd_plan *p, int sep, int interval);
+/* Build the device work lists of one tree level for (rank, world); caller frees with chol_level_work_free */
+int chol_build_level_work(const struct cholamd_plan *p, int level, int rank, int world, chol_level_work *out);
+void chol_level_work_free(chol_level_work *w);
+int chol_owner_of(const struct cholamd_plan *p, int label, int world); /* -1: shared top of the tree */
+int chol_split_level(int world);
+/* solve lists of one tree level; caller frees with chol_solve_level_free */
+typedef struct {
+  int n_trsv; chol_trsv_desc *trsv;                 /* one per separator of the level (forward and backward) */
+  int n_fw; chol_gemv_desc *fw;                     /* forward sources, grouped by target row chunk */
+  int n_grp; int *grp_start; int *grp_rows;         /* grp_start[n_grp+1]; grp_rows = (row0, y_off) pairs */
+  int n_bw; chol_gemv_desc *bw; int *bw_start;      /* backward sources per separator: bw_start[n_trsv+1] */
+} chol_solve_level;
+int chol_build_solve_level(const struct cholamd_plan *p, int level, chol_solve_level *out);
+void chol_solve_level_free(chol_solve_level *w);
+void chol_set_error(const char *fmt, ...);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,103 @@
+"""Device-side driver objects: the level schedule of mmat.rg:1227-1355 on one MI355X.
+
+torch is used for what it is good at here -- device buffers, streams, torch.distributed (RCCL) --
+and every numeric step is a call into libcholamd.so with raw pointers."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, load
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return None
+    if hasattr(stream, "cuda_stream"):
+        return C.c_void_p(stream.cuda_stream)
+    return C.c_void_p(int(stream))
+
+
+class Device:
+    KINDS = ("potrf", "trsm", "update", "other")
+
+    def __init__(self, plan, device_id=0):
+        self.L = load()
+        self.plan = plan
+        self.device_id = device_id
+        h = C.c_void_p()
+        check(self.L.cholamd_device_create(plan.h, device_id, C.byref(h)), "cholamd_device_create")
+        self.h = h
+        self._owned = []
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                for p in self._owned:
+                    self.L.cholamd_device_free(self.h, p)
+                self.L.cholamd_device_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # -- memory ---------------------------------------------------------------------------------
+    def alloc(self, doubles):
+        """Library-owned device buffer (hipMalloc); returns the raw pointer as int."""
+        p = C.c_void_p()
+        check(self.L.cholamd_device_alloc(self.h, int(doubles), C.byref(p)), "cholamd_device_alloc")
+        self._owned.append(p)
+        return p.value
+
+    def new_arena(self):
+        """A torch fp64 CUDA tensor of the arena size (caller-owned buffer, like Legion's regions)."""
+        import torch
+        return torch.empty(self.plan.arena_doubles, dtype=torch.float64, device=f"cuda:{self.device_id}")
+
+    @staticmethod
+    def ptr(t):
+        return C.c_void_p(t if isinstance(t, int) else t.data_ptr())
+
+    def upload(self, dptr, host, stream=None):
+        host = np.ascontiguousarray(host, dtype=np.float64)
+        check(self.L.cholamd_device_upload(self.h, self.ptr(dptr), host.ctypes.data, host.size, _stream_ptr(stream)), "upload")
+
+    def download(self, dptr, doubles, stream=None):
+        out = np.empty(int(doubles), dtype=np.float64)
+        check(self.L.cholamd_device_download(self.h, out.ctypes.data, self.ptr(dptr), out.size, _stream_ptr(stream)), "download")
+        return out
+
+    def sync(self, stream=None):
+        check(self.L.cholamd_device_sync(self.h, _stream_ptr(stream)), "sync")
+
+    # -- the path -------------------------------------------------------------------------------
+    def fill(self, arena, stream=None):
+        """A scatter on the device: fill_block for every block (mmat.rg:1216-1224)."""
+        check(self.L.cholamd_device_fill(self.h, self.ptr(arena), _stream_ptr(stream)), "cholamd_device_fill")
+
+    def factor(self, arena, stream=None):
+        """The level loop (mmat.rg:1227-1355), asynchronous on `stream`."""
+        check(self.L.cholamd_factor(self.h, self.ptr(arena), _stream_ptr(stream)), "cholamd_factor")
+
+    def factor_levels(self, arena, level_hi, level_lo, stream=None):
+        check(self.L.cholamd_factor_levels(self.h, self.ptr(arena), level_hi, level_lo, _stream_ptr(stream)), "cholamd_factor_levels")
+
+    def set_partition(self, rank, world):
+        check(self.L.cholamd_device_set_partition(self.h, rank, world), "cholamd_device_set_partition")
+
+    def info(self):
+        sep = C.c_int(0)
+        rc = self.L.cholamd_factor_info(self.h, C.byref(sep))
+        if rc < 0:
+            check(rc, "cholamd_factor_info")
+        return rc, sep.value
+
+    def solve(self, arena, b, x, stream=None):
+        check(self.L.cholamd_solve(self.h, self.ptr(arena), self.ptr(b), self.ptr(x), _stream_ptr(stream)), "cholamd_solve")
+
+    def set_timing(self, on):
+        check(self.L.cholamd_device_set_timing(self.h, int(on)), "set_timing")
+
+    def get_timing(self):
+        ms = np.zeros(4, dtype=np.float32)
+        cnt = np.zeros(4, dtype=np.int32)
+        check(self.L.cholamd_device_get_timing(self.h, ms.ctypes.data, cnt.ctypes.data), "get_timing")
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KINDS)}

@@ -1,0 +1,155 @@
+"""Host-side plan: ingest + symbolic analysis (the part of mmat.rg's main before the level loop,
+mmat.rg:1097-1209), computed by the C library."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._lib import Filled, Op, check, load
+
+OP_NAMES = ("POTRF", "TRSM", "SYRK", "GEMM")
+
+
+class Plan:
+    def __init__(self, matrix_file=None, separator_file=None, clusters_file=None, _handle=None):
+        self.L = load()
+        if _handle is not None:
+            self.h = _handle
+        else:
+            h = C.c_void_p()
+            check(self.L.cholamd_plan_create(os.fsencode(matrix_file), os.fsencode(separator_file), os.fsencode(clusters_file), C.byref(h)),
+                  "cholamd_plan_create")
+            self.h = h
+        g = self.L
+        self.n = g.cholamd_plan_n(self.h)
+        self.nz = g.cholamd_plan_nz(self.h)
+        self.levels = g.cholamd_plan_levels(self.h)
+        self.nsep = g.cholamd_plan_num_separators(self.h)
+        self.num_blocks = g.cholamd_plan_num_blocks(self.h)
+        self.arena_doubles = g.cholamd_plan_arena_doubles(self.h)
+        self.flops = g.cholamd_plan_flops(self.h)          # F_ref
+        self.alg_bytes = g.cholamd_plan_alg_bytes(self.h)  # B_alg
+        self.nnz_a = g.cholamd_plan_nnz_a(self.h)
+        self.nnz_l = g.cholamd_plan_nnz_l(self.h)
+        self.nnz_tiles = g.cholamd_plan_nnz_tiles(self.h)
+        self.fmin = g.cholamd_plan_fmin(self.h)
+        self.dropped = g.cholamd_plan_dropped_entries(self.h)
+        self.max_int_size = g.cholamd_plan_max_int_size(self.h)
+
+    @classmethod
+    def from_arrays(cls, n, levels, perm, sep_sizes, cl_idx, cl_interval, cl_sep, a_row, a_col, a_val, banner=None):
+        L = load()
+        arr = lambda a, t: np.ascontiguousarray(a, dtype=t)  # noqa: E731
+        perm, sep_sizes = arr(perm, np.int32), arr(sep_sizes, np.int32)
+        cl_idx, cl_interval, cl_sep = arr(cl_idx, np.int32), arr(cl_interval, np.int32), arr(cl_sep, np.int32)
+        a_row, a_col, a_val = arr(a_row, np.int32), arr(a_col, np.int32), arr(a_val, np.float64)
+        h = C.c_void_p()
+        check(L.cholamd_plan_create_from_arrays(n, levels, perm.ctypes.data, sep_sizes.ctypes.data, cl_idx.ctypes.data,
+                                                cl_interval.ctypes.data, cl_sep.ctypes.data, len(cl_idx), len(a_val),
+                                                a_row.ctypes.data, a_col.ctypes.data, a_val.ctypes.data,
+                                                banner.encode() if banner else None, C.byref(h)), "cholamd_plan_create_from_arrays")
+        return cls(_handle=h)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.cholamd_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _ints(self, fn, n):
+        a = np.zeros(n, dtype=np.int32)
+        getattr(self.L, fn)(self.h, a.ctypes.data)
+        return a
+
+    @property
+    def banner(self):
+        return self.L.cholamd_plan_banner(self.h).decode()
+
+    @property
+    def perm(self):
+        return self._ints("cholamd_plan_perm", self.n)
+
+    @property
+    def sep_sizes(self):
+        return self._ints("cholamd_plan_sep_sizes", self.nsep)
+
+    @property
+    def sep_offsets(self):
+        return self._ints("cholamd_plan_sep_offsets", self.nsep)
+
+    @property
+    def tree(self):
+        return self._ints("cholamd_plan_tree", self.nsep)
+
+    @property
+    def blocks(self):
+        """rows: r, c, lo_x, lo_y, hi_x, hi_y, ld, arena offset (int64)"""
+        raw = self._ints("cholamd_plan_blocks", 9 * self.num_blocks).reshape(-1, 9).astype(np.int64)
+        off = (raw[:, 7] & 0xFFFFFFFF) | (raw[:, 8] << 32)
+        return np.concatenate([raw[:, :7], off[:, None]], axis=1)
+
+    def snapshot(self, interval_lbl):
+        n = self.L.cholamd_plan_snapshot_count(self.h, interval_lbl)
+        buf = (Filled * max(n, 1))()
+        self.L.cholamd_plan_snapshot(self.h, interval_lbl, buf)
+        return buf, n
+
+    def snapshot_array(self, interval_lbl):
+        buf, n = self.snapshot(interval_lbl)
+        a = np.frombuffer(buf, dtype=np.int32).reshape(-1, 9)[:n]
+        return a[:, [1, 2, 4, 5, 6, 7, 8]].copy()  # sep_x, sep_y, cluster, lo_x, lo_y, hi_x, hi_y
+
+    def ops(self):
+        n = self.L.cholamd_plan_num_ops(self.h)
+        buf = (Op * max(n, 1))()
+        self.L.cholamd_plan_ops(self.h, buf)
+        return np.frombuffer(buf, dtype=np.int32).reshape(-1, 14)[:n].copy()
+
+    def counts(self, level=-1):
+        c = np.zeros(4, dtype=np.int64)
+        f = np.zeros(4, dtype=np.float64)
+        self.L.cholamd_plan_counts(self.h, level, c.ctypes.data, f.ctypes.data)
+        return c, f
+
+    def fill_host(self):
+        """fill_block for every block: the arena holding P A P^T (host array)."""
+        a = np.zeros(self.arena_doubles, dtype=np.float64)
+        check(self.L.cholamd_plan_fill_host(self.h, a.ctypes.data), "cholamd_plan_fill_host")
+        return a
+
+    def arena_to_dense(self, arena):
+        arena = np.ascontiguousarray(arena, dtype=np.float64)
+        assert arena.size == self.arena_doubles
+        d = np.zeros((self.n, self.n), dtype=np.float64, order="F")
+        check(self.L.cholamd_plan_arena_to_dense(self.h, arena.ctypes.data, d.ctypes.data), "cholamd_plan_arena_to_dense")
+        return d
+
+    def write_matrix(self, arena, path, full_precision=False):
+        arena = np.ascontiguousarray(arena, dtype=np.float64)
+        check(self.L.cholamd_plan_write_matrix(self.h, arena.ctypes.data, os.fsencode(path), int(full_precision)), "cholamd_plan_write_matrix")
+
+    def write_debug_log(self, path):
+        libc = C.CDLL(None)
+        libc.fopen.restype = C.c_void_p
+        libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+        libc.fclose.argtypes = [C.c_void_p]
+        fp = libc.fopen(os.fsencode(path), b"w")
+        if not fp:
+            raise IOError(path)
+        try:
+            check(self.L.cholamd_plan_write_debug_log(self.h, fp), "cholamd_plan_write_debug_log")
+        finally:
+            libc.fclose(fp)
+
+
+def read_vector(path, n):
+    out = np.zeros(n, dtype=np.float64)
+    check(load().cholamd_read_vector(os.fsencode(path), n, out.ctypes.data), "cholamd_read_vector")
+    return out
+
+
+def write_solution(path, x, full_precision=False):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    check(load().cholamd_write_solution(os.fsencode(path), x.ctypes.data, x.size, int(full_precision)), "cholamd_write_solution")

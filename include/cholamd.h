@@ -1,0 +1,271 @@
+/*
+ * cholamd.h -- C ABI of the MI355X-native supernodal Cholesky hot path.
+ *
+ * This is the drop-in boundary for ONE path of syamajala/cholesky: the per-supernode
+ * POTRF / TRSM / SYRK / GEMM frontal updates driven by the nested-dissection separator tree
+ * (reference: mmat.rg:1227-1355 -> blas.rg:292-504 -> libcblas/liblapacke).  Plain pointers and
+ * sizes only; no torch / HIP types appear in any signature (streams are passed as void*).
+ *
+ * Three nested levels are exported, each replacing a reference interface (file:line cited at each
+ * declaration, paths relative to the reference tree):
+ *
+ *   L-A  BLAS level   -- what Terra links today (blas.rg:18-22, mmat.rg:29-30): the six CBLAS /
+ *                        LAPACKE entry points with the exact parameter combinations the reference
+ *                        uses.  Host pointers in, host pointers out (like the CPU library they
+ *                        replace); `_dev` variants take device pointers + stream.
+ *   L-B  task level   -- the four `fused_*` leaf tasks (blas.rg:292-504): one call = one task =
+ *                        one batched HIP launch over the task's list of filled tiles.
+ *   L-C  driver level -- what `main` does around them (mmat.rg:1097-1362): ingest, symbolic
+ *                        analysis, A scatter, the level schedule, factor/solution writers, solve.
+ *
+ * All functions return 0 on success unless stated otherwise.  Errors are never silent: there is no
+ * CPU fallback anywhere in this library -- if no HIP device is usable, every compute entry point
+ * returns CHOLAMD_ERR_NO_DEVICE.
+ */
+#ifndef CHOLAMD_H
+#define CHOLAMD_H
+
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ----------------------------------------------------------------------------------------- */
+/* error codes                                                                                 */
+/* ----------------------------------------------------------------------------------------- */
+#define CHOLAMD_OK 0
+#define CHOLAMD_ERR_IO (-1)          /* fopen/parse failure (the reference leaves these unchecked, mnd.c:33,84,161,209) */
+#define CHOLAMD_ERR_FORMAT (-2)      /* file violates the on-disk contract */
+#define CHOLAMD_ERR_INVARIANT (-3)   /* ordering/cluster invariant the reference relies on is violated */
+#define CHOLAMD_ERR_ARG (-4)         /* unsupported parameter combination */
+#define CHOLAMD_ERR_NO_DEVICE (-5)   /* no usable HIP device: there is NO CPU fallback */
+#define CHOLAMD_ERR_HIP (-6)         /* a HIP runtime call failed (see cholamd_last_error) */
+#define CHOLAMD_ERR_NOMEM (-7)
+/* > 0: LAPACK-style info of the first failing pivot (see cholamd_factor_info) */
+
+const char *cholamd_last_error(void);
+const char *cholamd_version(void);
+
+/* ----------------------------------------------------------------------------------------- */
+/* Matrix-Market ingest: the four mmio.c entry points the reference calls                       */
+/*   mm_read_banner        mmio.c:96-179   (called mmat.rg:81)                                  */
+/*   mm_read_mtx_crd_size  mmio.c:189-217  (called mmat.rg:91)                                  */
+/*   mm_write_banner       mmio.c:406-415  (called mmat.rg:128)                                 */
+/*   mm_write_mtx_crd_size mmio.c:181-187  (called mmat.rg:129)                                 */
+/* Same names, same argument meaning, same return codes (mmio.h:73-79), so libmmio.so's users    */
+/* can link this library instead.  Like the reference, mm_read_banner does NOT run mm_is_valid,  */
+/* so the fixtures' "real hermitian" banner is accepted.                                         */
+/* ----------------------------------------------------------------------------------------- */
+typedef char MM_typecode[4];
+#define MM_COULD_NOT_READ_FILE 11
+#define MM_PREMATURE_EOF 12
+#define MM_NOT_MTX 13
+#define MM_NO_HEADER 14
+#define MM_UNSUPPORTED_TYPE 15
+#define MM_LINE_TOO_LONG 16
+#define MM_COULD_NOT_WRITE_FILE 17
+
+int mm_read_banner(FILE *f, MM_typecode *matcode);
+int mm_read_mtx_crd_size(FILE *f, int *M, int *N, int *nz);
+int mm_write_banner(FILE *f, MM_typecode matcode);
+int mm_write_mtx_crd_size(FILE *f, int M, int N, int nz);
+char *mm_typecode_to_str(MM_typecode matcode); /* mmio.c:488-511; caller frees */
+
+/* ----------------------------------------------------------------------------------------- */
+/* Separator / cluster / matrix / vector readers: plain-array equivalents of mnd.h:28-66        */
+/* (the reference versions write into Legion accessors; the file formats are the contract).     */
+/* ----------------------------------------------------------------------------------------- */
+typedef struct cholamd_sepinfo { int levels; int num_separators; } cholamd_sepinfo; /* SepInfo, mnd.h:23-26 */
+
+/* read_separators (mnd.c:22-69).  idx_out[pos] = original dof at permuted position pos,
+ * sep_out[pos] = 1-based separator label; both of length dim. */
+int cholamd_read_separators(const char *file, int dim, int *idx_out, int *sep_out, cholamd_sepinfo *info);
+
+/* read_clusters (mnd.c:71-150).  Emits the flat (idx, interval, sep) triples in file order, at
+ * most cap of them; *count_out = number available.  Returns max_int_size (>= 0) like the
+ * reference, or a negative error code. */
+int cholamd_read_clusters(const char *file, int *idx_out, int *interval_out, int *sep_out, int64_t cap, int64_t *count_out);
+
+/* read_matrix (mnd.c:152-199): nz coordinate entries, 0-based, as stored in the file (the
+ * reference hashes them; here they come back as plain COO arrays). */
+int cholamd_read_matrix(const char *file, int nz, int *row_out, int *col_out, double *val_out);
+
+/* read_vector (mnd.c:201-229): skips three header lines blindly, then n values. */
+int cholamd_read_vector(const char *file, int n, double *out);
+
+/* ----------------------------------------------------------------------------------------- */
+/* L-C: plan (host) = ingest + symbolic analysis of mmat.rg:1097-1209, re-expressed as plain C  */
+/* ----------------------------------------------------------------------------------------- */
+typedef struct cholamd_plan cholamd_plan;
+
+/* Filled tile descriptor: fspace Filled, blas.rg:55-61 (filled == 0 means FILLED, sic). */
+typedef struct cholamd_filled {
+  int filled;
+  int sep_x, sep_y;       /* block colour: (row separator, col separator), 1-based labels */
+  int interval;           /* interval label of the snapshot */
+  int cluster;            /* tile id z = row * ncols + col */
+  int lo_x, lo_y, hi_x, hi_y; /* rect2d bounds, inclusive, permuted matrix coordinates */
+} cholamd_filled;
+
+/* One reference BLAS call of the level schedule, in the reference's program order. */
+typedef struct cholamd_op {
+  int op;                 /* 0 POTRF, 1 TRSM, 2 SYRK, 3 GEMM */
+  int level;
+  int m, n, k;
+  int a_sx, a_sy, a_z;    /* A tile colour */
+  int b_sx, b_sy, b_z;    /* B tile colour (0 if unused) */
+  int c_sx, c_sy, c_z;    /* C tile colour (0 if unused) */
+} cholamd_op;
+
+int cholamd_plan_create(const char *matrix_file, const char *separator_file, const char *clusters_file, cholamd_plan **out);
+/* Same, from arrays already in memory (generated problems).  perm[pos] = dof; sep_sizes by label
+ * 1..nsep; clusters as (idx, interval, sep) triples like cholamd_read_clusters emits; A as COO
+ * lower triangle (row >= col), 0-based original coordinates. */
+int cholamd_plan_create_from_arrays(int n, int levels, const int *perm, const int *sep_sizes,
+                                    const int *cl_idx, const int *cl_interval, const int *cl_sep, int64_t cl_count,
+                                    int64_t nz, const int *a_row, const int *a_col, const double *a_val,
+                                    const char *banner, cholamd_plan **out);
+void cholamd_plan_destroy(cholamd_plan *p);
+
+int cholamd_plan_n(const cholamd_plan *p);
+int cholamd_plan_nz(const cholamd_plan *p);
+int cholamd_plan_levels(const cholamd_plan *p);
+int cholamd_plan_num_separators(const cholamd_plan *p);
+int cholamd_plan_max_int_size(const cholamd_plan *p);
+int cholamd_plan_num_blocks(const cholamd_plan *p);
+int64_t cholamd_plan_arena_doubles(const cholamd_plan *p);   /* size of the panel arena */
+int64_t cholamd_plan_dropped_entries(const cholamd_plan *p); /* entries of A outside every allocated block */
+const char *cholamd_plan_banner(const cholamd_plan *p);
+void cholamd_plan_perm(const cholamd_plan *p, int *out);          /* n ints */
+void cholamd_plan_sep_sizes(const cholamd_plan *p, int *out);     /* nsep ints, by label */
+void cholamd_plan_sep_offsets(const cholamd_plan *p, int *out);   /* nsep ints, by label */
+void cholamd_plan_tree(const cholamd_plan *p, int *out);          /* nsep ints: heap index-1 -> label (mmat.rg:834-849) */
+/* per allocated block, ordered by (row label, col label): r, c, lo_x, lo_y, hi_x, hi_y, ld, and
+ * the block's offset (in doubles) inside the arena split into two ints (lo32, hi32): 9 ints */
+void cholamd_plan_blocks(const cholamd_plan *p, int *out);
+/* snapshot `interval_lbl` of compute_filled_clusters (mmat.rg:1000-1016), filled tiles only,
+ * ordered by (row label, col label, cluster) */
+int64_t cholamd_plan_snapshot_count(const cholamd_plan *p, int interval_lbl);
+void cholamd_plan_snapshot(const cholamd_plan *p, int interval_lbl, cholamd_filled *out);
+/* the reference's BLAS call list (program order of mmat.rg:1227-1355) and its work */
+int64_t cholamd_plan_num_ops(const cholamd_plan *p);
+void cholamd_plan_ops(const cholamd_plan *p, cholamd_op *out);
+void cholamd_plan_counts(const cholamd_plan *p, int level /* -1 = all */, int64_t calls[4], double flops[4]);
+double cholamd_plan_flops(const cholamd_plan *p);           /* F_ref, SURVEY 8d */
+int64_t cholamd_plan_nnz_a(const cholamd_plan *p);          /* nnz(tril A) kept */
+int64_t cholamd_plan_nnz_l(const cholamd_plan *p);          /* exact symbolic nnz(L) of P A P^T (scalar elimination tree) */
+int64_t cholamd_plan_nnz_tiles(const cholamd_plan *p);      /* area of the filled tiles the schedule stores (>= nnz(L)) */
+double cholamd_plan_fmin(const cholamd_plan *p);            /* F_min = sum_j colcount_j^2 */
+int64_t cholamd_plan_alg_bytes(const cholamd_plan *p);      /* B_alg = 8 (nnz(tril A) + nnz(L)) */
+
+/* fill_block for every block (mmat.rg:529-633, 1216-1224): zero the arena and scatter A. */
+int cholamd_plan_fill_host(const cholamd_plan *p, double *arena);
+/* dense N x N col-major image of an arena (zeros outside allocated blocks) and back */
+int cholamd_plan_arena_to_dense(const cholamd_plan *p, const double *arena, double *dense);
+/* write_matrix (mmat.rg:102-147): banner, "M N nnz", "row col %0.8g" per non-zero, block by
+ * block; full_precision != 0 writes %.17g instead (needed for the 1e-10 gate). */
+int cholamd_plan_write_matrix(const cholamd_plan *p, const double *arena, const char *file, int full_precision);
+/* write_solution (mmat.rg:785-798): n lines "%0.8g" (or %.17g), original dof order, no header */
+int cholamd_write_solution(const char *file, const double *x, int n, int full_precision);
+/* the reference's -d structured log lines for one level of the schedule (blas.rg:308,340,405) */
+int cholamd_plan_write_debug_log(const cholamd_plan *p, FILE *f);
+
+/* ----------------------------------------------------------------------------------------- */
+/* L-C: device side.  The arena (all per-separator panels, col-major, contiguous) lives in HBM. */
+/* ----------------------------------------------------------------------------------------- */
+typedef struct cholamd_device cholamd_device;
+
+int cholamd_device_count(void);
+/* Uploads the level schedule (op descriptors) of `plan` to device `device_id`. */
+int cholamd_device_create(const cholamd_plan *plan, int device_id, cholamd_device **out);
+void cholamd_device_destroy(cholamd_device *d);
+/* device memory owned by the library (hipMalloc); callers may instead pass their own buffers
+ * (e.g. torch tensors) of cholamd_plan_arena_doubles() doubles to the calls below */
+int cholamd_device_alloc(cholamd_device *d, int64_t doubles, double **dptr);
+int cholamd_device_free(cholamd_device *d, double *dptr);
+int cholamd_device_upload(cholamd_device *d, double *d_dst, const double *h_src, int64_t doubles, void *stream);
+int cholamd_device_download(cholamd_device *d, double *h_dst, const double *d_src, int64_t doubles, void *stream);
+int cholamd_device_sync(cholamd_device *d, void *stream);
+/* A scatter on the device (fill_block, mmat.rg:1216-1224): zero d_arena, scatter tril(A). */
+int cholamd_device_fill(cholamd_device *d, double *d_arena, void *stream);
+/* The hot path: the whole level loop of mmat.rg:1227-1355 on d_arena, asynchronously on stream
+ * (at most three kernel launches per tree level).  level_lo/level_hi restrict the loop to tree
+ * levels [level_lo, level_hi] (inclusive; pass 0, levels-1 for everything) -- used by the
+ * multi-GPU driver to run subtree levels and top levels separately. */
+int cholamd_factor(cholamd_device *d, double *d_arena, void *stream);
+int cholamd_factor_levels(cholamd_device *d, double *d_arena, int level_hi, int level_lo, void *stream);
+/* Restrict the schedule to the subtrees owned by `rank` of `world` (a power of two <= 2^(levels-1)):
+ * separators below the split level that are not in this rank's subtrees are skipped.  world == 1
+ * restores the full schedule. */
+int cholamd_device_set_partition(cholamd_device *d, int rank, int world);
+/* LAPACK-style info after the stream has been synchronised: 0 ok; k > 0 = leading minor k of the
+ * pivot of separator *sep_out is not positive definite (the reference ignores this, blas.rg:71) */
+int cholamd_factor_info(cholamd_device *d, int *sep_out);
+/* Solve phase, mmat.rg:1364-1495: b and x in ORIGINAL dof order (device pointers, n doubles) */
+int cholamd_solve(cholamd_device *d, const double *d_arena, const double *d_b, double *d_x, void *stream);
+/* average device time (ms) of the three kernel families of the last cholamd_factor call measured
+ * with HIP events on its stream; valid after cholamd_device_sync.  Enable with set_timing(1). */
+int cholamd_device_set_timing(cholamd_device *d, int on);
+int cholamd_device_get_timing(cholamd_device *d, float ms_by_kind[4], int launches_by_kind[4]);
+
+/* ----------------------------------------------------------------------------------------- */
+/* L-B: task level -- the four fused leaf tasks of blas.rg.  A region is a block instance:     */
+/* device pointer of element (lo_x, lo_y), leading dimension, and its bounds in permuted         */
+/* matrix coordinates (what get_raw_ptr_2d, blas.rg:35-43, resolves from Legion).                */
+/* filled lists are HOST arrays, exactly the `Filled` records the reference tasks iterate.       */
+/* ----------------------------------------------------------------------------------------- */
+typedef struct cholamd_region {
+  double *ptr;
+  int ld;
+  int lo_x, lo_y, hi_x, hi_y;
+} cholamd_region;
+
+/* fused_dpotrf, blas.rg:292-315.  Returns LAPACK info of the first failing tile (the reference discards it). */
+int cholamd_fused_dpotrf(const cholamd_region *rA, const cholamd_filled *filled_rA, int nA, int level, int interval, int debug, void *stream);
+/* fused_dtrsm, blas.rg:317-351 */
+int cholamd_fused_dtrsm(const cholamd_region *rA, const cholamd_region *rB, const cholamd_filled *filled_rA, int nA,
+                        const cholamd_filled *filled_rB, int nB, int level, int interval, int debug, void *stream);
+/* fused_dsyrk, blas.rg:353-436 */
+int cholamd_fused_dsyrk(const cholamd_region *rA, const cholamd_region *rB, const cholamd_region *rC,
+                        const cholamd_filled *filled_rA, int nA, const cholamd_filled *filled_rB, int nB,
+                        const cholamd_filled *filled_rC, int nC, int col_cluster_size, int level, int interval, int debug, void *stream);
+/* fused_dgemm, blas.rg:438-504 */
+int cholamd_fused_dgemm(const cholamd_region *rA, const cholamd_region *rB, const cholamd_region *rC,
+                        const cholamd_filled *filled_rA, int nA, const cholamd_filled *filled_rB, int nB,
+                        const cholamd_filled *filled_rC, int nC, int col_cluster_size, int level, int interval, int debug, void *stream);
+
+/* ----------------------------------------------------------------------------------------- */
+/* L-A: BLAS level -- the C symbols Terra binds (blas.rg:71, 99, 139, 187, 226, 263;           */
+/* mmat.rg:1057).  Enum values are CBLAS's.  Only the parameter combinations the reference      */
+/* issues are implemented; anything else sets cholamd_last_error and returns/raises ERR_ARG.    */
+/* `_dev` variants: device pointers, asynchronous on `stream`.                                   */
+/* ----------------------------------------------------------------------------------------- */
+enum { CholamdColMajor = 102, CholamdNoTrans = 111, CholamdTrans = 112, CholamdUpper = 121, CholamdLower = 122,
+       CholamdNonUnit = 131, CholamdLeft = 141, CholamdRight = 142 };
+
+int cholamd_LAPACKE_dpotrf(int matrix_layout, char uplo, int n, double *a, int lda);                      /* blas.rg:71 */
+void cholamd_cblas_dtrsm(int layout, int side, int uplo, int transa, int diag, int m, int n, double alpha,
+                         const double *a, int lda, double *b, int ldb);                                   /* blas.rg:99 */
+void cholamd_cblas_dgemm(int layout, int transa, int transb, int m, int n, int k, double alpha, const double *a, int lda,
+                         const double *b, int ldb, double beta, double *c, int ldc);                      /* blas.rg:139 */
+void cholamd_cblas_dsyrk(int layout, int uplo, int trans, int n, int k, double alpha, const double *a, int lda,
+                         double beta, double *c, int ldc);                                                /* blas.rg:187 */
+void cholamd_cblas_dtrsv(int layout, int uplo, int transa, int diag, int n, const double *a, int lda, double *x, int incx); /* blas.rg:226 */
+void cholamd_cblas_dgemv(int layout, int trans, int m, int n, double alpha, const double *a, int lda, const double *x, int incx,
+                         double beta, double *y, int incy);                                               /* blas.rg:263 */
+void cholamd_openblas_set_num_threads(int num_threads);                                                  /* mmat.rg:1057: accepted, no effect */
+int cholamd_blas_status(void); /* 0, or the error code of the last L-A call on this thread */
+
+int cholamd_dpotrf_dev(int n, double *d_a, int lda, int *d_info, void *stream);
+int cholamd_dtrsm_dev(int m, int n, const double *d_a, int lda, double *d_b, int ldb, void *stream);
+int cholamd_dgemm_dev(int m, int n, int k, const double *d_a, int lda, const double *d_b, int ldb, double *d_c, int ldc, void *stream);
+int cholamd_dsyrk_dev(int n, int k, const double *d_a, int lda, double *d_c, int ldc, void *stream);
+int cholamd_dtrsv_dev(int trans, int n, const double *d_a, int lda, double *d_x, void *stream);
+int cholamd_dgemv_dev(int trans, int m, int n, const double *d_a, int lda, const double *d_x, double *d_y, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHOLAMD_H */

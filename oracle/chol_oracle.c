@@ -1006,3 +1006,16 @@ int orc_write_matrix(Orc *o, const char *file, int fmt17)
   fclose(fp);
   return 0;
 }
+
+/* ---------------------------------------------------------------------------------------- */
+/* Stand-alone access to the oracle's BLAS restatements (checker for the L-A entry points)    */
+/* ---------------------------------------------------------------------------------------- */
+int orc_blas_potrf(int n, double *a, int lda) { return B_potrf(ColMajor, 'L', n, a, lda); }
+void orc_blas_trsm(int m, int n, const double *a, int lda, double *b, int ldb) { B_trsm(ColMajor, Right, Lower, Trans, NonUnit, m, n, 1.0, a, lda, b, ldb); }
+void orc_blas_syrk(int n, int k, const double *a, int lda, double *c, int ldc) { B_syrk(ColMajor, Lower, NoTrans, n, k, -1.0, a, lda, 1.0, c, ldc); }
+void orc_blas_gemm(int m, int n, int k, const double *a, int lda, const double *b, int ldb, double *c, int ldc)
+{
+  B_gemm(ColMajor, NoTrans, Trans, m, n, k, -1.0, a, lda, b, ldb, 1.0, c, ldc);
+}
+void orc_blas_trsv(int trans, int n, const double *a, int lda, double *x) { B_trsv(ColMajor, Lower, trans, NonUnit, n, a, lda, x, 1); }
+void orc_blas_gemv(int trans, int m, int n, const double *a, int lda, const double *x, double *y) { B_gemv(ColMajor, trans, m, n, -1.0, a, lda, x, 1, 1.0, y, 1); }

@@ -195,3 +195,33 @@ def use_own_kernels():
 
 def backend_name():
     return lib().orc_backend_name().decode()
+
+
+# ---- stand-alone BLAS restatements (numpy float64, order='F') -------------------------------
+def _ld(a):
+    return a.strides[1] // 8 if a.ndim == 2 and a.shape[1] > 1 else max(1, a.shape[0])
+
+
+def blas_potrf(a):
+    return lib().orc_blas_potrf(a.shape[0], C.c_void_p(a.ctypes.data), _ld(a))
+
+
+def blas_trsm(A, B):
+    lib().orc_blas_trsm(B.shape[0], B.shape[1], C.c_void_p(A.ctypes.data), _ld(A), C.c_void_p(B.ctypes.data), _ld(B))
+
+
+def blas_syrk(A, Cm):
+    lib().orc_blas_syrk(A.shape[0], A.shape[1], C.c_void_p(A.ctypes.data), _ld(A), C.c_void_p(Cm.ctypes.data), _ld(Cm))
+
+
+def blas_gemm(A, B, Cm):
+    lib().orc_blas_gemm(Cm.shape[0], Cm.shape[1], A.shape[1], C.c_void_p(A.ctypes.data), _ld(A), C.c_void_p(B.ctypes.data), _ld(B),
+                        C.c_void_p(Cm.ctypes.data), _ld(Cm))
+
+
+def blas_trsv(A, x, trans=111):
+    lib().orc_blas_trsv(trans, A.shape[0], C.c_void_p(A.ctypes.data), _ld(A), C.c_void_p(x.ctypes.data))
+
+
+def blas_gemv(A, x, y, trans=111):
+    lib().orc_blas_gemv(trans, A.shape[0], A.shape[1], C.c_void_p(A.ctypes.data), _ld(A), C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data))

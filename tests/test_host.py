@@ -1,0 +1,218 @@
+"""CPU-only tests of the product's host side: ingest, symbolic analysis and schedule of
+libcholamd.so against the oracle (which is pinned to the reference in test_oracle.py), plus the
+C-ABI surface check (every symbol include/cholamd.h declares is exported; no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import CASES, KNOWN, ROOT, case_paths
+from oracle import oracle as orc
+
+
+@pytest.fixture(scope="module")
+def ca():
+    import __graft_entry__
+    if not os.path.exists(os.path.join(ROOT, "cholesky_amd", "lib", "libcholamd.so")):
+        __graft_entry__.build()
+    import cholesky_amd
+    return cholesky_amd
+
+
+@pytest.fixture(scope="module")
+def plans(ca):
+    return {case: ca.Plan(*case_paths(case)[:3]) for case in CASES}
+
+
+@pytest.fixture(scope="module")
+def oracles():
+    orc.use_own_kernels()
+    out = {}
+    for case in CASES:
+        O = orc.Oracle(*case_paths(case)[:3])
+        O.factor(log_ops=True)
+        out[case] = O
+    return out
+
+
+def test_header_symbols_are_exported(ca):
+    """Every function declared in include/cholamd.h is exported by libcholamd.so."""
+    from cholesky_amd import _lib
+    text = open(_lib.HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b((?:cholamd|mm)_[A-Za-z0-9_]+)\s*\(", text))
+    assert len(names) > 60
+    lib = C.CDLL(_lib.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_no_device_means_loud_failure(ca):
+    """Without a GPU the compute entry points fail with an error code; nothing computes on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    a = np.asfortranarray(np.eye(4) * 4.0)
+    with pytest.raises(ca.CholamdError):
+        ca.blas.LAPACKE_dpotrf(a)
+    assert a[0, 0] == 4.0  # untouched
+    plan = ca.Plan(*case_paths("lapl_9x9")[:3])
+    with pytest.raises(ca.CholamdError):
+        ca.Device(plan, 0)
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_plan_matches_oracle(case, plans, oracles):
+    P, O = plans[case], oracles[case]
+    assert (P.n, P.nz, P.levels, P.nsep) == (O.N, O.NZ, O.levels, O.nsep)
+    assert P.banner == O.banner
+    assert np.array_equal(P.perm, O.perm)
+    assert np.array_equal(P.sep_sizes, O.sep_sizes)
+    assert np.array_equal(P.sep_offsets, O.sep_offsets)
+    assert np.array_equal(P.tree, O.tree)
+    assert np.array_equal(P.blocks[:, :6], O.blocks)
+    assert P.max_int_size == O.L.orc_max_int_size(O.h)
+    for lbl in range(P.levels):
+        assert np.array_equal(P.snapshot_array(lbl), O.snapshot(lbl)), f"snapshot {lbl}"
+    assert np.array_equal(P.ops(), O.ops())  # same BLAS calls, same program order
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_known_answers(case, plans):
+    P = plans[case]
+    calls, flops = P.counts()
+    assert tuple(int(c) for c in calls) == KNOWN[case][0]
+    assert flops.sum() == pytest.approx(KNOWN[case][1], rel=1e-5)
+    assert P.flops == pytest.approx(KNOWN[case][1], rel=1e-5)
+    assert P.nnz_a == KNOWN[case][2]
+    assert P.nnz_l == KNOWN[case][3]
+    assert P.alg_bytes == 8 * (KNOWN[case][2] + KNOWN[case][3])
+    assert P.dropped == 0
+    assert P.nnz_tiles >= P.nnz_l
+
+
+def test_fmin_known_answers(plans):
+    want = {"lapl_9x9": 96, "lapl_25x25": 603, "lapl_400x400": 7.792e4, "lapl_3375x3375": 5.273e7}
+    for case, v in want.items():
+        assert plans[case].fmin == pytest.approx(v, rel=1e-3)
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_host_fill_is_the_reference_permuted_matrix(case, plans, golden):
+    P = plans[case]
+    assert np.array_equal(P.arena_to_dense(P.fill_host()), golden(case)["pmat"])
+
+
+def test_panel_layout(plans):
+    """One contiguous panel per separator; the top of the tree is a contiguous tail of the arena."""
+    P = plans["lapl_3375x3375"]
+    b = P.blocks
+    ns = P.nsep
+    # diagonal blocks start their panels; panels ordered by label
+    diag = b[b[:, 0] == b[:, 1]]
+    assert np.all(np.diff(diag[:, 7]) > 0)
+    # block (r, c) lies in panel c: same ld as (c, c) and offset between panel start and next panel
+    for row in b:
+        r, c = int(row[0]), int(row[1])
+        d = diag[diag[:, 1] == c][0]
+        assert row[6] == d[6] and row[7] >= d[7]
+        if c < ns:
+            nxt = diag[diag[:, 1] == c + 1][0]
+            assert row[7] + (row[5] - row[3]) * row[6] + (row[4] - row[2]) < nxt[7]
+    assert P.arena_doubles * 8 < 16e6  # 13.9 MB of allocated blocks + alignment
+
+
+def test_writers_roundtrip(tmp_path, ca, plans, golden):
+    import scipy.io
+    P = plans["lapl_25x25"]
+    arena = P.fill_host()
+    p = tmp_path / "permuted.mtx"
+    P.write_matrix(arena, str(p))
+    first = open(p).readline().strip()
+    assert first == "%%MatrixMarket matrix coordinate real hermitian"
+    M = scipy.io.mmread(str(p)).toarray()
+    assert np.array_equal(np.tril(M), golden("lapl_25x25")["pmat"])
+    x = np.linspace(-1, 1, 25)
+    s = tmp_path / "sol.txt"
+    ca.plan.write_solution(str(s), x)
+    assert np.allclose(np.genfromtxt(str(s)), x, atol=1e-7)
+    ca.plan.write_solution(str(s), x, full_precision=True)
+    assert np.array_equal(np.genfromtxt(str(s)), x)
+
+
+def test_debug_log_is_replayable(tmp_path, plans):
+    """The -d structured op log has the reference's dict-literal line format (blas.rg:308,340,405):
+    every line after the tag evaluates as a Python dict with the keys verify.debug_factor reads."""
+    P = plans["lapl_25x25"]
+    p = tmp_path / "oplog.txt"
+    P.write_debug_log(str(p))
+    tags = {"Block": 0, "POTRF": 0, "TRSM": 0, "GEMM": 0}
+    for line in open(p):
+        tag, rest = line.split(":", 1)
+        d = eval(rest)  # noqa: S307 - same consumption as verify.py:26-29
+        tags[tag] += 1
+        if tag != "Block":
+            assert {"A", "A_Lo", "A_Hi", "Block", "Level", "Interval"} <= set(d)
+    assert tags["POTRF"] == 7 and tags["TRSM"] == 16 and tags["GEMM"] == 30 and tags["Block"] == P.num_blocks
+
+
+def test_ingest_errors_are_reported(tmp_path, ca):
+    m, o, c, _ = case_paths("lapl_9x9")
+    with pytest.raises(ca.CholamdError):
+        ca.Plan(str(tmp_path / "missing.mtx"), o, c)
+    bad = tmp_path / "bad_ord.txt"
+    bad.write_text("2 3\n0;0,3,6,\n1;2,5,8,\n")  # third separator missing
+    with pytest.raises(ca.CholamdError):
+        ca.Plan(m, str(bad), c)
+    badc = tmp_path / "bad_clust.txt"
+    badc.write_text("2 3\n0;0,3,;\n1;0,3,;\n2;0,1,3,;\n")  # root not a single tile when eliminated
+    with pytest.raises(ca.CholamdError):
+        ca.Plan(m, o, str(badc))
+
+
+def test_mm_reader_matches_reference_build(ca):
+    """The library's mm_read_banner / mm_read_mtx_crd_size agree with the reference's own mmio.c
+    (compiled where it lies into oracle/_ref) on every fixture."""
+    so = os.path.join(ROOT, "oracle", "_ref", "libmmio_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    from cholesky_amd import _lib
+    ref, mine, libc = C.CDLL(so), C.CDLL(_lib.LIB_PATH), C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    for lib in (ref, mine):
+        lib.mm_read_banner.argtypes = [C.c_void_p, C.c_char_p]
+        lib.mm_read_mtx_crd_size.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 3
+    for case in CASES:
+        for path in (case_paths(case)[0], case_paths(case)[3]):
+            res = []
+            for lib in (ref, mine):
+                fp = libc.fopen(path.encode(), b"r")
+                tc = C.create_string_buffer(4)
+                rc = lib.mm_read_banner(fp, tc)
+                M, N, NZ = C.c_int(), C.c_int(), C.c_int()
+                rc2 = lib.mm_read_mtx_crd_size(fp, C.byref(M), C.byref(N), C.byref(NZ)) if tc.raw[1:2] == b"C" else 0
+                libc.fclose(fp)
+                res.append((rc, tc.raw, rc2, M.value, N.value, NZ.value))
+            assert res[0] == res[1], path
+
+
+def test_partition_work_lists(ca, plans):
+    """Multi-GPU subtree sharding: every separator below the cut is owned by exactly one
+    rank and the shared top is the contiguous tail of the arena."""
+    P = plans["lapl_3375x3375"]
+    tree = P.tree
+    for world in (1, 2, 4, 8):
+        d = world.bit_length() - 1
+        owners = {}
+        for h in range(1, P.nsep + 1):
+            lvl = h.bit_length() - 1
+            owners[int(tree[h - 1])] = -1 if lvl < d else (h >> (lvl - d)) - (1 << d)
+        for rank in range(world):
+            mine = [s for s, o in owners.items() if o == rank]
+            assert len(mine) == (P.nsep - (world - 1)) // world
+        top = sorted(s for s, o in owners.items() if o == -1)
+        assert top == list(range(P.nsep - (world - 1) + 1, P.nsep + 1))
