@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- fp64 supernodal Cholesky factorisation throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--case lapl_3375x3375]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one numeric factorisation (the level loop of mmat.rg:1227-1355) of the workload, on an
+arena that already holds P A P^T in HBM when the timed region starts (a fresh pre-filled arena per
+step, so nothing is cached from the previous step and no re-fill sits inside the timed region).
+value = F_ref * K / t, F_ref = the reference's own BLAS-call flop count.
+
+N > 1: the SAME factorisation is sharded by subtrees of the separator tree (strong scaling): rank g
+factors the subtrees below tree level log2(N), the extend-add contributions to the shared top of
+the tree are summed with one RCCL all-reduce over the contiguous tail of the arena, then every
+rank factors the top levels.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CASES = {
+    "lapl_9x9": ("lapl_3_2.mtx", "lapl_3_2_ord_2.txt", "lapl_3_2_clust_2.txt"),
+    "lapl_25x25": ("lapl_5_2.mtx", "lapl_5_2_ord_3.txt", "lapl_5_2_clust_3.txt"),
+    "lapl_400x400": ("lapl_20_2.mtx", "lapl_20_2_ord_5.txt", "lapl_20_2_clust_5.txt"),
+    "lapl_3375x3375": ("lapl_15_3.mtx", "lapl_15_3_ord_5.txt", "lapl_15_3_clust_5.txt"),
+}
+PEAK_FP64_TFLOPS = 78.6   # MI355X dense fp64 (vector = matrix) peak, public spec; the microarch guide lists no fp64 row
+PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(files, flops, budget_s=12.0):
+    """The oracle (C restatement of the reference CPU path, OpenBLAS 1 thread when one is on the box,
+    exactly as the reference links it) timed on this host on a bounded sample."""
+    from oracle import oracle as orc
+    backend = "openblas" if orc.use_openblas() else "own-c-kernels"
+    try:
+        O = orc.Oracle(*files)
+        O.factor()  # warm-up
+        t_acc, n = 0.0, 0
+        t_wall = time.perf_counter()
+        while time.perf_counter() - t_wall < budget_s and n < 2000:
+            t_acc += O.factor()
+            n += 1
+        name = orc.backend_name()
+    finally:
+        orc.use_own_kernels()
+    return {
+        "value": round(flops * n / t_acc * 1e-9, 3), "unit": "GF/s", "cores": 1, "kind": "port",
+        "sample": f"{n} full numeric factorisations of the same workload (level loop only, {t_acc / n * 1e3:.2f} ms each), "
+                  f"oracle/chol_oracle.c with {name}",
+        "backend": backend,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--case", default="lapl_3375x3375")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import cholesky_amd as ca
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    g = os.path.join(ROOT, "tests", "golden", args.case)
+    files = [os.path.join(g, f) for f in CASES[args.case]]
+    plan = ca.Plan(*files)
+    dev = ca.Device(plan, local_rank)
+    split = 0
+    tail_off = plan.arena_doubles
+    if world > 1:
+        dev.set_partition(rank, world)
+        split = world.bit_length() - 1
+        diag = {int(b[1]): int(b[7]) for b in plan.blocks if b[0] == b[1]}
+        tail_off = diag[plan.nsep - (world - 1) + 1]  # first panel of the shared top of the tree
+
+    K, W = args.steps, args.warmup
+    stream = torch.cuda.current_stream()
+    per_arena = plan.arena_doubles * 8
+    n_arenas = max(1, min(K + W, int(8e9 // per_arena)))
+    arenas = [dev.new_arena() for _ in range(n_arenas)]
+
+    def refill():
+        for a in arenas:
+            dev.fill(a, stream)
+        dev.sync(stream)
+
+    def step(a):
+        if world == 1:
+            dev.factor(a, stream)
+        else:
+            dev.factor_levels(a, plan.levels - 1, split, stream)
+            dist.all_reduce(a[tail_off:])          # extend-add contributions to the shared ancestors
+            dev.factor_levels(a, split - 1, 0, stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    refill()
+    done = 0
+    for _ in range(W):
+        step(arenas[done % n_arenas])
+        done += 1
+    fence()
+    if done + K > n_arenas:  # not enough pre-filled arenas for K more steps: restore them outside the timed region
+        refill()
+        done = 0
+    fence()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(arenas[(done + i) % n_arenas])
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    info = dev.info()
+
+    # dominant-kernel roofline: HIP events recorded by the library around every launch, on the
+    # stream the kernels run on, in a separate pass over pre-filled arenas
+    refill()
+    dev.set_timing(1)
+    reps = min(n_arenas, 20)
+    for a in arenas[:reps]:
+        dev.factor(a, stream) if world == 1 else dev.factor_levels(a, plan.levels - 1, split, stream)
+    dev.sync(stream)
+    timing = dev.get_timing()
+    dev.set_timing(0)
+
+    if rank == 0:
+        calls, flops = plan.counts()
+        kinds = {"potrf": float(flops[0]), "trsm": float(flops[1]), "update": float(flops[2] + flops[3])}
+        dom = max(("potrf", "trsm", "update"), key=lambda k: timing[k][0])
+        ms, n_launch = timing[dom]
+        avg_s = ms / max(n_launch, 1) * 1e-3
+        launches_per_factor = n_launch / reps
+        flops_per_launch = kinds[dom] / max(launches_per_factor, 1) if world == 1 else None
+        achieved = (flops_per_launch / avg_s * 1e-12) if flops_per_launch else None
+        value = plan.flops * K / dt * 1e-9
+        out = {
+            "metric": "fp64 factorization GF/s (numeric level loop, F_ref flops) on 3-D Laplacian",
+            "value": round(value, 3), "unit": "GF/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"tests/{args.case} (reference fixture: 7-point Laplacian, nested-dissection ordering from the fixture files)",
+                       "n": plan.n, "levels": plan.levels, "separators": plan.nsep, "F_ref_flops": plan.flops,
+                       "B_alg_bytes": plan.alg_bytes, "parallelism": f"subtree-sharded x{world}" if world > 1 else "single GPU",
+                       "factor_info": list(info)},
+            "roofline": {"bound": "mfma", "kernel": f"k_{dom}", "achieved": None if achieved is None else round(achieved, 5),
+                         "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                         "frac": None if achieved is None else round(achieved / PEAK_FP64_TFLOPS, 6), "traffic": None,
+                         "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": launches_per_factor,
+                         "alg_flops_per_launch": flops_per_launch,
+                         "whole_step_frac_of_fp64_peak": round(value * 1e-3 / PEAK_FP64_TFLOPS, 6),
+                         "whole_step_alg_GBs": round(plan.alg_bytes * K / dt * 1e-9, 3), "hbm_peak_GBs": PEAK_HBM_GBS,
+                         "kernel_ms_per_step": {k: round(timing[k][0] / reps, 5) for k in ("potrf", "trsm", "update")}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(files, plan.flops)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

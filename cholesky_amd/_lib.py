@@ -41,6 +41,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run `make` (or __graft_entry__.build()) first; "
                           "cholesky_amd has no fallback path without its HIP library")
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7; when it is loaded first
+    # the dynamic linker resolves libcholamd's dependency to that same copy by soname.  Loading
+    # /opt/rocm's copy first and torch's second leaves torch without a visible GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, ci, cd, i64 = C.c_void_p, C.c_int, C.c_double, C.c_int64
     L.cholamd_last_error.restype = C.c_char_p

@@ -23,6 +23,7 @@
 
 struct level_dev {
   int n_potrf = 0, n_trsm = 0, n_task = 0, n_src = 0;
+  int n_potrf_big = 0, n_trsm_big = 0; // pivots beyond CHOL_RR_MAXN are listed after the small ones
   chol_potrf_desc *potrf = nullptr;
   chol_trsm_desc *trsm = nullptr;
   chol_upd_task *task = nullptr;
@@ -88,9 +89,20 @@ static int build_levels(cholamd_device *d)
     int rc = chol_build_level_work(d->plan, lvl, d->rank, d->world, &w);
     if (rc) return rc;
     level_dev &l = d->lv[lvl];
-    l.n_potrf = w.n_potrf; l.n_trsm = w.n_trsm; l.n_task = w.n_task; l.n_src = w.n_src;
-    rc = upload_vec(&l.potrf, w.potrf, (size_t)w.n_potrf);
-    if (!rc) rc = upload_vec(&l.trsm, w.trsm, (size_t)w.n_trsm);
+    l.n_task = w.n_task; l.n_src = w.n_src;
+    // stable partition: register-resident kernels first, the generic ones for big pivots after
+    std::vector<chol_potrf_desc> pv;
+    for (int i = 0; i < w.n_potrf; i++) if (w.potrf[i].n <= CHOL_RR_MAXN) pv.push_back(w.potrf[i]);
+    l.n_potrf = (int)pv.size();
+    for (int i = 0; i < w.n_potrf; i++) if (w.potrf[i].n > CHOL_RR_MAXN) pv.push_back(w.potrf[i]);
+    l.n_potrf_big = w.n_potrf - l.n_potrf;
+    std::vector<chol_trsm_desc> tv;
+    for (int i = 0; i < w.n_trsm; i++) if (w.trsm[i].n <= CHOL_RR_MAXN) tv.push_back(w.trsm[i]);
+    l.n_trsm = (int)tv.size();
+    for (int i = 0; i < w.n_trsm; i++) if (w.trsm[i].n > CHOL_RR_MAXN) tv.push_back(w.trsm[i]);
+    l.n_trsm_big = w.n_trsm - l.n_trsm;
+    rc = upload_vec(&l.potrf, pv.data(), pv.size());
+    if (!rc) rc = upload_vec(&l.trsm, tv.data(), tv.size());
     if (!rc) rc = upload_vec(&l.task, w.task, (size_t)w.n_task);
     if (!rc) rc = upload_vec(&l.src, w.src, (size_t)w.n_src);
     chol_level_work_free(&w);
@@ -185,7 +197,17 @@ extern "C" int cholamd_device_fill(cholamd_device *d, double *d_arena, void *str
   HIPCHK(hipSetDevice(d->dev));
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipMemsetAsync(d_arena, 0, (size_t)d->plan->arena * sizeof(double), st));
-  HIPCHK((hipError_t)chol_launch_scatter(d_arena, d->a_dst, d->a_val, d->plan->nnz_a, st));
+  // multi-GPU: the shared top of the tree (tail of the arena) starts from A on rank 0 only and from
+  // zero elsewhere, so that the sum over ranks after the local levels is A_top - all contributions
+  int64_t nnz = d->plan->nnz_a;
+  if (d->world > 1 && d->rank != 0) {
+    const int first_top = d->plan->nsep - (d->world - 1) + 1;
+    const int64_t tail = d->plan->panel_off[first_top];
+    int64_t lo = 0, hi = nnz;
+    while (lo < hi) { int64_t mid = (lo + hi) / 2; if (d->plan->a_dst[mid] < tail) lo = mid + 1; else hi = mid; }
+    nnz = lo;
+  }
+  HIPCHK((hipError_t)chol_launch_scatter(d_arena, d->a_dst, d->a_val, nnz, st));
   return 0;
 }
 
@@ -242,8 +264,16 @@ extern "C" int cholamd_factor_levels(cholamd_device *d, double *d_arena, int lev
   if (level_hi == L - 1) HIPCHK(hipMemsetAsync(d->info, 0, 2 * sizeof(int), st));
   for (int lvl = level_hi; lvl >= level_lo; lvl--) { // mmat.rg:1227
     const level_dev &l = d->lv[lvl];
-    { scoped_timer t(d, st, 0, l.n_potrf > 0); HIPCHK((hipError_t)chol_launch_potrf(d_arena, d->ws, l.potrf, l.n_potrf, d->info, st)); }
-    { scoped_timer t(d, st, 1, l.n_trsm > 0); HIPCHK((hipError_t)chol_launch_trsm(d_arena, d->ws, l.trsm, l.n_trsm, st)); }
+    {
+      scoped_timer t(d, st, 0, l.n_potrf + l.n_potrf_big > 0);
+      HIPCHK((hipError_t)chol_launch_potrf(d_arena, d->ws, l.potrf, l.n_potrf, d->info, st));
+      HIPCHK((hipError_t)chol_launch_potrf_big(d_arena, d->ws, l.potrf + l.n_potrf, l.n_potrf_big, d->info, st));
+    }
+    {
+      scoped_timer t(d, st, 1, l.n_trsm + l.n_trsm_big > 0);
+      HIPCHK((hipError_t)chol_launch_trsm(d_arena, d->ws, l.trsm, l.n_trsm, st));
+      HIPCHK((hipError_t)chol_launch_trsm_big(d_arena, d->ws, l.trsm + l.n_trsm, l.n_trsm_big, st));
+    }
     { scoped_timer t(d, st, 2, l.n_task > 0); HIPCHK((hipError_t)chol_launch_update(d_arena, l.task, l.src, l.n_task, st)); }
   }
   return 0;
@@ -396,7 +426,8 @@ static int run_trsm(const double *Lp, int n, int ldl, const std::vector<chol_trs
     }
   rc = sc.put(&dd, v.data(), v.size(), st);
   if (rc) return rc;
-  HIPCHK((hipError_t)chol_launch_trsm(nullptr, nullptr, dd, (int)v.size(), st));
+  if (n <= CHOL_RR_MAXN) HIPCHK((hipError_t)chol_launch_trsm(nullptr, nullptr, dd, (int)v.size(), st));
+  else HIPCHK((hipError_t)chol_launch_trsm_big(nullptr, nullptr, dd, (int)v.size(), st));
   HIPCHK(hipStreamSynchronize(st));
   return 0;
 }
@@ -407,7 +438,10 @@ static int run_potrf(const std::vector<chol_potrf_desc> &v, hipStream_t st, int 
   if (v.empty()) return 0;
   scratch sc;
   size_t wsz = 0;
-  std::vector<chol_potrf_desc> dv = v;
+  std::vector<chol_potrf_desc> dv;
+  for (const auto &p : v) if (p.n <= CHOL_RR_MAXN) dv.push_back(p);
+  const int n_small = (int)dv.size();
+  for (const auto &p : v) if (p.n > CHOL_RR_MAXN) dv.push_back(p);
   for (auto &p : dv) { p.dinv_off = (int64_t)wsz; wsz += (size_t)((p.n + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB; }
   double *W; int *info; chol_potrf_desc *dd;
   int rc = sc.get(&W, wsz);
@@ -416,7 +450,8 @@ static int run_potrf(const std::vector<chol_potrf_desc> &v, hipStream_t st, int 
   HIPCHK(hipMemsetAsync(info, 0, 2 * sizeof(int), st));
   rc = sc.put(&dd, dv.data(), dv.size(), st);
   if (rc) return rc;
-  HIPCHK((hipError_t)chol_launch_potrf(nullptr, W, dd, (int)dv.size(), info, st));
+  HIPCHK((hipError_t)chol_launch_potrf(nullptr, W, dd, n_small, info, st));
+  HIPCHK((hipError_t)chol_launch_potrf_big(nullptr, W, dd + n_small, (int)dv.size() - n_small, info, st));
   int h[2] = { 0, 0 };
   HIPCHK(hipMemcpyAsync(h, info, sizeof h, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));

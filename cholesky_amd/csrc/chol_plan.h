@@ -19,7 +19,8 @@
 extern "C" {
 #endif
 
-#define CHOL_NB 32 /* diagonal-block width of the blocked POTRF/TRSM kernels */
+#define CHOL_NB 16        /* diagonal-block width of the POTRF/TRSM kernels = one fp64 MFMA tile */
+#define CHOL_RR_MAXN 272  /* largest pivot the register-resident kernels take (17 tiles) */
 
 typedef struct {
   int n_int;    /* number of intervals */
@@ -52,7 +53,7 @@ typedef struct {
   int n, ldl, m, ldb; /* m rows (<= CHOL_TRSM_ROWS) */
 } chol_trsm_desc;
 
-#define CHOL_TRSM_ROWS 32
+#define CHOL_TRSM_ROWS 16
 
 typedef struct {
   int64_t a_off, b_off; /* first row of the A tile rows / B tile rows used by this task */

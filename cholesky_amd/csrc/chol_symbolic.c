@@ -132,6 +132,12 @@ static void scalar_symbolic(plan_t *p, const int *px, const int *py)
   free(rowptr); free(cols); free(parent); free(anc); free(mark); free(cc);
 }
 
+static int cmp_dv(const void *x, const void *y)
+{
+  const int64_t a = *(const int64_t *)x, b = *(const int64_t *)y;
+  return a < b ? -1 : (a > b);
+}
+
 /* ---------------------------------------------------------------------------------------- */
 int chol_plan_finish(plan_t *p, int nz, const int *a_row, const int *a_col, const double *a_val)
 {
@@ -236,6 +242,15 @@ int chol_plan_finish(plan_t *p, int nz, const int *a_row, const int *a_col, cons
   }
   scalar_symbolic(p, px, py);
   free(px); free(py);
+  { /* ascending arena offsets: coalesced device scatter, and the entries of the shared top of the
+     * tree (the tail of the arena) form a suffix that non-root ranks skip (multi-GPU fill) */
+    typedef struct { int64_t d; double v; } dv_t;
+    dv_t *t = malloc((size_t)(p->nnz_a > 0 ? p->nnz_a : 1) * sizeof(dv_t));
+    for (int64_t e = 0; e < p->nnz_a; e++) { t[e].d = p->a_dst[e]; t[e].v = p->a_val[e]; }
+    qsort(t, (size_t)p->nnz_a, sizeof(dv_t), cmp_dv);
+    for (int64_t e = 0; e < p->nnz_a; e++) { p->a_dst[e] = t[e].d; p->a_val[e] = t[e].v; }
+    free(t);
+  }
   /* per-level fill prediction, snapshots and the reference-order call list
    * (compute_filled_clusters mmat.rg:896-1028 interleaved with the schedule mmat.rg:1227-1355) */
   p->snap_n = calloc(L, sizeof(int64_t));

@@ -1,0 +1,31 @@
+// Diagnostic build: where does the factor wave of k_potrf_rr spend its cycles?  (not part of the product)
+//   hipcc --offload-arch=gfx950 -O3 -DCHOL_STAMPS -Iinclude -Icholesky_amd/csrc scripts/stamp_potrf.hip -o scripts/stamp_potrf
+#include "../cholesky_amd/csrc/chol_kernels.hip"
+#include <cstdio>
+#include <vector>
+#include <cmath>
+int main(int argc, char **argv)
+{
+  int n = argc > 1 ? atoi(argv[1]) : 256;
+  std::vector<double> A((size_t)n * n);
+  for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) A[i + (size_t)j * n] = (i == j) ? 4.0 + n : 1.0 / (1.0 + abs(i - j));
+  double *dA, *dW; int *dinfo; chol_potrf_desc *dd;
+  hipMalloc(&dA, A.size() * 8); hipMalloc(&dW, 64 * 256 * 8); hipMalloc(&dinfo, 8); hipMalloc(&dd, sizeof(chol_potrf_desc));
+  chol_potrf_desc d = { 0, 0, n, n, 1, 0 };
+  hipMemcpy(dd, &d, sizeof d, hipMemcpyHostToDevice);
+  for (int rep = 0; rep < 3; rep++) {
+    hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
+    hipMemset(dinfo, 0, 8);
+    hipLaunchKernelGGL(k_potrf_rr, dim3(1), dim3(1024), 0, 0, dA, dW, dd, dinfo);
+    hipDeviceSynchronize();
+  }
+  unsigned long long st[16];
+  hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof st);
+  const char *names[8] = { "", "read sDiag", "chol16", "linv16", "publish Linv", "B1 wait", "stores+B2 (solve)", "B3 wait (update)" };
+  int T = (n + 15) / 16;
+  unsigned long long tot = 0;
+  for (int i = 1; i < 8; i++) tot += st[i];
+  printf("n=%d steps=%d total %.1f cycles/step (s_memtime ticks @100MHz? see ratio)\n", n, T, (double)tot / T);
+  for (int i = 1; i < 8; i++) printf("  %-18s %10.1f ticks/step  %5.1f%%\n", names[i], (double)st[i] / T, 100.0 * st[i] / tot);
+  return 0;
+}
