@@ -89,39 +89,59 @@ __global__ __launch_bounds__(256) void k_update(double *__restrict__ base, const
 }
 
 // ================================================================================================
-// Dense pivot kernels.  Diagonal blocks are TS = 16 wide (one fp64 MFMA tile); the inverse of every
-// 16x16 diagonal block of L is written to the workspace as W[blk][k * 16 + c] = Linv(c, k), the
-// layout the TRSM kernels read as the MFMA "Y" operand.
+// Dense pivot kernels.  Diagonal blocks are TS = 16 wide (one fp64 MFMA tile).
+//
+// Triangular solves X = T L^-T against a 16x16 diagonal block never form the 16x16 inverse (its
+// serial chain is as long as the Cholesky of the block).  L is cut into 4x4 blocks; only the four
+// 4x4 diagonal blocks are inverted (chain length 4, the four blocks side by side in the quads of a
+// wave) and the solve is 7 dependent MFMAs (tile_solve below): for block column b = 0..3
+//     X_b = T_b Linv_bb^T                    one MFMA, Y operand = "Ydiag"
+//     T_{>b} -= X_b L(:, 4b..4b+3)^T         one MFMA, Y operand = register b of L in tile layout
+// Ydiag(c, k) = Linv_{c/4,c/4}(c % 4, k) is what the workspace holds per diagonal block
+// (W[blk * 256 + k * 16 + c], 64 doubles used) for the TRSM kernels.
 //
 // Register-resident design for pivots up to CHOL_RR_MAXN = 272 (17 tiles): the MI355X register
 // file (512 KB per CU) is the only on-chip memory that holds a 259 x 259 fp64 lower triangle
 // (269 KB; LDS has 160 KB), so the trailing matrix lives in VGPRs as 16x16 tiles in MFMA
-// accumulator layout, spread round-robin over 15 "tile" waves of a 1024-thread workgroup; wave 0
-// is the "factor" wave (diagonal tile: Cholesky + inverse).  An accumulator tile is directly a
-// valid "X" operand of the next MFMA (register q of lane l holds column (l >> 4) + 4 q = k-step q
-// of the operand map), so the panel solve X = T Linv^T and the trailing update T -= P_i P_j^T need
-// no data movement for T; P goes through LDS.
+// accumulator layout, spread round-robin over 11 "tile" waves of a 768-thread workgroup (3 waves per SIMD = 168 registers each); wave 0
+// is the "factor" wave (Cholesky of the diagonal tile).  An accumulator tile is directly a valid
+// "X" operand of the next MFMA (register q of lane l holds column (l >> 4) + 4 q = k-step q of the
+// operand map), so neither the panel solve nor the trailing update T -= P_i P_j^T moves T; P goes
+// through LDS.  Look-ahead: the owner of tile (k+1, k+1) updates and hands it to the factor wave
+// first, so the factor wave works on step k+1 while the tile waves finish the updates of step k.
 // ================================================================================================
 #define TS 16
 #define RR_MAXT 17
+#define RR_TILE_WAVES 11
+#define RR_SLOTS 14 /* ceil(17 * 18 / 2 / 11) */
+#define RR_THREADS ((RR_TILE_WAVES + 1) * 64)
 // In-kernel cycle stamps of the factor wave: diagnostic builds only (-DCHOL_STAMPS, scripts/stamp_potrf.hip)
 #ifdef CHOL_STAMPS
 __device__ unsigned long long g_stamps[16];
 #define STAMP_DECL unsigned long long st_[8], acc_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
 #define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_[i]) :: "memory"); __builtin_amdgcn_sched_barrier(0); if ((i) > 0) acc_[i] += st_[i] - st_[(i) - 1]; } while (0)
 #define STAMP_FLUSH do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) g_stamps[i_] = acc_[i_]; } while (0)
+#define STAMP_FLUSH2 do { if (lane == 0 && w == 3) for (int i_ = 0; i_ < 8; ++i_) g_stamps[8 + i_] = acc_[i_]; } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(i)
 #define STAMP_FLUSH
+#define STAMP_FLUSH2
 #endif
-#define RR_TILE_WAVES 15
-#define RR_SLOTS 11 /* ceil(17 * 18 / 2 / 15) */
 
 __device__ __forceinline__ double readlane_f64(double v, int l)
 {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// broadcast of quad-lane I inside every quad (4 consecutive lanes), DPP quad_perm
+template <int I> __device__ __forceinline__ double quad_bcast(double v)
+{
+  constexpr int ctrl = I | (I << 2) | (I << 4) | (I << 6);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 
@@ -140,10 +160,11 @@ __device__ __forceinline__ double rsqrt_nr(double d)
 
 // 16x16 lower Cholesky, one row per lane (row = lane & 15; the four 16-lane groups of the wave
 // compute the same thing).  a[c] = A(row, c) on entry (c <= row used), L(row, c) on exit.
-// inv[j] = 1 / L(j, j) (wave uniform).  Returns the first non-positive pivot (1-based) or 0.
-__device__ __forceinline__ int chol16_rows(double (&a)[TS], double (&inv)[TS])
+// myinv = 1 / L(row, row).  Returns the first non-positive pivot (1-based) or 0.
+__device__ __forceinline__ int chol16_rows(double (&a)[TS], double &myinv, int r15)
 {
   int bad = 0;
+  myinv = 0.0;
 #pragma unroll
   for (int j = 0; j < TS; ++j) {
     const double d = readlane_f64(a[j], j);
@@ -151,8 +172,9 @@ __device__ __forceinline__ int chol16_rows(double (&a)[TS], double (&inv)[TS])
 #pragma unroll
     for (int k = j + 1; k < TS; ++k) akj[k] = readlane_f64(a[j], k); // unscaled column j, overlaps the rsqrt chain
     if (!(d > 0.0) && bad == 0) bad = j + 1;
-    const double r = readlane_f64(rsqrt_nr(d), 0); // wave uniform: keep it in SGPRs
-    inv[j] = r;
+    const double rv = rsqrt_nr(d);
+    const double r = readlane_f64(rv, 0); // wave uniform: keep it in SGPRs
+    myinv = (r15 == j) ? rv : myinv;
     const double t = a[j] * (r * r);
 #pragma unroll
     for (int k = j + 1; k < TS; ++k) a[k] = fma(-t, akj[k], a[k]);
@@ -162,21 +184,52 @@ __device__ __forceinline__ int chol16_rows(double (&a)[TS], double (&inv)[TS])
   return bad;
 }
 
-// Inverse of the lower factor held row-per-lane: on exit lane c holds column c of Linv,
-// x[r] = Linv(r, c) (zero for r < c).
-__device__ __forceinline__ void linv16_cols(const double (&a)[TS], const double (&inv)[TS], double (&x)[TS], int lane15)
+// Inverses of the four 4x4 diagonal blocks, one block per quad.  Lane r15 = 4 b + i holds
+// blk[k] = L(4b+i, 4b+k) and invd = 1 / L(4b+i, 4b+i).  On exit x[m] = Linv_bb(m, i): the lane owns
+// column i of its block's inverse.
+__device__ __forceinline__ void linv4_quad(const double (&blk)[4], double invd, double (&x)[4], int qi)
 {
+  const double inv0 = quad_bcast<0>(invd), inv1 = quad_bcast<1>(invd), inv2 = quad_bcast<2>(invd), inv3 = quad_bcast<3>(invd);
+  const double l10 = quad_bcast<1>(blk[0]);
+  const double l20 = quad_bcast<2>(blk[0]), l21 = quad_bcast<2>(blk[1]);
+  const double l30 = quad_bcast<3>(blk[0]), l31 = quad_bcast<3>(blk[1]), l32 = quad_bcast<3>(blk[2]);
+  x[0] = (qi == 0) ? inv0 : 0.0;
+  x[1] = (qi == 1) ? inv1 : -(l10 * x[0]) * inv1;
+  x[2] = (qi == 2) ? inv2 : -fma(l21, x[1], l20 * x[0]) * inv2;
+  x[3] = (qi == 3) ? inv3 : -fma(l32, x[2], fma(l31, x[1], l30 * x[0])) * inv3;
+}
+
+// X = T L^-T for a 16x16 tile T in accumulator layout.  Lr[b] = L(r15, 4b + g), b = 0..2 (register b
+// of the diagonal block in tile layout), yd = Ydiag(c = r15, k = g).
+__device__ __forceinline__ d4 tile_solve(d4 t, const double (&Lr)[3], double yd)
+{
+  const d4 z = { 0.0, 0.0, 0.0, 0.0 };
+  d4 x, s, u;
+  s = __builtin_amdgcn_mfma_f64_16x16x4f64(yd, t[0], z, 0, 0, 0);
+  x[0] = s[0];
+  u = __builtin_amdgcn_mfma_f64_16x16x4f64(Lr[0], -x[0], t, 0, 0, 0);
+  s = __builtin_amdgcn_mfma_f64_16x16x4f64(yd, u[1], z, 0, 0, 0);
+  x[1] = s[1];
+  u = __builtin_amdgcn_mfma_f64_16x16x4f64(Lr[1], -x[1], u, 0, 0, 0);
+  s = __builtin_amdgcn_mfma_f64_16x16x4f64(yd, u[2], z, 0, 0, 0);
+  x[2] = s[2];
+  u = __builtin_amdgcn_mfma_f64_16x16x4f64(Lr[2], -x[2], u, 0, 0, 0);
+  s = __builtin_amdgcn_mfma_f64_16x16x4f64(yd, u[3], z, 0, 0, 0);
+  x[3] = s[3];
+  return x;
+}
+
+// the lane's own 4x4 diagonal-block row out of its 16-entry row: blk[k] = a[4 (r15 / 4) + k]
+__device__ __forceinline__ void own_block_row(const double (&a)[TS], int r15, double (&blk)[4])
+{
+  const int b = r15 >> 2;
 #pragma unroll
-  for (int r = 0; r < TS; ++r) {
-    double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-    for (int k = 0; k < r; ++k) {
-      const double lrk = readlane_f64(a[k], r); // L(r, k)
-      if (k & 1) s1 = fma(lrk, x[k], s1); else s0 = fma(lrk, x[k], s0);
-    }
-    const double v = -(s0 + s1) * inv[r];
-    x[r] = (lane15 == r) ? inv[r] : v; // rows above the diagonal of this column come out as -0 * inv = 0
-    __builtin_amdgcn_sched_barrier(0); // keep the 120 broadcast pairs from being hoisted together
+  for (int k = 0; k < 4; ++k) {
+    double v = a[k];
+    v = (b == 1) ? a[4 + k] : v;
+    v = (b == 2) ? a[8 + k] : v;
+    v = (b == 3) ? a[12 + k] : v;
+    blk[k] = v;
   }
 }
 
@@ -188,12 +241,15 @@ __device__ __forceinline__ void tile_of_index(int idx, int T, int &ti, int &tj)
   if (j >= T) { ti = -1; tj = 1 << 20; } else { ti = j + idx; tj = j; }
 }
 
-__global__ __launch_bounds__(1024) void k_potrf_rr(double *__restrict__ base, double *__restrict__ ws,
+__global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ base, double *__restrict__ ws,
                                                    const chol_potrf_desc *__restrict__ descs, int *__restrict__ info)
 {
   __shared__ double sPanel[RR_MAXT][TS][TS]; // [tile i][k][r]: solved panel of the current step
-  __shared__ double sDiag[TS][TS + 1];       // [r][c]: diagonal tile on its way to / from the factor wave
-  __shared__ double sLinv[TS][TS + 1];       // [k][c] = Linv(c, k)
+  __shared__ double sDiag[TS][TS + 1];       // [r][c]: diagonal tile on its way to the factor wave
+  __shared__ double sL[TS][TS + 1];          // [r][c]: factored diagonal block L(k,k) for the tile waves
+  __shared__ double sYd[4][TS];              // [k][c] = Ydiag(c, k)
+  __shared__ unsigned short sIJ[RR_SLOTS * RR_TILE_WAVES + 16];
+  __shared__ int sFlag;                      // number of diagonal tiles handed to the factor wave
   const chol_potrf_desc d = descs[blockIdx.x];
   double *A = base + d.a_off;
   double *W = ws + d.dinv_off;
@@ -204,66 +260,66 @@ __global__ __launch_bounds__(1024) void k_potrf_rr(double *__restrict__ base, do
   const int r15 = lane & 15, g = lane >> 4;
 
   // (i, j) of every lower-triangle tile, column-major enumeration; slot s of tile wave w holds tile
-  // s * RR_TILE_WAVES + w.  Kept in LDS (one broadcast read per use) instead of 22 live scalars.
-  __shared__ unsigned short sIJ[RR_SLOTS * RR_TILE_WAVES + 16];
-  for (int t = threadIdx.x; t < RR_SLOTS * RR_TILE_WAVES; t += 1024) {
+  // s * RR_TILE_WAVES + w
+  for (int t = threadIdx.x; t < RR_SLOTS * RR_TILE_WAVES; t += RR_THREADS) {
     int ti, tj;
     tile_of_index(t, T, ti, tj);
     sIJ[t] = ti < 0 ? (unsigned short)0xffff : (unsigned short)(ti | (tj << 8));
   }
+  if (threadIdx.x == 0) sFlag = 0;
   __syncthreads();
 
   if (wave == 0) {
     // ------------------------------------------------------------------ factor wave
-    __syncthreads(); // B0: tile (0,0) published
+    __builtin_amdgcn_s_setprio(3); // its dependent chain is the critical path of the whole pivot
     STAMP_DECL;
     for (int k = 0; k < T; ++k) {
-      double a[TS], inv[TS], x[TS];
       STAMP(0);
+      // wait for tile (k, k): published by its owner as soon as it has its last update
+      while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= k) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      double a[TS], blk[4], x[4], myinv;
 #pragma unroll
       for (int c = 0; c < TS; ++c) a[c] = sDiag[r15][c];
       STAMP(1);
-      const int bad = chol16_rows(a, inv);
+      const int bad = chol16_rows(a, myinv, r15);
       STAMP(2);
       if (bad && k * TS + bad <= n && lane == 0) {
         if (atomicCAS(&info[0], 0, k * TS + bad) == 0) info[1] = d.sep;
       }
-      linv16_cols(a, inv, x, r15);
+      own_block_row(a, r15, blk);
+      linv4_quad(blk, myinv, x, r15 & 3);
       STAMP(3);
+      // sL / sYd are free: the tile waves read them only between B2 and B3 of the previous step
       if (lane < TS) {
+        const int b4 = lane & ~3, qi = lane & 3;
 #pragma unroll
-        for (int c = 0; c < TS; ++c) sLinv[lane][c] = x[c]; // lane = column index kk: sLinv[kk][cc] = Linv(cc, kk)
+        for (int c = 0; c < TS; ++c) sL[lane][c] = (c <= lane) ? a[c] : 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) sYd[qi][b4 + m] = x[m]; // Ydiag(c = 4b+m, k = qi) = Linv_bb(m, qi)
       }
       STAMP(4);
-      __syncthreads(); // B1: Linv(k) published
+      __syncthreads(); // B2: L(k,k) and Ydiag(k) published
       STAMP(5);
-      if (lane < TS) { // global stores overlap the tile waves' panel solve
-        const int row = k * TS + lane;
-        double *dst = A + row + (int64_t)(k * TS) * lda;
-        double *wd = W + (int64_t)k * TS * TS + lane * TS;
-#pragma unroll
-        for (int c = 0; c < TS; ++c) wd[c] = x[c];
-        if (row < n) {
-#pragma unroll
-          for (int c = 0; c < TS; ++c)
-            if (c <= lane) dst[(int64_t)c * lda] = a[c]; // L(k,k), lower part
-        }
-      }
-      __syncthreads(); // B2: panel solved
+      __syncthreads(); // B3: panel solved
       STAMP(6);
-      __syncthreads(); // B3: trailing update done, tile (k+1,k+1) published
-      STAMP(7);
     }
     STAMP_FLUSH;
   } else {
     // ------------------------------------------------------------------ tile waves
     d4 tile[RR_SLOTS];
     const int w = wave - 1;
-    int ijp[RR_SLOTS]; // packed (i | j << 8) per slot, wave uniform (11 scalars)
+    int ijp[RR_SLOTS]; // packed (i | j << 8) per slot, wave uniform
 #pragma unroll
     for (int s = 0; s < RR_SLOTS; ++s) ijp[s] = __builtin_amdgcn_readfirstlane((int)sIJ[s * RR_TILE_WAVES + w]);
 #define SLOT_IJ(s, ti_, tj_) \
     const int ti_ = (ijp[s] == 0xffff) ? -1 : (ijp[s] & 0xff), tj_ = (ijp[s] == 0xffff) ? (1 << 20) : (ijp[s] >> 8)
+#define PUBLISH_DIAG(v, kk)                                                     \
+    do {                                                                        \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) sDiag[r15][g + 4 * q] = (v)[q]; \
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                    \
+      if (lane == 0) __hip_atomic_store(&sFlag, (kk) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    } while (0)
 #pragma unroll
     for (int s = 0; s < RR_SLOTS; ++s) {
       SLOT_IJ(s, ti, tj);
@@ -279,51 +335,75 @@ __global__ __launch_bounds__(1024) void k_potrf_rr(double *__restrict__ base, do
           if (rowok && col < n) e = (ti > tj || c <= r15) ? src[(int64_t)(4 * q) * lda] : 0.0;
           v[q] = e;
         }
-        if (ti == 0 && tj == 0) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) sDiag[r15][g + 4 * q] = v[q];
-        }
+        if (ti == 0 && tj == 0) PUBLISH_DIAG(v, 0);
       }
       tile[s] = v;
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads(); // B0
+    double *const sP = &sPanel[0][0][0];
+    STAMP_DECL;
     for (int k = 0; k < T; ++k) {
-      __syncthreads(); // B1
-      // ---- panel solve: X = T Linv^T for owned tiles (i, k), i > k
+      STAMP(0);
+      // lane part of every LDS panel address, made opaque once per step so that the 2 x 14 per-slot
+      // addresses are formed where they are used instead of being hoisted (and spilled) as invariants
+      int lp = g * TS + r15;
+      asm volatile("" : "+v"(lp));
+      __syncthreads(); // B2: L(k,k), Ydiag(k) available; every tile wave has finished step k-1
+      STAMP(1);
+      // ---- panel solve: X = T L(k,k)^-T for owned tiles (i, k), i > k
+      {
+        double Lr[3];
 #pragma unroll
-      for (int s = 0; s < RR_SLOTS; ++s) {
-        SLOT_IJ(s, ti, tj);
-        if (tj == k && ti > k) {
-          d4 x = { 0.0, 0.0, 0.0, 0.0 };
+        for (int b = 0; b < 3; ++b) Lr[b] = sL[r15][g + 4 * b];
+        const double yd = sYd[g][r15];
+        if (w == (k % RR_TILE_WAVES)) { // one tile wave per step writes L(k,k) and Ydiag(k) back (off the critical path)
+          const double l3 = sL[r15][g + 12];
+          const int row = k * TS + r15;
+          double *dst = A + row + (int64_t)(k * TS + g) * lda;
+          if (row < n) {
 #pragma unroll
-          for (int st = 0; st < 4; ++st) x = __builtin_amdgcn_mfma_f64_16x16x4f64(sLinv[4 * st + g][r15], tile[s][st], x, 0, 0, 0);
-          tile[s] = x; // final values of L(i, k): stay in registers until the epilogue stores them
-#pragma unroll
-          for (int q = 0; q < 4; ++q) sPanel[ti][g + 4 * q][r15] = x[q];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      __syncthreads(); // B2
-      // ---- trailing update: T(i, j) -= P_i P_j^T for owned tiles with j > k
-#pragma unroll
-      for (int s = 0; s < RR_SLOTS; ++s) {
-        SLOT_IJ(s, ti, tj);
-        if (tj > k && tj < T) {
-          d4 acc = tile[s];
-#pragma unroll
-          for (int st = 0; st < 4; ++st)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sPanel[tj][4 * st + g][r15], -sPanel[ti][4 * st + g][r15], acc, 0, 0, 0);
-          tile[s] = acc;
-          if (tj == k + 1 && ti == k + 1) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sDiag[r15][g + 4 * q] = acc[q];
+            for (int b = 0; b < 3; ++b)
+              if (g + 4 * b <= r15) dst[(int64_t)(4 * b) * lda] = Lr[b];
+            if (g + 12 <= r15) dst[(int64_t)12 * lda] = l3;
           }
+          W[(int64_t)k * TS * TS + g * TS + r15] = yd;
         }
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < RR_SLOTS; ++s) {
+          SLOT_IJ(s, ti, tj);
+          if (tj == k && ti > k) {
+            const d4 x = tile_solve(tile[s], Lr, yd);
+            tile[s] = x; // final values of L(i, k): stay in registers until the epilogue stores them
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sP[ti * (TS * TS) + q * (4 * TS) + lp] = x[q];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      __syncthreads(); // B3
+      STAMP(2);
+      __syncthreads(); // B3: panel published
+      STAMP(3);
+      // ---- trailing update T(i, j) -= P_i P_j^T, j > k; the next diagonal tile first (look-ahead)
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int s = 0; s < RR_SLOTS; ++s) {
+          SLOT_IJ(s, ti, tj);
+          const bool next_diag = (tj == k + 1 && ti == k + 1);
+          if (tj > k && tj < T && (pass == 0 ? next_diag : !next_diag)) {
+            d4 acc = tile[s];
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sP[tj * (TS * TS) + st * (4 * TS) + lp], -sP[ti * (TS * TS) + st * (4 * TS) + lp], acc, 0, 0, 0);
+            tile[s] = acc;
+            if (next_diag) PUBLISH_DIAG(acc, k + 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      STAMP(4);
     }
+    STAMP_FLUSH2;
     // epilogue: every off-diagonal tile now holds its block of L
 #pragma unroll
     for (int s = 0; s < RR_SLOTS; ++s) {
@@ -338,6 +418,7 @@ __global__ __launch_bounds__(1024) void k_potrf_rr(double *__restrict__ base, do
       __builtin_amdgcn_sched_barrier(0);
     }
 #undef SLOT_IJ
+#undef PUBLISH_DIAG
   }
 }
 
@@ -348,7 +429,8 @@ __global__ __launch_bounds__(1024) void k_potrf_rr(double *__restrict__ base, do
 __global__ __launch_bounds__(256) void k_potrf_big(double *__restrict__ base, double *__restrict__ ws,
                                                    const chol_potrf_desc *__restrict__ descs, int *__restrict__ info)
 {
-  __shared__ double sLinv[TS][TS + 1];
+  __shared__ double sL[TS][TS + 1];
+  __shared__ double sYd[4][TS];
   const chol_potrf_desc d = descs[blockIdx.x];
   double *A = base + d.a_off;
   double *W = ws + d.dinv_off;
@@ -359,7 +441,7 @@ __global__ __launch_bounds__(256) void k_potrf_big(double *__restrict__ base, do
   for (int k = 0, j0 = 0; j0 < n; ++k, j0 += TS) {
     const int below = n - j0 - TS; // rows under the diagonal tile (may be <= 0)
     if (wave == 0) {
-      double a[TS], inv[TS], x[TS];
+      double a[TS], blk[4], x[4], myinv;
       const int row = j0 + r15;
 #pragma unroll
       for (int c = 0; c < TS; ++c) {
@@ -367,34 +449,44 @@ __global__ __launch_bounds__(256) void k_potrf_big(double *__restrict__ base, do
         if (row < n && j0 + c < n) v = (c <= r15) ? A[row + (int64_t)(j0 + c) * lda] : 0.0;
         a[c] = v;
       }
-      const int bad = chol16_rows(a, inv);
+      const int bad = chol16_rows(a, myinv, r15);
       if (bad && j0 + bad <= n && lane == 0) {
         if (atomicCAS(&info[0], 0, j0 + bad) == 0) info[1] = d.sep;
       }
-      linv16_cols(a, inv, x, r15);
+      own_block_row(a, r15, blk);
+      linv4_quad(blk, myinv, x, r15 & 3);
       if (lane < TS) {
+        const int b4 = lane & ~3, qi = lane & 3;
 #pragma unroll
         for (int c = 0; c < TS; ++c) {
+          sL[lane][c] = (c <= lane) ? a[c] : 0.0;
           if (row < n && c <= lane) A[row + (int64_t)(j0 + c) * lda] = a[c];
-          sLinv[lane][c] = x[c];
-          W[(int64_t)k * TS * TS + lane * TS + c] = x[c];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          sYd[qi][b4 + m] = x[m];
+          W[(int64_t)k * TS * TS + qi * TS + b4 + m] = x[m];
         }
       }
     }
     __syncthreads();
-    // panel: 16-row tiles below the diagonal tile, X = T Linv^T
+    // panel: 16-row tiles below the diagonal tile
     const int nt = below > 0 ? (below + TS - 1) / TS : 0;
-    for (int t = wave; t < nt; t += 4) {
-      const int row = j0 + TS + t * TS + r15;
-      d4 x = { 0.0, 0.0, 0.0, 0.0 };
+    {
+      double Lr[3];
 #pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        const double tv = (row < n) ? A[row + (int64_t)(j0 + 4 * st + g) * lda] : 0.0;
-        x = __builtin_amdgcn_mfma_f64_16x16x4f64(sLinv[4 * st + g][r15], tv, x, 0, 0, 0);
+      for (int b = 0; b < 3; ++b) Lr[b] = sL[r15][g + 4 * b];
+      const double yd = sYd[g][r15];
+      for (int t = wave; t < nt; t += 4) {
+        const int row = j0 + TS + t * TS + r15;
+        d4 tv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tv[q] = (row < n) ? A[row + (int64_t)(j0 + g + 4 * q) * lda] : 0.0;
+        const d4 x = tile_solve(tv, Lr, yd);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (row < n) A[row + (int64_t)(j0 + g + 4 * q) * lda] = x[q];
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (row < n) A[row + (int64_t)(j0 + g + 4 * q) * lda] = x[q];
     }
     __syncthreads();
     // trailing update of the lower triangle
@@ -423,36 +515,39 @@ __global__ __launch_bounds__(256) void k_potrf_big(double *__restrict__ base, do
 }
 
 // ------------------------------------------------------------------------------------------------
-// Inverses of the 16x16 diagonal blocks of an already factored L (BLAS-/task-level TRSM entry
-// points, where L was not produced by a POTRF kernel of the same call chain).  One wave per block.
+// Ydiag of the 16x16 diagonal blocks of an already factored L (BLAS-/task-level TRSM entry points,
+// where L was not produced by a POTRF kernel of the same call chain).  One wave per block.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_dinv(const double *__restrict__ Lp, int n, int ldl, double *__restrict__ W)
 {
   const int j0 = blockIdx.x * TS, lane = threadIdx.x, r15 = lane & 15;
-  double a[TS], inv[TS], x[TS];
-  const int row = j0 + r15;
+  const int row = j0 + r15, b4 = r15 & ~3, qi = r15 & 3;
+  double blk[4], x[4];
 #pragma unroll
-  for (int c = 0; c < TS; ++c) {
-    double v = (r15 == c) ? 1.0 : 0.0;
-    if (row < n && j0 + c < n) v = (c <= r15) ? Lp[row + (int64_t)(j0 + c) * ldl] : 0.0;
-    a[c] = v;
+  for (int k = 0; k < 4; ++k) {
+    const int col = j0 + b4 + k;
+    double v = (k == qi) ? 1.0 : 0.0; // identity padding past n
+    if (row < n && col < n) v = (k <= qi) ? Lp[row + (int64_t)col * ldl] : 0.0;
+    blk[k] = v;
   }
-#pragma unroll
-  for (int j = 0; j < TS; ++j) inv[j] = readlane_f64(1.0 / readlane_f64(a[j], j), 0);
-  linv16_cols(a, inv, x, r15);
+  double diag = blk[0];
+  diag = (qi == 1) ? blk[1] : diag;
+  diag = (qi == 2) ? blk[2] : diag;
+  diag = (qi == 3) ? blk[3] : diag;
+  linv4_quad(blk, 1.0 / diag, x, qi);
   if (lane < TS) {
 #pragma unroll
-    for (int c = 0; c < TS; ++c) W[(int64_t)blockIdx.x * TS * TS + lane * TS + c] = x[c];
+    for (int m = 0; m < 4; ++m) W[(int64_t)blockIdx.x * TS * TS + qi * TS + b4 + m] = x[m];
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // TRSM: B <- B L^-T for a strip of <= 16 rows (cblas_dtrsm Right/Lower/Trans/NonUnit alpha=1,
 // blas.rg:99), n <= CHOL_RR_MAXN.  The strip's 16x16 column tiles live in registers (accumulator
-// layout), tile J owned by wave J mod 4.  Right-looking: the owner solves X_J = T_J Linv_J^T (the
-// accumulator tile is the MFMA X operand as it stands), publishes X_J in LDS (double buffered, one
-// barrier per step), and every wave applies T_J'' -= X_J L(J'', J)^T to its tiles J'' > J with the
-// L tile streamed from global memory / L2.
+// layout), tile J owned by wave J mod 4.  Right-looking: the owner solves X_J = T_J L(J,J)^-T
+// (tile_solve), publishes X_J in LDS (double buffered, one barrier per step), and every wave
+// applies T_J'' -= X_J L(J'', J)^T to its tiles J'' > J with the L tile streamed from global
+// memory / L2 ahead of the barrier.
 // ------------------------------------------------------------------------------------------------
 #define TRSM_SLOTS 5 /* ceil(17 / 4) */
 __global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base, const double *__restrict__ ws,
@@ -484,10 +579,35 @@ __global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base, cons
     }
     tile[s] = v;
   }
+  // diagonal-block operands of the solve of column tile J (Lr = L(J,J) in tile layout, yd = Ydiag(J))
+#define LOAD_DIAG_OPERANDS(J_, Lr_, yd_)                                                                \
+  {                                                                                                     \
+    const int lrow_ = (J_) * TS + r15;                                                                  \
+    _Pragma("unroll") for (int b = 0; b < 3; ++b) {                                                     \
+      const int col_ = (J_) * TS + g + 4 * b;                                                           \
+      Lr_[b] = (lrow_ < n && col_ < n && g + 4 * b <= r15) ? Lm[lrow_ + (int64_t)col_ * ldl] : 0.0;     \
+    }                                                                                                   \
+    yd_ = W[(int64_t)(J_) * TS * TS + g * TS + r15];                                                    \
+  }
+#define PUBLISH_X(J_, x_)                                                                               \
+  {                                                                                                     \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                     \
+      const int c_ = g + 4 * q, col_ = (J_) * TS + c_;                                                  \
+      sX[(J_) & 1][c_][r15] = x_[q];                                                                    \
+      if (vrow && col_ < n) B[r15 + (int64_t)col_ * ldb] = x_[q];                                       \
+    }                                                                                                   \
+  }
+  if (wave == 0) { // column tile 0 has no predecessors
+    double Lr[3], yd;
+    LOAD_DIAG_OPERANDS(0, Lr, yd);
+    const d4 x = tile_solve(tile[0], Lr, yd);
+    PUBLISH_X(0, x);
+  }
 #pragma unroll
   for (int J = 0; J < RR_MAXT; ++J) {
     if (J < T) {
-      // L tiles of this step's updates: issued ahead of the solve and the barrier that hide their latency
+      // L tiles of this step's updates and the diagonal operands of the next solve: issued ahead of
+      // the barrier that hides their latency
       double lpre[TRSM_SLOTS][4];
 #pragma unroll
       for (int s = 0; s < TRSM_SLOTS; ++s) {
@@ -498,23 +618,26 @@ __global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base, cons
 #pragma unroll
         for (int st = 0; st < 4; ++st) lpre[s][st] = ok ? lp[(int64_t)(4 * st) * ldl] : 0.0;
       }
-      if ((J & 3) == wave) { // solve
-        const double *V = W + (int64_t)J * TS * TS;
-        d4 x = { 0.0, 0.0, 0.0, 0.0 };
+      const bool next_owner = (J + 1 < T) && (((J + 1) & 3) == wave);
+      double LrN[3] = { 0.0, 0.0, 0.0 }, ydN = 0.0;
+      if (next_owner) LOAD_DIAG_OPERANDS(J + 1, LrN, ydN);
+      __syncthreads(); // X_J visible
+      if (next_owner) { // look-ahead: bring tile J+1 up to date, solve it and publish it first
+        const int s1 = (J + 1) >> 2;
+        if (s1 < TRSM_SLOTS) {
+          d4 acc = tile[s1];
 #pragma unroll
-        for (int st = 0; st < 4; ++st) x = __builtin_amdgcn_mfma_f64_16x16x4f64(V[(4 * st + g) * TS + r15], tile[J >> 2][st], x, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c = g + 4 * q, col = J * TS + c;
-          sX[J & 1][c][r15] = x[q];
-          if (vrow && col < n) B[r15 + (int64_t)col * ldb] = x[q];
+          for (int st = 0; st < 4; ++st)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lpre[s1][st], -sX[J & 1][4 * st + g][r15], acc, 0, 0, 0);
+          const d4 x = tile_solve(acc, LrN, ydN);
+          tile[s1] = x;
+          PUBLISH_X(J + 1, x);
         }
       }
-      __syncthreads();
 #pragma unroll
       for (int s = 0; s < TRSM_SLOTS; ++s) {
         const int J2 = wave + 4 * s;
-        if (J2 > J && J2 < T) {
+        if (J2 > J + 1 && J2 < T) {
           d4 acc = tile[s];
 #pragma unroll
           for (int st = 0; st < 4; ++st)
@@ -524,11 +647,13 @@ __global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base, cons
       }
     }
   }
+#undef LOAD_DIAG_OPERANDS
+#undef PUBLISH_X
 }
 
 // ------------------------------------------------------------------------------------------------
 // TRSM for pivots larger than CHOL_RR_MAXN: one independent wave per 16-row strip (4 strips per
-// workgroup), left-looking from global memory: T_J = B_J - X_<J L(J,<J)^T, X_J = T_J Linv_J^T.
+// workgroup), left-looking from global memory: T_J = B_J - X_<J L(J,<J)^T, X_J = T_J L(J,J)^-T.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_trsm_big(double *__restrict__ base, const double *__restrict__ ws,
                                                   const chol_trsm_desc *__restrict__ descs, int ndesc)
@@ -552,10 +677,14 @@ __global__ __launch_bounds__(256) void k_trsm_big(double *__restrict__ base, con
       const int c = g + 4 * q;
       t[q] = (r15 < m && c < nv) ? B[r15 + (int64_t)(j0 + c) * ldb] - acc[q] : 0.0;
     }
-    const double *V = W + (int64_t)J * TS * TS;
-    d4 x = { 0.0, 0.0, 0.0, 0.0 };
+    double Lr[3];
 #pragma unroll
-    for (int st = 0; st < 4; ++st) x = __builtin_amdgcn_mfma_f64_16x16x4f64(V[(4 * st + g) * TS + r15], t[st], x, 0, 0, 0);
+    for (int b = 0; b < 3; ++b) {
+      const int c = g + 4 * b;
+      Lr[b] = (j0 + r15 < n && j0 + c < n && c <= r15) ? Lm[(j0 + r15) + (int64_t)(j0 + c) * ldl] : 0.0;
+    }
+    const double yd = W[(int64_t)J * TS * TS + g * TS + r15];
+    const d4 x = tile_solve(t, Lr, yd);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int c = g + 4 * q;
@@ -710,7 +839,7 @@ int chol_launch_scatter(double *arena, const int64_t *dst, const double *val, in
 int chol_launch_potrf(double *base, double *ws, const chol_potrf_desc *descs, int n, int *info, hipStream_t st)
 { // pivots up to CHOL_RR_MAXN: register-resident kernel, one 1024-thread workgroup each
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(k_potrf_rr, dim3(n), dim3(1024), 0, st, base, ws, descs, info);
+  hipLaunchKernelGGL(k_potrf_rr, dim3(n), dim3(RR_THREADS), 0, st, base, ws, descs, info);
   return (int)hipGetLastError();
 }
 int chol_launch_potrf_big(double *base, double *ws, const chol_potrf_desc *descs, int n, int *info, hipStream_t st)

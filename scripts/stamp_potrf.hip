@@ -16,16 +16,19 @@ int main(int argc, char **argv)
   for (int rep = 0; rep < 3; rep++) {
     hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
     hipMemset(dinfo, 0, 8);
-    hipLaunchKernelGGL(k_potrf_rr, dim3(1), dim3(1024), 0, 0, dA, dW, dd, dinfo);
+    hipLaunchKernelGGL(k_potrf_rr, dim3(1), dim3(RR_THREADS), 0, 0, dA, dW, dd, dinfo);
     hipDeviceSynchronize();
   }
   unsigned long long st[16];
   hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof st);
-  const char *names[8] = { "", "read sDiag", "chol16", "linv16", "publish Linv", "B1 wait", "stores+B2 (solve)", "B3 wait (update)" };
+  const char *names[8] = { "", "wait diag tile", "chol16", "linv4", "publish L,Yd", "B2 wait", "stores+B3 (solve)", "-" };
   int T = (n + 15) / 16;
   unsigned long long tot = 0;
   for (int i = 1; i < 8; i++) tot += st[i];
   printf("n=%d steps=%d total %.1f cycles/step (s_memtime ticks @100MHz? see ratio)\n", n, T, (double)tot / T);
   for (int i = 1; i < 8; i++) printf("  %-18s %10.1f ticks/step  %5.1f%%\n", names[i], (double)st[i] / T, 100.0 * st[i] / tot);
+  const char *n2[8] = { "", "B2 wait", "solve", "B3 wait", "update (both passes)", "", "", "" };
+  printf("tile wave 3:\n");
+  for (int i = 1; i < 5; i++) printf("  %-22s %10.1f ticks/step\n", n2[i], (double)st[8 + i] / T);
   return 0;
 }
