@@ -112,9 +112,6 @@ __global__ __launch_bounds__(256) void k_update(double *__restrict__ base, const
 // ================================================================================================
 #define TS 16
 #define RR_MAXT 17
-#define RR_TILE_WAVES 11
-#define RR_SLOTS 14 /* ceil(17 * 18 / 2 / 11) */
-#define RR_THREADS ((RR_TILE_WAVES + 1) * 64)
 // In-kernel cycle stamps of the factor wave: diagnostic builds only (-DCHOL_STAMPS, scripts/stamp_potrf.hip)
 #ifdef CHOL_STAMPS
 __device__ unsigned long long g_stamps[16];
@@ -241,90 +238,158 @@ __device__ __forceinline__ void tile_of_index(int idx, int T, int &ti, int &tj)
   if (j >= T) { ti = -1; tj = 1 << 20; } else { ti = j + idx; tj = j; }
 }
 
-__global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ base, double *__restrict__ ws,
-                                                   const chol_potrf_desc *__restrict__ descs, int *__restrict__ info)
+// ------------------------------------------------------------------------------------------------
+// k_potrf_rr: register-resident POTRF, one 768-thread workgroup per pivot (n <= CHOL_RR_MAXN).
+//
+// Roles.  Wave 0 = factor wave, waves 1..11 = tile waves.  The lower triangle of 16x16 tiles is
+// enumerated column-major and dealt round-robin to the tile waves (slot s of tile wave w holds tile
+// s * 11 + w); a tile stays in registers (accumulator layout) while it still receives updates.
+//
+// Step k (block column k):
+//   factor wave   a. Cholesky of the diagonal tile (k,k) (row per lane) + 4x4 block inverses,
+//                    publishes L(k,k) / Ydiag(k) in LDS                                [flag fL]
+//                 b. waits until every tile wave has finished the updates of step k-1   [cnt cUpd]
+//                 c. solves the sub-diagonal tile (k+1,k) itself (7 MFMAs), publishes it [flag fP]
+//                 d. applies it to the diagonal tile (k+1,k+1) it already holds (4 MFMAs) and
+//                    goes straight to step k+1: the chain a-c-d never waits for a tile wave's
+//                    dispatch, only for the (coarse) cUpd counter.
+//   tile waves    1. solve the remaining panel tiles (i,k), i >= k+2, out of LDS: raw tiles of a
+//                    column are parked in LDS by their owners after their last update, so the solve
+//                    is a plain loop (tile i -> wave i mod 11) with no register-array dispatch
+//                 2. software barrier (LDS counter cSol) + fP
+//                 3. trailing update of their register tiles, slots walked from the top down with
+//                    one early exit (the active tiles are a suffix of the enumeration); a tile that
+//                    just got its last update is parked: column k+1 -> sRaw, diagonal (k+2,k+2) ->
+//                    sDg (handed to the factor wave one step ahead)
+//                 4. cUpd += 1
+// All hand-offs are LDS words written after a workgroup-scope release fence and polled relaxed,
+// then acquired; no s_barrier inside the loop (the factor wave would have to take part in it).
+// ------------------------------------------------------------------------------------------------
+#define RR_NW 11
+#define RR_SLOTS 14 /* ceil(17 * 18 / 2 / 11) */
+#define RR_THREADS ((RR_NW + 1) * 64)
+
+__device__ __forceinline__ void lds_wait_ge(int *flag, int target)
 {
-  __shared__ double sPanel[RR_MAXT][TS][TS]; // [tile i][k][r]: solved panel of the current step
-  __shared__ double sDiag[TS][TS + 1];       // [r][c]: diagonal tile on its way to the factor wave
-  __shared__ double sL[TS][TS + 1];          // [r][c]: factored diagonal block L(k,k) for the tile waves
-  __shared__ double sYd[4][TS];              // [k][c] = Ydiag(c, k)
-  __shared__ unsigned short sIJ[RR_SLOTS * RR_TILE_WAVES + 16];
-  __shared__ int sFlag;                      // number of diagonal tiles handed to the factor wave
+  while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+    __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void lds_set(int *flag, int value, int lane)
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_inc(int *cnt, int lane)
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ base, double *__restrict__ ws,
+                                                         const chol_potrf_desc *__restrict__ descs, int *__restrict__ info)
+{
+  // tiles in LDS are stored like accumulator registers: element (r, c) at c * 16 + r, so lane (r15, g)
+  // register q sits at q * 64 + lp with lp = g * 16 + r15 (conflict free, and directly an MFMA operand)
+  __shared__ double sRaw[RR_MAXT][TS * TS]; // raw (fully updated, unsolved) tiles of the next panel column
+  __shared__ double sSol[RR_MAXT][TS * TS]; // solved panel P of the current step
+  __shared__ double sDg[2][TS * TS];        // diagonal tiles on their way to the factor wave (parity of j)
+  __shared__ double sL[2][TS][TS + 1];      // L(k,k), [r][c], parity of k
+  __shared__ double sYd[2][4][TS];          // Ydiag(k), [k][c], parity of k
+  __shared__ double sConv[TS][TS + 1];      // factor wave: accumulator layout -> row per lane
+  __shared__ unsigned short sIJ[RR_SLOTS * RR_NW + 16];
+  __shared__ int sFlag[4];                  // fL, fP, cSol, cUpd
+  int *const fL = &sFlag[0], *const fP = &sFlag[1], *const cSol = &sFlag[2], *const cUpd = &sFlag[3];
+
   const chol_potrf_desc d = descs[blockIdx.x];
   double *A = base + d.a_off;
   double *W = ws + d.dinv_off;
   const int n = d.n, lda = d.lda;
   const int T = (n + TS - 1) / TS;
+  const int ntl = T * (T + 1) / 2;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r15 = lane & 15, g = lane >> 4;
+  const int lp0 = g * TS + r15;
 
-  // (i, j) of every lower-triangle tile, column-major enumeration; slot s of tile wave w holds tile
-  // s * RR_TILE_WAVES + w
-  for (int t = threadIdx.x; t < RR_SLOTS * RR_TILE_WAVES; t += RR_THREADS) {
+  for (int t = threadIdx.x; t < RR_SLOTS * RR_NW; t += RR_THREADS) {
     int ti, tj;
     tile_of_index(t, T, ti, tj);
     sIJ[t] = ti < 0 ? (unsigned short)0xffff : (unsigned short)(ti | (tj << 8));
   }
-  if (threadIdx.x == 0) sFlag = 0;
+  if (threadIdx.x < 4) sFlag[threadIdx.x] = 0;
   __syncthreads();
 
   if (wave == 0) {
-    // ------------------------------------------------------------------ factor wave
-    __builtin_amdgcn_s_setprio(3); // its dependent chain is the critical path of the whole pivot
-    STAMP_DECL;
+    // ================================================================== factor wave
+    __builtin_amdgcn_s_setprio(3);
+    lds_wait_ge(cUpd, RR_NW); // prologue of the tile waves done: (0,0) and (1,1) are in sDg
+    d4 dk; // diagonal tile of the current step, accumulator layout
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dk[q] = sDg[0][q * 64 + lp0];
     for (int k = 0; k < T; ++k) {
-      STAMP(0);
-      // wait for tile (k, k): published by its owner as soon as it has its last update
-      while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&sFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= k) __builtin_amdgcn_s_sleep(1);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      // ---- a. factor (k,k)
       double a[TS], blk[4], x[4], myinv;
 #pragma unroll
-      for (int c = 0; c < TS; ++c) a[c] = sDiag[r15][c];
-      STAMP(1);
+      for (int q = 0; q < 4; ++q) sConv[r15][g + 4 * q] = dk[q];
+#pragma unroll
+      for (int c = 0; c < TS; ++c) a[c] = sConv[r15][c];
       const int bad = chol16_rows(a, myinv, r15);
-      STAMP(2);
       if (bad && k * TS + bad <= n && lane == 0) {
         if (atomicCAS(&info[0], 0, k * TS + bad) == 0) info[1] = d.sep;
       }
       own_block_row(a, r15, blk);
       linv4_quad(blk, myinv, x, r15 & 3);
-      STAMP(3);
-      // sL / sYd are free: the tile waves read them only between B2 and B3 of the previous step
+      const int par = k & 1;
       if (lane < TS) {
         const int b4 = lane & ~3, qi = lane & 3;
 #pragma unroll
-        for (int c = 0; c < TS; ++c) sL[lane][c] = (c <= lane) ? a[c] : 0.0;
+        for (int c = 0; c < TS; ++c) sL[par][lane][c] = (c <= lane) ? a[c] : 0.0;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) sYd[qi][b4 + m] = x[m]; // Ydiag(c = 4b+m, k = qi) = Linv_bb(m, qi)
+        for (int m = 0; m < 4; ++m) sYd[par][qi][b4 + m] = x[m]; // Ydiag(c = 4b+m, k = qi) = Linv_bb(m, qi)
       }
-      STAMP(4);
-      __syncthreads(); // B2: L(k,k) and Ydiag(k) published
-      STAMP(5);
-      __syncthreads(); // B3: panel solved
-      STAMP(6);
+      lds_set(fL, k + 1, lane);
+      if (k + 1 >= T) break;
+      // ---- b. everything the tile waves owed from step k-1 is in LDS
+      lds_wait_ge(cUpd, RR_NW * (k + 1));
+      // ---- c. solve (k+1, k) and publish it
+      double Lr[3];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) Lr[b] = sL[par][r15][g + 4 * b];
+      const double yd = sYd[par][g][r15];
+      d4 raw, dn;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { raw[q] = sRaw[k + 1][q * 64 + lp0]; dn[q] = sDg[(k + 1) & 1][q * 64 + lp0]; }
+      const d4 p = tile_solve(raw, Lr, yd);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sSol[k + 1][q * 64 + lp0] = p[q];
+      lds_set(fP, k + 1, lane);
+      // ---- d. (k+1,k+1) -= P P^T: both operands are the accumulator registers of P
+#pragma unroll
+      for (int st = 0; st < 4; ++st) dn = __builtin_amdgcn_mfma_f64_16x16x4f64(p[st], -p[st], dn, 0, 0, 0);
+      dk = dn;
+      { // L(k+1, k) to global memory (fire and forget)
+        const int row = (k + 1) * TS + r15;
+        double *dst = A + row + (int64_t)(k * TS + g) * lda;
+        if (row < n) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dst[(int64_t)(4 * q) * lda] = p[q];
+        }
+      }
     }
-    STAMP_FLUSH;
   } else {
-    // ------------------------------------------------------------------ tile waves
+    // ================================================================== tile waves
     d4 tile[RR_SLOTS];
     const int w = wave - 1;
     int ijp[RR_SLOTS]; // packed (i | j << 8) per slot, wave uniform
 #pragma unroll
-    for (int s = 0; s < RR_SLOTS; ++s) ijp[s] = __builtin_amdgcn_readfirstlane((int)sIJ[s * RR_TILE_WAVES + w]);
-#define SLOT_IJ(s, ti_, tj_) \
-    const int ti_ = (ijp[s] == 0xffff) ? -1 : (ijp[s] & 0xff), tj_ = (ijp[s] == 0xffff) ? (1 << 20) : (ijp[s] >> 8)
-#define PUBLISH_DIAG(v, kk)                                                     \
-    do {                                                                        \
-      _Pragma("unroll") for (int q = 0; q < 4; ++q) sDiag[r15][g + 4 * q] = (v)[q]; \
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                    \
-      if (lane == 0) __hip_atomic_store(&sFlag, (kk) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-    } while (0)
+    for (int s = 0; s < RR_SLOTS; ++s) ijp[s] = __builtin_amdgcn_readfirstlane((int)sIJ[s * RR_NW + w]);
+    // ---- prologue: load the owned tiles; park column 0 and the first two diagonal tiles
 #pragma unroll
     for (int s = 0; s < RR_SLOTS; ++s) {
-      SLOT_IJ(s, ti, tj);
       d4 v = { 0.0, 0.0, 0.0, 0.0 };
-      if (ti >= 0) {
+      if (ijp[s] != 0xffff) {
+        const int ti = ijp[s] & 0xff, tj = ijp[s] >> 8;
         const int row = ti * TS + r15;
         const bool rowok = row < n;
         const double *src = A + row + (int64_t)(tj * TS + g) * lda;
@@ -335,29 +400,33 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
           if (rowok && col < n) e = (ti > tj || c <= r15) ? src[(int64_t)(4 * q) * lda] : 0.0;
           v[q] = e;
         }
-        if (ti == 0 && tj == 0) PUBLISH_DIAG(v, 0);
+        double *park = nullptr;
+        if (ti == tj && ti < 2) park = &sDg[ti][0];
+        else if (tj == 0) park = &sRaw[ti][0];
+        if (park) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) park[q * 64 + lp0] = v[q];
+        }
       }
       tile[s] = v;
       __builtin_amdgcn_sched_barrier(0);
     }
-    double *const sP = &sPanel[0][0][0];
-    STAMP_DECL;
+    lds_inc(cUpd, lane);
     for (int k = 0; k < T; ++k) {
-      STAMP(0);
-      // lane part of every LDS panel address, made opaque once per step so that the 2 x 14 per-slot
-      // addresses are formed where they are used instead of being hoisted (and spilled) as invariants
-      int lp = g * TS + r15;
+      int lp = lp0; // opaque once per step: keeps per-slot LDS addresses from being hoisted and spilled
       asm volatile("" : "+v"(lp));
-      __syncthreads(); // B2: L(k,k), Ydiag(k) available; every tile wave has finished step k-1
-      STAMP(1);
-      // ---- panel solve: X = T L(k,k)^-T for owned tiles (i, k), i > k
+      const int par = k & 1;
+      const int st1 = (k + 1) * T - ((k + 1) * k) / 2; // index of tile (k+1, k+1)
+      // ---- 1. panel solve out of LDS (needs L(k,k) and every raw tile of column k)
+      lds_wait_ge(fL, k + 1);
+      lds_wait_ge(cUpd, RR_NW * (k + 1));
       {
         double Lr[3];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) Lr[b] = sL[r15][g + 4 * b];
-        const double yd = sYd[g][r15];
-        if (w == (k % RR_TILE_WAVES)) { // one tile wave per step writes L(k,k) and Ydiag(k) back (off the critical path)
-          const double l3 = sL[r15][g + 12];
+        for (int b = 0; b < 3; ++b) Lr[b] = sL[par][r15][g + 4 * b];
+        const double yd = sYd[par][g][r15];
+        if (w == (k % RR_NW)) { // one tile wave per step writes L(k,k) and Ydiag(k) back
+          const double l3 = sL[par][r15][g + 12];
           const int row = k * TS + r15;
           double *dst = A + row + (int64_t)(k * TS + g) * lda;
           if (row < n) {
@@ -368,57 +437,52 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
           }
           W[(int64_t)k * TS * TS + g * TS + r15] = yd;
         }
+        for (int i = k + 2 + ((w + RR_NW - ((k + 2) % RR_NW)) % RR_NW); i < T; i += RR_NW) { // i = w (mod 11)
+          d4 raw;
 #pragma unroll
-        for (int s = 0; s < RR_SLOTS; ++s) {
-          SLOT_IJ(s, ti, tj);
-          if (tj == k && ti > k) {
-            const d4 x = tile_solve(tile[s], Lr, yd);
-            tile[s] = x; // final values of L(i, k): stay in registers until the epilogue stores them
+          for (int q = 0; q < 4; ++q) raw[q] = sRaw[i][q * 64 + lp];
+          const d4 x = tile_solve(raw, Lr, yd);
+          const int row = i * TS + r15;
+          double *dst = A + row + (int64_t)(k * TS + g) * lda;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) sP[ti * (TS * TS) + q * (4 * TS) + lp] = x[q];
+          for (int q = 0; q < 4; ++q) {
+            sSol[i][q * 64 + lp] = x[q];
+            if (row < n) dst[(int64_t)(4 * q) * lda] = x[q];
           }
-          __builtin_amdgcn_sched_barrier(0);
         }
       }
-      STAMP(2);
-      __syncthreads(); // B3: panel published
-      STAMP(3);
-      // ---- trailing update T(i, j) -= P_i P_j^T, j > k; the next diagonal tile first (look-ahead)
+      // ---- 2. the whole panel is solved
+      lds_inc(cSol, lane);
+      lds_wait_ge(cSol, RR_NW * (k + 1));
+      if (k + 1 < T) lds_wait_ge(fP, k + 1);
+      // ---- 3. trailing update, slots from the top down, early exit at the first tile of column <= k
+      const double *const sS = &sSol[0][0];
 #pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-        for (int s = 0; s < RR_SLOTS; ++s) {
-          SLOT_IJ(s, ti, tj);
-          const bool next_diag = (tj == k + 1 && ti == k + 1);
-          if (tj > k && tj < T && (pass == 0 ? next_diag : !next_diag)) {
+      for (int s = RR_SLOTS - 1; s >= 0; --s) {
+        const int idx = s * RR_NW + w;
+        if (idx < st1) break;
+        if (idx < ntl) {
+          const int ti = ijp[s] & 0xff, tj = ijp[s] >> 8;
+          if (!(ti == tj && tj == k + 1)) { // (k+1,k+1) went to the factor wave one step ago
             d4 acc = tile[s];
 #pragma unroll
             for (int st = 0; st < 4; ++st)
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sP[tj * (TS * TS) + st * (4 * TS) + lp], -sP[ti * (TS * TS) + st * (4 * TS) + lp], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sS[tj * (TS * TS) + st * 64 + lp], -sS[ti * (TS * TS) + st * 64 + lp], acc, 0, 0, 0);
             tile[s] = acc;
-            if (next_diag) PUBLISH_DIAG(acc, k + 1);
+            double *park = nullptr;
+            if (tj == k + 1) park = &sRaw[ti][0];                        // last update: next panel column
+            else if (ti == tj && tj == k + 2) park = &sDg[tj & 1][0];    // diagonal tile, one step ahead
+            if (park) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) park[q * 64 + lp] = acc[q];
+            }
           }
-          __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      STAMP(4);
+      // ---- 4.
+      lds_inc(cUpd, lane);
     }
-    STAMP_FLUSH2;
-    // epilogue: every off-diagonal tile now holds its block of L
-#pragma unroll
-    for (int s = 0; s < RR_SLOTS; ++s) {
-      SLOT_IJ(s, ti, tj);
-      if (ti > tj && ti >= 0) {
-        const int row = ti * TS + r15;
-        double *dst = A + row + (int64_t)(tj * TS + g) * lda;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (row < n) dst[(int64_t)(4 * q) * lda] = tile[s][q];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#undef SLOT_IJ
-#undef PUBLISH_DIAG
   }
 }
 
