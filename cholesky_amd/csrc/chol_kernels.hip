@@ -32,6 +32,14 @@ __device__ __forceinline__ d4 rank_k_16x16(d4 acc, const double *__restrict__ X,
   const double *px = X + r + (int64_t)kq * ldx;
   const double *py = Y + r + (int64_t)kq * ldy;
   int k0 = 0;
+  for (; k0 + 32 <= K; k0 += 32) { // eight MFMAs per trip, sixteen loads in flight
+    double x[8], y[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { x[u] = vx ? px[(int64_t)(4 * u) * ldx] : 0.0; y[u] = vy ? py[(int64_t)(4 * u) * ldy] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y[u], x[u], acc, 0, 0, 0);
+    px += 32 * (int64_t)ldx; py += 32 * (int64_t)ldy;
+  }
   for (; k0 + 16 <= K; k0 += 16) { // four MFMAs per trip, eight loads in flight
     double x0 = vx ? px[0] : 0.0, y0 = vy ? py[0] : 0.0;
     double x1 = vx ? px[4 * (int64_t)ldx] : 0.0, y1 = vy ? py[4 * (int64_t)ldy] : 0.0;
@@ -63,28 +71,49 @@ __global__ void k_scatter(double *__restrict__ arena, const int64_t *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// UPDATE: one wavefront per 16x16 output sub-tile of a target C tile; loops over the tile's sources
-// in the reference's program order.  C <- C - sum_s A_s B_s^T   (cblas_dgemm NoTrans/Trans alpha=-1
-// beta=1, blas.rg:139; cblas_dsyrk Lower alpha=-1 beta=1, blas.rg:187 for `lower` diagonal tiles)
+// UPDATE: one workgroup (4 waves) per 16x16 output sub-tile of a target C tile.  The tile's sources
+// are walked in the reference's program order; the four waves split every source's K range (the
+// tasks are latency bound: K / 4 dependent MFMAs each fed by two L2 loads, so 4x the loads in flight
+// is 4x less time), partial sums meet in LDS and are added in a fixed order (deterministic).
+//   C <- C - sum_s A_s B_s^T   (cblas_dgemm NoTrans/Trans alpha=-1 beta=1, blas.rg:139;
+//                               cblas_dsyrk Lower alpha=-1 beta=1, blas.rg:187 for `lower` tiles)
+// Task ids are remapped so that consecutive tasks (sub-tiles of one target, sharing their source
+// panels) run on the same XCD and hit in its L2.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_update(double *__restrict__ base, const chol_upd_task *__restrict__ tasks,
-                                                const chol_upd_src *__restrict__ srcs, int ntask)
+                                                const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd)
 {
+  __shared__ double sAcc[3][4][64];
   const int lane = threadIdx.x & 63;
-  const int tid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-  if (tid >= ntask) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per_xcd || tid >= ntask) return;
   const chol_upd_task t = tasks[tid];
   d4 acc = { 0.0, 0.0, 0.0, 0.0 };
   for (int s = t.src_begin; s < t.src_end; ++s) {
     const chol_upd_src sd = srcs[s];
-    acc = rank_k_16x16(acc, base + sd.a_off + t.ar, sd.lda, t.mv, base + sd.b_off + t.br, sd.ldb, t.nv, sd.k, lane);
+    const int kc = ((((sd.k + 3) >> 2) + 3) >> 2) << 2; // K per wave, a multiple of 4
+    const int k_lo = wave * kc;
+    if (k_lo < sd.k) {
+      const int kn = min(kc, sd.k - k_lo);
+      acc = rank_k_16x16(acc, base + sd.a_off + t.ar + (int64_t)k_lo * sd.lda, sd.lda, t.mv,
+                         base + sd.b_off + t.br + (int64_t)k_lo * sd.ldb, sd.ldb, t.nv, kn, lane);
+    }
   }
-  const int r = lane & 15;
-  double *C = base + t.c_off + r;
+  if (wave > 0) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int c = (lane >> 4) + 4 * q;
-    if (r < t.mv && c < t.nv && (!t.lower || r >= c)) C[(int64_t)c * t.ldc] -= acc[q];
+    for (int q = 0; q < 4; ++q) sAcc[wave - 1][q][lane] = acc[q];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int r = lane & 15;
+    double *C = base + t.c_off + r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = (lane >> 4) + 4 * q;
+      const double v = ((acc[q] + sAcc[0][q][lane]) + sAcc[1][q][lane]) + sAcc[2][q][lane];
+      if (r < t.mv && c < t.nv && (!t.lower || r >= c)) C[(int64_t)c * t.ldc] -= v;
+    }
   }
 }
 
@@ -216,6 +245,27 @@ __device__ __forceinline__ d4 tile_solve(d4 t, const double (&Lr)[3], double yd)
   return x;
 }
 
+// Linv(k,k) for the TRSM kernels, off every critical path: X = I L^-T = Linv^T by one tile_solve, stored
+// as Wb[k * 16 + c] = Linv(c, k) -- the layout solve16() reads as its MFMA Y operand.
+__device__ __forceinline__ void store_linv16(double *Wb, const double (&Lr)[3], double yd, int r15, int g)
+{
+  d4 id;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) id[q] = (r15 == g + 4 * q) ? 1.0 : 0.0;
+  const d4 xi = tile_solve(id, Lr, yd); // xi(r, c) = Linv(c, r)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) Wb[r15 * TS + g + 4 * q] = xi[q];
+}
+// X = T Linv^T with the explicit inverse: four accumulator-dependent MFMAs (256 cycles) instead of the
+// seven operand-dependent ones of tile_solve (~700); w[st] = Wb[(4 st + g) * 16 + r15]
+__device__ __forceinline__ d4 solve16(d4 t, const double (&w)[4])
+{
+  d4 x = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+  for (int st = 0; st < 4; ++st) x = __builtin_amdgcn_mfma_f64_16x16x4f64(w[st], t[st], x, 0, 0, 0);
+  return x;
+}
+
 // the lane's own 4x4 diagonal-block row out of its 16-entry row: blk[k] = a[4 (r15 / 4) + k]
 __device__ __forceinline__ void own_block_row(const double (&a)[TS], int r15, double (&blk)[4])
 {
@@ -265,25 +315,39 @@ __device__ __forceinline__ void tile_of_index(int idx, int T, int &ti, int &tj)
 // All hand-offs are LDS words written after a workgroup-scope release fence and polled relaxed,
 // then acquired; no s_barrier inside the loop (the factor wave would have to take part in it).
 // ------------------------------------------------------------------------------------------------
-#define RR_NW 11
-#define RR_SLOTS 14 /* ceil(17 * 18 / 2 / 11) */
+#define RR_NW 11     /* tile waves */
+#define RR_SLOTS 14  /* ceil(17 * 18 / 2 / 11) */
 #define RR_THREADS ((RR_NW + 1) * 64)
+// Note (measured): waves of a workgroup are dealt to the four SIMDs round-robin, so waves 0, 4 and 8
+// share a SIMD, and fp64 MFMA runs on the same DP units as fp64 VALU: the tile waves' 64-cycle MFMAs
+// on the factor wave's SIMD stretch its scalar chain (chol16 3.4k -> 4.9k cycles).  Leaving waves 4 and
+// 8 without tiles fixes that (3.7k) but 9 tile waves need 17 register slots for n > 256 and the trailing
+// update becomes the bottleneck on 3 SIMDs; 11 tile waves are faster end to end (79 vs 88 us at n = 259).
 
+// LDS-only synchronisation.  Everything the waves of these kernels hand to each other goes through
+// LDS, so the hand-offs must NOT use __syncthreads() / workgroup-scope fences: those also drain the
+// vector-memory counter, i.e. every step would wait for the global stores of finished tiles and for
+// the prefetch loads to land (measured: ~2k of the 3.2k cycles of a TRSM step).
 __device__ __forceinline__ void lds_wait_ge(int *flag, int target)
 {
   while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
     __builtin_amdgcn_s_sleep(1);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  asm volatile("" ::: "memory"); // later LDS reads stay behind the poll (LDS executes a wave's accesses in order)
 }
 __device__ __forceinline__ void lds_set(int *flag, int value, int lane)
 {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's LDS writes have landed
   if (lane == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void lds_inc(int *cnt, int lane)
 {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// workgroup barrier that orders LDS traffic only (global loads / stores stay in flight across it)
+__device__ __forceinline__ void lds_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ base, double *__restrict__ ws,
@@ -327,14 +391,18 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
     d4 dk; // diagonal tile of the current step, accumulator layout
 #pragma unroll
     for (int q = 0; q < 4; ++q) dk[q] = sDg[0][q * 64 + lp0];
+    STAMP_DECL;
     for (int k = 0; k < T; ++k) {
+      STAMP(0);
       // ---- a. factor (k,k)
       double a[TS], blk[4], x[4], myinv;
 #pragma unroll
       for (int q = 0; q < 4; ++q) sConv[r15][g + 4 * q] = dk[q];
 #pragma unroll
       for (int c = 0; c < TS; ++c) a[c] = sConv[r15][c];
+      STAMP(1);
       const int bad = chol16_rows(a, myinv, r15);
+      STAMP(2);
       if (bad && k * TS + bad <= n && lane == 0) {
         if (atomicCAS(&info[0], 0, k * TS + bad) == 0) info[1] = d.sep;
       }
@@ -349,9 +417,11 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
         for (int m = 0; m < 4; ++m) sYd[par][qi][b4 + m] = x[m]; // Ydiag(c = 4b+m, k = qi) = Linv_bb(m, qi)
       }
       lds_set(fL, k + 1, lane);
+      STAMP(3);
       if (k + 1 >= T) break;
       // ---- b. everything the tile waves owed from step k-1 is in LDS
       lds_wait_ge(cUpd, RR_NW * (k + 1));
+      STAMP(4);
       // ---- c. solve (k+1, k) and publish it
       double Lr[3];
 #pragma unroll
@@ -364,6 +434,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
 #pragma unroll
       for (int q = 0; q < 4; ++q) sSol[k + 1][q * 64 + lp0] = p[q];
       lds_set(fP, k + 1, lane);
+      STAMP(5);
       // ---- d. (k+1,k+1) -= P P^T: both operands are the accumulator registers of P
 #pragma unroll
       for (int st = 0; st < 4; ++st) dn = __builtin_amdgcn_mfma_f64_16x16x4f64(p[st], -p[st], dn, 0, 0, 0);
@@ -376,7 +447,9 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
           for (int q = 0; q < 4; ++q) dst[(int64_t)(4 * q) * lda] = p[q];
         }
       }
+      STAMP(6);
     }
+    STAMP_FLUSH;
   } else {
     // ================================================================== tile waves
     d4 tile[RR_SLOTS];
@@ -425,7 +498,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
 #pragma unroll
         for (int b = 0; b < 3; ++b) Lr[b] = sL[par][r15][g + 4 * b];
         const double yd = sYd[par][g][r15];
-        if (w == (k % RR_NW)) { // one tile wave per step writes L(k,k) and Ydiag(k) back
+        if (w == (k % RR_NW)) { // one tile wave per step writes L(k,k) and Linv(k,k) back
           const double l3 = sL[par][r15][g + 12];
           const int row = k * TS + r15;
           double *dst = A + row + (int64_t)(k * TS + g) * lda;
@@ -435,7 +508,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
               if (g + 4 * b <= r15) dst[(int64_t)(4 * b) * lda] = Lr[b];
             if (g + 12 <= r15) dst[(int64_t)12 * lda] = l3;
           }
-          W[(int64_t)k * TS * TS + g * TS + r15] = yd;
+          store_linv16(W + (int64_t)k * TS * TS, Lr, yd, r15, g);
         }
         for (int i = k + 2 + ((w + RR_NW - ((k + 2) % RR_NW)) % RR_NW); i < T; i += RR_NW) { // i = w (mod 11)
           d4 raw;
@@ -527,10 +600,7 @@ __global__ __launch_bounds__(256) void k_potrf_big(double *__restrict__ base, do
           if (row < n && c <= lane) A[row + (int64_t)(j0 + c) * lda] = a[c];
         }
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          sYd[qi][b4 + m] = x[m];
-          W[(int64_t)k * TS * TS + qi * TS + b4 + m] = x[m];
-        }
+        for (int m = 0; m < 4; ++m) sYd[qi][b4 + m] = x[m];
       }
     }
     __syncthreads();
@@ -541,6 +611,7 @@ __global__ __launch_bounds__(256) void k_potrf_big(double *__restrict__ base, do
 #pragma unroll
       for (int b = 0; b < 3; ++b) Lr[b] = sL[r15][g + 4 * b];
       const double yd = sYd[g][r15];
+      if (wave == 3) store_linv16(W + (int64_t)k * TS * TS, Lr, yd, r15, g);
       for (int t = wave; t < nt; t += 4) {
         const int row = j0 + TS + t * TS + r15;
         d4 tv;
@@ -584,7 +655,8 @@ __global__ __launch_bounds__(256) void k_potrf_big(double *__restrict__ base, do
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_dinv(const double *__restrict__ Lp, int n, int ldl, double *__restrict__ W)
 {
-  const int j0 = blockIdx.x * TS, lane = threadIdx.x, r15 = lane & 15;
+  __shared__ double sYd[4][TS];
+  const int j0 = blockIdx.x * TS, lane = threadIdx.x, r15 = lane & 15, g = lane >> 4;
   const int row = j0 + r15, b4 = r15 & ~3, qi = r15 & 3;
   double blk[4], x[4];
 #pragma unroll
@@ -601,8 +673,18 @@ __global__ __launch_bounds__(64) void k_dinv(const double *__restrict__ Lp, int 
   linv4_quad(blk, 1.0 / diag, x, qi);
   if (lane < TS) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) W[(int64_t)blockIdx.x * TS * TS + qi * TS + b4 + m] = x[m];
+    for (int m = 0; m < 4; ++m) sYd[qi][b4 + m] = x[m];
   }
+  __syncthreads();
+  double Lr[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const int c = g + 4 * b;
+    double v = (r15 == c) ? 1.0 : 0.0;
+    if (row < n && j0 + c < n) v = (c <= r15) ? Lp[row + (int64_t)(j0 + c) * ldl] : 0.0;
+    Lr[b] = v;
+  }
+  store_linv16(W + (int64_t)blockIdx.x * TS * TS, Lr, sYd[g][r15], r15, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -617,7 +699,7 @@ __global__ __launch_bounds__(64) void k_dinv(const double *__restrict__ Lp, int 
 __global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base, const double *__restrict__ ws,
                                                  const chol_trsm_desc *__restrict__ descs)
 {
-  __shared__ double sX[2][TS][TS]; // [buf][k][r]
+  __shared__ double sX[3][TS * TS]; // [J mod 3][c * 16 + r]: solved column tiles, accumulator-register order
   const chol_trsm_desc d = descs[blockIdx.x];
   const double *Lm = base + d.l_off;
   const double *W = ws + d.dinv_off;
@@ -627,9 +709,12 @@ __global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base, cons
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r15 = lane & 15, g = lane >> 4;
+  const int lp = g * TS + r15;
   const bool vrow = r15 < m;
 
   d4 tile[TRSM_SLOTS];
+  int64_t voff[TRSM_SLOTS]; // lane part of the address of L(J2 * 16 + r15, g): rows past n are clamped (their
+                            // products only reach output columns >= n, which are never stored)
 #pragma unroll
   for (int s = 0; s < TRSM_SLOTS; ++s) {
     const int J = wave + 4 * s;
@@ -642,77 +727,102 @@ __global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base, cons
       }
     }
     tile[s] = v;
+    voff[s] = min(J * TS + r15, n - 1) + (int64_t)g * ldl;
   }
-  // diagonal-block operands of the solve of column tile J (Lr = L(J,J) in tile layout, yd = Ydiag(J))
-#define LOAD_DIAG_OPERANDS(J_, Lr_, yd_)                                                                \
-  {                                                                                                     \
-    const int lrow_ = (J_) * TS + r15;                                                                  \
-    _Pragma("unroll") for (int b = 0; b < 3; ++b) {                                                     \
-      const int col_ = (J_) * TS + g + 4 * b;                                                           \
-      Lr_[b] = (lrow_ < n && col_ < n && g + 4 * b <= r15) ? Lm[lrow_ + (int64_t)col_ * ldl] : 0.0;     \
+  // L tiles (J2, J) of the updates of step J (uniform branch per slot, one scalar base per step)
+#define LOAD_L(J_, buf_)                                                                                \
+  if ((J_) < T) {                                                                                       \
+    const double *lb_ = Lm + (int64_t)((J_) * TS) * ldl;                                                \
+    _Pragma("unroll") for (int s = 0; s < TRSM_SLOTS; ++s) {                                            \
+      const int J2_ = wave + 4 * s;                                                                     \
+      if (J2_ > (J_) && J2_ < T) {                                                                      \
+        _Pragma("unroll") for (int st = 0; st < 4; ++st) buf_[s][st] = lb_[voff[s] + (int64_t)(4 * st) * ldl]; \
+      }                                                                                                 \
     }                                                                                                   \
-    yd_ = W[(int64_t)(J_) * TS * TS + g * TS + r15];                                                    \
+  }
+#define LOAD_W(J_, buf_)                                                                                \
+  {                                                                                                     \
+    _Pragma("unroll") for (int st = 0; st < 4; ++st) buf_[st] = W[(int64_t)(J_) * TS * TS + (4 * st + g) * TS + r15]; \
   }
 #define PUBLISH_X(J_, x_)                                                                               \
   {                                                                                                     \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                     \
-      const int c_ = g + 4 * q, col_ = (J_) * TS + c_;                                                  \
-      sX[(J_) & 1][c_][r15] = x_[q];                                                                    \
+      const int col_ = (J_) * TS + g + 4 * q;                                                           \
+      sX[(J_) % 3][q * 64 + lp] = x_[q];                                                                \
       if (vrow && col_ < n) B[r15 + (int64_t)col_ * ldb] = x_[q];                                       \
     }                                                                                                   \
   }
+#define APPLY_X(JX_, s_)                                                                                \
+  {                                                                                                     \
+    d4 acc_ = tile[s_];                                                                                 \
+    _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                    \
+      acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(lpre[(JX_) % 3][s_][st], -sX[(JX_) % 3][st * 64 + lp], acc_, 0, 0, 0); \
+    tile[s_] = acc_;                                                                                    \
+  }
+  // operands are fetched two steps ahead; vmcnt retires in order, so the inverse the next solve waits
+  // for is issued before the L tiles of the same step
+  double lpre[3][TRSM_SLOTS][4], wpre[3][4];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      wpre[u][st] = 0.0;
+#pragma unroll
+      for (int s = 0; s < TRSM_SLOTS; ++s) lpre[u][s][st] = 0.0;
+    }
+  }
+  if (wave == 0) LOAD_W(0, wpre[0]);
+  if (wave == 1 && 1 < T) LOAD_W(1, wpre[1]);
+  LOAD_L(0, lpre[0]);
+  LOAD_L(1, lpre[1]);
   if (wave == 0) { // column tile 0 has no predecessors
-    double Lr[3], yd;
-    LOAD_DIAG_OPERANDS(0, Lr, yd);
-    const d4 x = tile_solve(tile[0], Lr, yd);
+    const d4 x = solve16(tile[0], wpre[0]);
     PUBLISH_X(0, x);
   }
+  STAMP_DECL;
 #pragma unroll
   for (int J = 0; J < RR_MAXT; ++J) {
     if (J < T) {
-      // L tiles of this step's updates and the diagonal operands of the next solve: issued ahead of
-      // the barrier that hides their latency
-      double lpre[TRSM_SLOTS][4];
-#pragma unroll
-      for (int s = 0; s < TRSM_SLOTS; ++s) {
-        const int J2 = wave + 4 * s;
-        const int lrow = J2 * TS + r15;
-        const bool ok = J2 > J && lrow < n;
-        const double *lp = Lm + (ok ? lrow : 0) + (int64_t)(J * TS + g) * ldl;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) lpre[s][st] = ok ? lp[(int64_t)(4 * st) * ldl] : 0.0;
-      }
+      STAMP(0);
       const bool next_owner = (J + 1 < T) && (((J + 1) & 3) == wave);
-      double LrN[3] = { 0.0, 0.0, 0.0 }, ydN = 0.0;
-      if (next_owner) LOAD_DIAG_OPERANDS(J + 1, LrN, ydN);
-      __syncthreads(); // X_J visible
-      if (next_owner) { // look-ahead: bring tile J+1 up to date, solve it and publish it first
+      lds_barrier(); // X_J visible
+      STAMP(1);
+      if (next_owner) {
+        // critical chain: bring tile J+1 up to date, solve it, publish it -- nothing else before the
+        // next barrier; this wave's other updates with X_J are deferred to the next step
         const int s1 = (J + 1) >> 2;
         if (s1 < TRSM_SLOTS) {
-          d4 acc = tile[s1];
-#pragma unroll
-          for (int st = 0; st < 4; ++st)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lpre[s1][st], -sX[J & 1][4 * st + g][r15], acc, 0, 0, 0);
-          const d4 x = tile_solve(acc, LrN, ydN);
+          APPLY_X(J, s1);
+          const d4 x = solve16(tile[s1], wpre[(J + 1) % 3]);
           tile[s1] = x;
           PUBLISH_X(J + 1, x);
         }
-      }
+      } else {
+        if (J >= 1 && (J & 3) == wave) { // owner of the previous look-ahead: catch up with X_{J-1}
 #pragma unroll
-      for (int s = 0; s < TRSM_SLOTS; ++s) {
-        const int J2 = wave + 4 * s;
-        if (J2 > J + 1 && J2 < T) {
-          d4 acc = tile[s];
+          for (int s = 0; s < TRSM_SLOTS; ++s) {
+            const int J2 = wave + 4 * s;
+            if (J2 > J && J2 < T) APPLY_X(J - 1, s);
+          }
+        }
 #pragma unroll
-          for (int st = 0; st < 4; ++st)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lpre[s][st], -sX[J & 1][4 * st + g][r15], acc, 0, 0, 0);
-          tile[s] = acc;
+        for (int s = 0; s < TRSM_SLOTS; ++s) {
+          const int J2 = wave + 4 * s;
+          if (J2 > J + 1 && J2 < T) APPLY_X(J, s);
         }
       }
+      STAMP(2);
+      // prefetch for step J+2: buffer (J+2) % 3 == (J-1) % 3 is free (deferred work uses X_J / lpre[J % 3])
+      if ((J + 2 < T) && (((J + 2) & 3) == wave)) LOAD_W(J + 2, wpre[(J + 2) % 3]);
+      LOAD_L(J + 2, lpre[(J + 2) % 3]);
+      STAMP(3);
     }
   }
-#undef LOAD_DIAG_OPERANDS
+  if (wave == 1 && blockIdx.x == 0) { STAMP_FLUSH; }
+#undef LOAD_L
+#undef LOAD_W
 #undef PUBLISH_X
+#undef APPLY_X
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -741,14 +851,10 @@ __global__ __launch_bounds__(256) void k_trsm_big(double *__restrict__ base, con
       const int c = g + 4 * q;
       t[q] = (r15 < m && c < nv) ? B[r15 + (int64_t)(j0 + c) * ldb] - acc[q] : 0.0;
     }
-    double Lr[3];
+    double wv[4];
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      const int c = g + 4 * b;
-      Lr[b] = (j0 + r15 < n && j0 + c < n && c <= r15) ? Lm[(j0 + r15) + (int64_t)(j0 + c) * ldl] : 0.0;
-    }
-    const double yd = W[(int64_t)J * TS * TS + g * TS + r15];
-    const d4 x = tile_solve(t, Lr, yd);
+    for (int st = 0; st < 4; ++st) wv[st] = W[(int64_t)J * TS * TS + (4 * st + g) * TS + r15];
+    const d4 x = solve16(t, wv);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int c = g + 4 * q;
@@ -933,7 +1039,8 @@ int chol_launch_trsm_big(double *base, const double *ws, const chol_trsm_desc *d
 int chol_launch_update(double *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st)
 {
   if (ntask <= 0) return 0;
-  hipLaunchKernelGGL(k_update, dim3((ntask + 3) / 4), dim3(256), 0, st, base, tasks, srcs, ntask);
+  const int per_xcd = (ntask + 7) / 8;
+  hipLaunchKernelGGL(k_update, dim3(per_xcd * 8), dim3(256), 0, st, base, tasks, srcs, ntask, per_xcd);
   return (int)hipGetLastError();
 }
 int chol_launch_permute(const double *in, const int *perm, double *out, int n, int inverse, hipStream_t st)

@@ -21,14 +21,11 @@ int main(int argc, char **argv)
   }
   unsigned long long st[16];
   hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof st);
-  const char *names[8] = { "", "wait diag tile", "chol16", "linv4", "publish L,Yd", "B2 wait", "stores+B3 (solve)", "-" };
+  const char *names[8] = { "", "convert to rows", "chol16", "linv4+publish L", "wait cUpd (tile waves)", "solve (k+1,k)+publish", "update (k+1,k+1)+store", "-" };
   int T = (n + 15) / 16;
   unsigned long long tot = 0;
   for (int i = 1; i < 8; i++) tot += st[i];
   printf("n=%d steps=%d total %.1f cycles/step (s_memtime ticks @100MHz? see ratio)\n", n, T, (double)tot / T);
   for (int i = 1; i < 8; i++) printf("  %-18s %10.1f ticks/step  %5.1f%%\n", names[i], (double)st[i] / T, 100.0 * st[i] / tot);
-  const char *n2[8] = { "", "B2 wait", "solve", "B3 wait", "update (both passes)", "", "", "" };
-  printf("tile wave 3:\n");
-  for (int i = 1; i < 5; i++) printf("  %-22s %10.1f ticks/step\n", n2[i], (double)st[8 + i] / T);
   return 0;
 }
