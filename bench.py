@@ -72,6 +72,7 @@ def main():
     import torch.distributed as dist
 
     import cholesky_amd as ca
+    from cholesky_amd import parallel
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -90,13 +91,10 @@ def main():
     files = [os.path.join(g, f) for f in CASES[args.case]]
     plan = ca.Plan(*files)
     dev = ca.Device(plan, local_rank)
-    split = 0
-    tail_off = plan.arena_doubles
+    split = parallel.split_level(world)
+    tail_off = parallel.tail_offset(plan, world)  # first panel of the shared top of the tree
     if world > 1:
         dev.set_partition(rank, world)
-        split = world.bit_length() - 1
-        diag = {int(b[1]): int(b[7]) for b in plan.blocks if b[0] == b[1]}
-        tail_off = diag[plan.nsep - (world - 1) + 1]  # first panel of the shared top of the tree
 
     K, W = args.steps, args.warmup
     stream = torch.cuda.current_stream()
@@ -110,12 +108,9 @@ def main():
         dev.sync(stream)
 
     def step(a):
-        if world == 1:
-            dev.factor(a, stream)
-        else:
-            dev.factor_levels(a, plan.levels - 1, split, stream)
-            dist.all_reduce(a[tail_off:])          # extend-add contributions to the shared ancestors
-            dev.factor_levels(a, split - 1, 0, stream)
+        # world > 1: local subtree levels, ONE RCCL all-reduce of the arena tail (extend-add
+        # contributions to the shared ancestors), then the top levels
+        parallel.factor_sharded(dev, a, world, tail_off, stream)
 
     def fence():
         torch.cuda.synchronize()

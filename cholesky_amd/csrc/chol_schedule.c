@@ -253,3 +253,28 @@ void chol_solve_level_free(chol_solve_level *w)
   free(w->trsv); free(w->fw); free(w->grp_start); free(w->grp_rows); free(w->bw); free(w->bw_start);
   memset(w, 0, sizeof *w);
 }
+
+/* ---------------------------------------------------------------------------------------- */
+/* host-side views of the multi-GPU partition (testable without a device)                     */
+/* ---------------------------------------------------------------------------------------- */
+int cholamd_plan_fill_host_part(const cholamd_plan *p, double *arena, int rank, int world, int64_t *tail_offset_out)
+{
+  const int d = chol_split_level(world);
+  if (world < 1 || (1 << d) != world || d > p->levels - 1 || rank < 0 || rank >= world) { chol_set_error("bad partition rank %d of %d", rank, world); return CHOLAMD_ERR_ARG; }
+  const int64_t tail = world > 1 ? p->panel_off[p->nsep - (world - 1) + 1] : p->arena;
+  if (tail_offset_out) *tail_offset_out = tail;
+  memset(arena, 0, (size_t)p->arena * sizeof(double));
+  for (int64_t e = 0; e < p->nnz_a; e++)
+    if (rank == 0 || p->a_dst[e] < tail) arena[p->a_dst[e]] = p->a_val[e];
+  return 0;
+}
+
+int cholamd_plan_level_work_counts(const cholamd_plan *p, int level, int rank, int world, int out[4])
+{
+  chol_level_work w;
+  int rc = chol_build_level_work(p, level, rank, world, &w);
+  if (rc) return rc;
+  out[0] = w.n_potrf; out[1] = w.n_trsm; out[2] = w.n_task; out[3] = w.n_src;
+  chol_level_work_free(&w);
+  return 0;
+}

@@ -119,6 +119,19 @@ class Plan:
         check(self.L.cholamd_plan_fill_host(self.h, a.ctypes.data), "cholamd_plan_fill_host")
         return a
 
+    def fill_host_part(self, rank, world):
+        """Host arena as rank `rank` of `world` starts from (A's shared-top entries on rank 0 only) and
+        the offset of the shared tail of the arena."""
+        a = np.zeros(self.arena_doubles, dtype=np.float64)
+        tail = C.c_int64(0)
+        check(self.L.cholamd_plan_fill_host_part(self.h, a.ctypes.data, rank, world, C.byref(tail)), "cholamd_plan_fill_host_part")
+        return a, tail.value
+
+    def level_work_counts(self, level, rank=0, world=1):
+        out = np.zeros(4, dtype=np.int32)
+        check(self.L.cholamd_plan_level_work_counts(self.h, level, rank, world, out.ctypes.data), "cholamd_plan_level_work_counts")
+        return tuple(int(v) for v in out)
+
     def arena_to_dense(self, arena):
         arena = np.ascontiguousarray(arena, dtype=np.float64)
         assert arena.size == self.arena_doubles

@@ -162,6 +162,13 @@ int64_t cholamd_plan_alg_bytes(const cholamd_plan *p);      /* B_alg = 8 (nnz(tr
 
 /* fill_block for every block (mmat.rg:529-633, 1216-1224): zero the arena and scatter A. */
 int cholamd_plan_fill_host(const cholamd_plan *p, double *arena);
+/* Multi-GPU view of the same: with `world` ranks the shared top of the tree (the tail of
+ * the arena starting at *tail_offset_out) receives A's entries on rank 0 only, so that the sum over
+ * ranks of the tails after the local levels equals A_top minus every contribution. */
+int cholamd_plan_fill_host_part(const cholamd_plan *p, double *arena, int rank, int world, int64_t *tail_offset_out);
+/* sizes of the device work lists of one tree level for (rank, world): potrf descriptors, trsm
+ * strips, update tasks, update sources */
+int cholamd_plan_level_work_counts(const cholamd_plan *p, int level, int rank, int world, int out[4]);
 /* dense N x N col-major image of an arena (zeros outside allocated blocks) and back */
 int cholamd_plan_arena_to_dense(const cholamd_plan *p, const double *arena, double *dense);
 /* write_matrix (mmat.rg:102-147): banner, "M N nnz", "row col %0.8g" per non-zero, block by

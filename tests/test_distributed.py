@@ -1,0 +1,131 @@
+"""Multi-rank tests of the subtree sharding.
+
+* CPU (gloo, world_size 2): the host-side partition logic -- per-rank fills whose tails sum to the
+  full fill, and per-rank work lists that tile the full schedule -- with a real all-reduce.
+* GPU (marker gpu; gloo, 2 and 4 ranks sharing the one GPU of the test box): the sharded
+  factorisation equals the single-GPU one to 1e-12."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import case_paths
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _cpu_worker(rank, world, port, case, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cholesky_amd as ca
+    plan = ca.Plan(*case_paths(case)[:3])
+    arena, tail = plan.fill_host_part(rank, world)
+    t = torch.from_numpy(arena[tail:].copy())
+    dist.all_reduce(t)
+    full = plan.fill_host()
+    ok_tail = bool(np.array_equal(t.numpy(), full[tail:]))
+    d = world.bit_length() - 1
+    counts = torch.tensor([plan.level_work_counts(l, rank, world) for l in range(plan.levels)], dtype=torch.int64)
+    below = counts.clone()
+    below[:d] = 0  # levels above the cut are replicated, not shared
+    dist.all_reduce(below)
+    whole = torch.tensor([plan.level_work_counts(l) for l in range(plan.levels)], dtype=torch.int64)
+    ok_lists = bool(torch.equal(below[d:, :2], whole[d:, :2])) and bool(torch.equal(counts[:d], whole[:d]))
+    # update sources below the cut are partitioned by source separator: their counts add up too
+    ok_src = bool(torch.equal(below[d:, 3], whole[d:, 3]))
+    if rank == 0:
+        q.put((ok_tail, ok_lists, ok_src, tail))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["lapl_400x400", "lapl_3375x3375"])
+def test_partition_logic_gloo_world2(case):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cpu_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    ok_tail, ok_lists, ok_src, tail = q.get()
+    assert ok_tail and ok_lists and ok_src and tail > 0
+
+
+def _gpu_worker(rank, world, port, case, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cholesky_amd as ca
+    from cholesky_amd import parallel
+    plan = ca.Plan(*case_paths(case)[:3])
+    dev = ca.Device(plan, 0)  # every rank on the one GPU of the test box
+    dev.set_partition(rank, world)
+    tail = parallel.tail_offset(plan, world)
+    arena = dev.new_arena()
+    dev.fill(arena)
+    parallel.factor_sharded(dev, arena, world, tail, via_host=True)
+    dev.sync()
+    info = dev.info()
+    # gather: every rank owns the panels of its subtrees + the (replicated) top
+    mine = arena.cpu()
+    gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, gathered, dst=0)
+    if rank == 0:
+        q.put((info, [g.numpy() for g in gathered], tail))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_factorisation_matches_single_gpu(world):
+    import cholesky_amd as ca
+    case = "lapl_3375x3375"
+    plan = ca.Plan(*case_paths(case)[:3])
+    dev = ca.Device(plan, 0)
+    arena = dev.new_arena()
+    dev.fill(arena)
+    dev.factor(arena)
+    dev.sync()
+    ref = arena.cpu().numpy()
+
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    info, parts, tail = q.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert info == (0, 0)
+    # assemble: panel of separator s comes from its owner; the top from rank 0
+    blocks = plan.blocks
+    d = world.bit_length() - 1
+    tree = plan.tree
+    owner = {}
+    for h in range(1, plan.nsep + 1):
+        lvl = h.bit_length() - 1
+        owner[int(tree[h - 1])] = 0 if lvl < d else (h >> (lvl - d)) - (1 << d)
+    diag = {int(b[1]): int(b[7]) for b in blocks if b[0] == b[1]}
+    order = sorted(diag)
+    out = np.zeros_like(ref)
+    for i, s in enumerate(order):
+        lo = diag[s]
+        hi = diag[order[i + 1]] if i + 1 < len(order) else plan.arena_doubles
+        out[lo:hi] = parts[owner[s]][lo:hi]
+    assert np.abs(out - ref).max() <= 1e-12
+    # every rank holds the same top factor
+    for r in range(1, world):
+        assert np.abs(parts[r][tail:] - parts[0][tail:]).max() <= 1e-12
