@@ -33,6 +33,18 @@ CASES = {
 }
 PEAK_FP64_TFLOPS = 78.6   # MI355X dense fp64 (vector = matrix) peak, public spec; the microarch guide lists no fp64 row
 PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")  # rocprofv3 --pmc passes of this very command
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (counters cannot be read live
+    from inside the process); None if that profile is not there."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            k = json.load(f)["kernels"][kernel]
+        return k["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(files, flops, budget_s=12.0):
@@ -171,7 +183,10 @@ def main():
                        "factor_info": list(info)},
             "roofline": {"bound": "mfma", "kernel": f"k_{dom}", "achieved": None if achieved is None else round(achieved, 5),
                          "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": None if achieved is None else round(achieved / PEAK_FP64_TFLOPS, 6), "traffic": None,
+                         "frac": None if achieved is None else round(achieved / PEAK_FP64_TFLOPS, 6),
+                         "traffic": pmc_traffic({"potrf": "k_potrf_rr", "trsm": "k_trsm_rr", "update": "k_update"}[dom]) if world == 1 else None,
+                         "traffic_note": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r1/pmc_summary.json (separate rocprofv3 --pmc passes of this command); algorithmic bytes of the same launch in alg_bytes_per_launch",
+                         "alg_bytes_per_launch": (16.0 * sum(int(n) * (int(n) + 1) // 2 for n in plan.sep_sizes) / max(launches_per_factor, 1)) if dom == "potrf" else None,
                          "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": launches_per_factor,
                          "alg_flops_per_launch": flops_per_launch,
                          "whole_step_frac_of_fp64_peak": round(value * 1e-3 / PEAK_FP64_TFLOPS, 6),

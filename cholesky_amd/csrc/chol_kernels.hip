@@ -412,7 +412,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
       if (lane < TS) {
         const int b4 = lane & ~3, qi = lane & 3;
 #pragma unroll
-        for (int c = 0; c < TS; ++c) sL[par][lane][c] = (c <= lane) ? a[c] : 0.0;
+        for (int c = 0; c < TS; ++c) sL[par][lane][c] = a[c]; // entries above the diagonal are finite junk nobody uses
 #pragma unroll
         for (int m = 0; m < 4; ++m) sYd[par][qi][b4 + m] = x[m]; // Ydiag(c = 4b+m, k = qi) = Linv_bb(m, qi)
       }
