@@ -141,13 +141,14 @@ __global__ __launch_bounds__(256) void k_update(double *__restrict__ base, const
 // ================================================================================================
 #define TS 16
 #define RR_MAXT 17
+#define RR_NHEAVY 9  /* tile waves that do not share a SIMD with the factor wave */
 // In-kernel cycle stamps of the factor wave: diagnostic builds only (-DCHOL_STAMPS, scripts/stamp_potrf.hip)
 #ifdef CHOL_STAMPS
 __device__ unsigned long long g_stamps[16];
 #define STAMP_DECL unsigned long long st_[8], acc_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
 #define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_[i]) :: "memory"); __builtin_amdgcn_sched_barrier(0); if ((i) > 0) acc_[i] += st_[i] - st_[(i) - 1]; } while (0)
 #define STAMP_FLUSH do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) g_stamps[i_] = acc_[i_]; } while (0)
-#define STAMP_FLUSH2 do { if (lane == 0 && w == 3) for (int i_ = 0; i_ < 8; ++i_) g_stamps[8 + i_] = acc_[i_]; } while (0)
+#define STAMP_FLUSH2 do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) g_stamps[8 + i_] = acc_[i_]; } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(i)
@@ -171,17 +172,17 @@ template <int I> __device__ __forceinline__ double quad_bcast(double v)
   return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(d) to fp64 accuracy: v_rsq_f64 seed + two Newton steps (6 dependent FMAs instead of the
-// ~45-instruction sqrt + divide sequence on the critical path of every column)
+// 1/sqrt(d) to fp64 accuracy.  Measured on gfx950: the v_rsq_f64 seed is good to 5.2e-8, one Newton step
+// leaves 4e-15 (36 ulp), two reach 1.4e-16.  A lone wave issues one DP instruction per ~11 cycles
+// (scripts/dp_lat.hip), so the pivot chain is bound by its DP instruction COUNT: one third-order step
+//   e = 1 - d y^2,  y <- y (1 + e/2 + 3 e^2/8)        (error ~ e^3 = 1e-22)
+// costs 5 DP instructions against 7 for two Newton steps.
 __device__ __forceinline__ double rsqrt_nr(double d)
 {
-  double y = __builtin_amdgcn_rsq(d);
-  const double h = 0.5 * d;
-  double e = fma(-(h * y), y, 0.5);
-  y = fma(y, e, y);
-  e = fma(-(h * y), y, 0.5);
-  y = fma(y, e, y);
-  return y;
+  const double y = __builtin_amdgcn_rsq(d);
+  const double e = fma(-(d * y), y, 1.0);
+  const double q = e * fma(0.375, e, 0.5);
+  return fma(y, q, y);
 }
 
 // 16x16 lower Cholesky, one row per lane (row = lane & 15; the four 16-lane groups of the wave
@@ -201,10 +202,10 @@ __device__ __forceinline__ int chol16_rows(double (&a)[TS], double &myinv, int r
     const double rv = rsqrt_nr(d);
     const double r = readlane_f64(rv, 0); // wave uniform: keep it in SGPRs
     myinv = (r15 == j) ? rv : myinv;
-    const double t = a[j] * (r * r);
+    a[j] = a[j] * r; // L(row, j); row j: d / sqrt(d)
+    const double t = a[j] * r;
 #pragma unroll
     for (int k = j + 1; k < TS; ++k) a[k] = fma(-t, akj[k], a[k]);
-    a[j] = a[j] * r; // row j: d / sqrt(d)
     __builtin_amdgcn_sched_barrier(0); // bound the live range of the broadcast scalars to one column
   }
   return bad;
@@ -280,6 +281,27 @@ __device__ __forceinline__ void own_block_row(const double (&a)[TS], int r15, do
   }
 }
 
+// Owner of tile `idx` of the column-major enumeration.  Hardware waves 0, 4, 8 share a SIMD and fp64 MFMA
+// shares the DP units with the factor wave's scalar chain, so the two tile waves on that SIMD (tile-wave
+// indices 3 and 7, "light") get 3 tiles for every 5 of the nine others: tiles are dealt in rounds of
+// 11, 9, 11, 9, 11 (= 51 per cycle; 153 tiles = 3 cycles -> 15 per heavy wave, 9 per light wave).
+// Slots grow with idx for every wave, so a wave's active tiles (column > k) are a suffix of its slots.
+__device__ __forceinline__ void rr_owner(int idx, int &w, int &slot)
+{
+  const int cyc = idx / 51, pos = idx % 51;
+  const int round = pos < 11 ? 0 : pos < 20 ? 1 : pos < 31 ? 2 : pos < 40 ? 3 : 4;
+  const int off = pos - (round == 0 ? 0 : round == 1 ? 11 : round == 2 ? 20 : round == 3 ? 31 : 40);
+  if (off < RR_NHEAVY) { // heavy waves in order: tile-wave indices 0,1,2,4,5,6,8,9,10
+    w = off + off / 3;
+    slot = cyc * 5 + round;
+  } else {
+    w = off == RR_NHEAVY ? 3 : 7;
+    slot = cyc * 3 + round / 2;
+  }
+}
+// position of a tile wave among the heavy ones (-1 for the two light waves)
+__device__ __forceinline__ int rr_heavy_index(int w) { return (w & 3) == 3 ? -1 : w - (w >> 2); }
+
 // tile index -> (i, j) of the column-major enumeration of the lower triangle of a T x T tile grid
 __device__ __forceinline__ void tile_of_index(int idx, int T, int &ti, int &tj)
 {
@@ -316,7 +338,7 @@ __device__ __forceinline__ void tile_of_index(int idx, int T, int &ti, int &tj)
 // then acquired; no s_barrier inside the loop (the factor wave would have to take part in it).
 // ------------------------------------------------------------------------------------------------
 #define RR_NW 11     /* tile waves */
-#define RR_SLOTS 14  /* ceil(17 * 18 / 2 / 11) */
+#define RR_SLOTS 15  /* most tiles a tile wave holds (see rr_owner) */
 #define RR_THREADS ((RR_NW + 1) * 64)
 // Note (measured): waves of a workgroup are dealt to the four SIMDs round-robin, so waves 0, 4 and 8
 // share a SIMD, and fp64 MFMA runs on the same DP units as fp64 VALU: the tile waves' 64-cycle MFMAs
@@ -376,12 +398,15 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
   const int r15 = lane & 15, g = lane >> 4;
   const int lp0 = g * TS + r15;
 
-  for (int t = threadIdx.x; t < RR_SLOTS * RR_NW; t += RR_THREADS) {
-    int ti, tj;
-    tile_of_index(t, T, ti, tj);
-    sIJ[t] = ti < 0 ? (unsigned short)0xffff : (unsigned short)(ti | (tj << 8));
-  }
+  for (int t = threadIdx.x; t < RR_SLOTS * RR_NW; t += RR_THREADS) sIJ[t] = (unsigned short)0xffff;
   if (threadIdx.x < 4) sFlag[threadIdx.x] = 0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < ntl; t += RR_THREADS) {
+    int ti, tj, ow, os;
+    tile_of_index(t, T, ti, tj);
+    rr_owner(t, ow, os);
+    sIJ[os * RR_NW + ow] = (unsigned short)(ti | (tj << 8));
+  }
   __syncthreads();
 
   if (wave == 0) {
@@ -485,32 +510,25 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
       __builtin_amdgcn_sched_barrier(0);
     }
     lds_inc(cUpd, lane);
+    STAMP_DECL;
     for (int k = 0; k < T; ++k) {
+      STAMP(0);
       int lp = lp0; // opaque once per step: keeps per-slot LDS addresses from being hoisted and spilled
       asm volatile("" : "+v"(lp));
       const int par = k & 1;
-      const int st1 = (k + 1) * T - ((k + 1) * k) / 2; // index of tile (k+1, k+1)
       // ---- 1. panel solve out of LDS (needs L(k,k) and every raw tile of column k)
       lds_wait_ge(fL, k + 1);
+      STAMP(1);
       lds_wait_ge(cUpd, RR_NW * (k + 1));
+      STAMP(2);
       {
         double Lr[3];
 #pragma unroll
         for (int b = 0; b < 3; ++b) Lr[b] = sL[par][r15][g + 4 * b];
         const double yd = sYd[par][g][r15];
-        if (w == (k % RR_NW)) { // one tile wave per step writes L(k,k) and Linv(k,k) back
-          const double l3 = sL[par][r15][g + 12];
-          const int row = k * TS + r15;
-          double *dst = A + row + (int64_t)(k * TS + g) * lda;
-          if (row < n) {
-#pragma unroll
-            for (int b = 0; b < 3; ++b)
-              if (g + 4 * b <= r15) dst[(int64_t)(4 * b) * lda] = Lr[b];
-            if (g + 12 <= r15) dst[(int64_t)12 * lda] = l3;
-          }
-          store_linv16(W + (int64_t)k * TS * TS, Lr, yd, r15, g);
-        }
-        for (int i = k + 2 + ((w + RR_NW - ((k + 2) % RR_NW)) % RR_NW); i < T; i += RR_NW) { // i = w (mod 11)
+        const int hw = rr_heavy_index(w);
+        // panel tile i goes to heavy wave i mod 9; the light waves keep the factor wave's SIMD quiet
+        for (int i = hw < 0 ? T : k + 2 + ((hw + RR_NHEAVY - ((k + 2) % RR_NHEAVY)) % RR_NHEAVY); i < T; i += RR_NHEAVY) {
           d4 raw;
 #pragma unroll
           for (int q = 0; q < 4; ++q) raw[q] = sRaw[i][q * 64 + lp];
@@ -525,17 +543,19 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
         }
       }
       // ---- 2. the whole panel is solved
+      STAMP(3);
       lds_inc(cSol, lane);
       lds_wait_ge(cSol, RR_NW * (k + 1));
+      STAMP(4);
       if (k + 1 < T) lds_wait_ge(fP, k + 1);
+      STAMP(5);
       // ---- 3. trailing update, slots from the top down, early exit at the first tile of column <= k
       const double *const sS = &sSol[0][0];
 #pragma unroll
       for (int s = RR_SLOTS - 1; s >= 0; --s) {
-        const int idx = s * RR_NW + w;
-        if (idx < st1) break;
-        if (idx < ntl) {
+        if (ijp[s] != 0xffff) {
           const int ti = ijp[s] & 0xff, tj = ijp[s] >> 8;
+          if (tj <= k) break; // this and every lower slot hold finished columns
           if (!(ti == tj && tj == k + 1)) { // (k+1,k+1) went to the factor wave one step ago
             d4 acc = tile[s];
 #pragma unroll
@@ -553,9 +573,30 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      // ---- the light waves solve no panel tiles: one of them writes L(k,k) and Linv(k,k) back to global
+      //      memory after its (short) update chain, off every other wave's path (sL / sYd of this parity
+      //      stay valid until every tile wave has finished step k)
+      if (w == ((k & 1) ? 7 : 3)) {
+        double Lr[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) Lr[b] = sL[par][r15][g + 4 * b];
+        const double yd = sYd[par][g][r15];
+        const double l3 = sL[par][r15][g + 12];
+        const int row = k * TS + r15;
+        double *dst = A + row + (int64_t)(k * TS + g) * lda;
+        if (row < n) {
+#pragma unroll
+          for (int b = 0; b < 3; ++b)
+            if (g + 4 * b <= r15) dst[(int64_t)(4 * b) * lda] = Lr[b];
+          if (g + 12 <= r15) dst[(int64_t)12 * lda] = l3;
+        }
+        store_linv16(W + (int64_t)k * TS * TS, Lr, yd, r15, g);
+      }
       // ---- 4.
+      STAMP(6);
       lds_inc(cUpd, lane);
     }
+    if (w == 0) { STAMP_FLUSH2; }
   }
 }
 

@@ -27,5 +27,9 @@ int main(int argc, char **argv)
   for (int i = 1; i < 8; i++) tot += st[i];
   printf("n=%d steps=%d total %.1f cycles/step (s_memtime ticks @100MHz? see ratio)\n", n, T, (double)tot / T);
   for (int i = 1; i < 8; i++) printf("  %-18s %10.1f ticks/step  %5.1f%%\n", names[i], (double)st[i] / T, 100.0 * st[i] / tot);
+  const char *n2[8] = { "", "wait fL (factor)", "wait cUpd (others)", "solve loop", "cSol barrier", "wait fP", "update chain", "" };
+  printf("tile wave 0:\n");
+  unsigned long long tt = 0; for (int i = 1; i < 7; i++) tt += st[8 + i];
+  for (int i = 1; i < 7; i++) printf("  %-22s %10.1f ticks/step %5.1f%%\n", n2[i], (double)st[8 + i] / T, 100.0 * st[8 + i] / tt);
   return 0;
 }
