@@ -9,7 +9,7 @@ BIN     := cholesky_amd/bin
 CFLAGS  := -O2 -fPIC -Wall -Wextra -std=gnu11 -Iinclude -I$(CSRC)
 HIPFLAGS:= -O3 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall
 
-HOST_OBJS := $(OUT)/chol_ingest.o $(OUT)/chol_symbolic.o $(OUT)/chol_schedule.o
+HOST_OBJS := $(OUT)/chol_ingest.o $(OUT)/chol_symbolic.o $(OUT)/chol_schedule.o $(OUT)/chol_generate.o
 HIP_OBJS  := $(OUT)/chol_kernels.o $(OUT)/chol_api.o
 
 all: $(OUT)/libcholamd.so $(BIN)/cholamd_mmat oracle

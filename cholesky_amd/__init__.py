@@ -7,8 +7,8 @@ tests, bench.py and the multi-GPU driver; torch is used only for device memory, 
 torch.distributed (RCCL).  Nothing here computes on the CPU.
 """
 from ._lib import CholamdError, Filled, Op, Region, load  # noqa: F401
-from .plan import Plan  # noqa: F401
+from .plan import Plan, Problem  # noqa: F401
 from .device import Device  # noqa: F401
 from . import blas  # noqa: F401
 
-__all__ = ["Plan", "Device", "blas", "CholamdError", "Filled", "Op", "Region", "load"]
+__all__ = ["Plan", "Problem", "Device", "blas", "CholamdError", "Filled", "Op", "Region", "load"]

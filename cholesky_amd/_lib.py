@@ -60,6 +60,13 @@ def load():
     L.cholamd_plan_create.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(vp)]
     L.cholamd_plan_create_from_arrays.argtypes = [ci, ci, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, C.c_char_p, C.POINTER(vp)]
     L.cholamd_plan_destroy.argtypes = [vp]
+    L.cholamd_generate_laplacian.argtypes = [ci, ci, ci, ci, ci, C.POINTER(vp)]
+    L.cholamd_problem_destroy.argtypes = [vp]
+    L.cholamd_problem_n.argtypes = [vp]
+    L.cholamd_problem_nz.argtypes = [vp]
+    L.cholamd_problem_write.argtypes = [vp, C.c_char_p]
+    L.cholamd_plan_create_from_problem.argtypes = [vp, C.POINTER(vp)]
+    L.cholamd_problem_rhs.argtypes = [vp, vp]
     for f in ("n", "nz", "levels", "num_separators", "max_int_size", "num_blocks"):
         getattr(L, "cholamd_plan_" + f).argtypes = [vp]
     for f in ("arena_doubles", "dropped_entries", "num_ops", "nnz_a", "nnz_l", "alg_bytes"):

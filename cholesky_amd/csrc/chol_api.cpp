@@ -23,7 +23,7 @@
 
 struct level_dev {
   int n_potrf = 0, n_trsm = 0, n_task = 0, n_src = 0;
-  int n_potrf_big = 0, n_trsm_big = 0; // pivots beyond CHOL_RR_MAXN are listed after the small ones
+  std::vector<chol_phase> phase; // launches of the level in order (big pivots are factored in column blocks)
   chol_potrf_desc *potrf = nullptr;
   chol_trsm_desc *trsm = nullptr;
   chol_upd_task *task = nullptr;
@@ -89,20 +89,10 @@ static int build_levels(cholamd_device *d)
     int rc = chol_build_level_work(d->plan, lvl, d->rank, d->world, &w);
     if (rc) return rc;
     level_dev &l = d->lv[lvl];
-    l.n_task = w.n_task; l.n_src = w.n_src;
-    // stable partition: register-resident kernels first, the generic ones for big pivots after
-    std::vector<chol_potrf_desc> pv;
-    for (int i = 0; i < w.n_potrf; i++) if (w.potrf[i].n <= CHOL_RR_MAXN) pv.push_back(w.potrf[i]);
-    l.n_potrf = (int)pv.size();
-    for (int i = 0; i < w.n_potrf; i++) if (w.potrf[i].n > CHOL_RR_MAXN) pv.push_back(w.potrf[i]);
-    l.n_potrf_big = w.n_potrf - l.n_potrf;
-    std::vector<chol_trsm_desc> tv;
-    for (int i = 0; i < w.n_trsm; i++) if (w.trsm[i].n <= CHOL_RR_MAXN) tv.push_back(w.trsm[i]);
-    l.n_trsm = (int)tv.size();
-    for (int i = 0; i < w.n_trsm; i++) if (w.trsm[i].n > CHOL_RR_MAXN) tv.push_back(w.trsm[i]);
-    l.n_trsm_big = w.n_trsm - l.n_trsm;
-    rc = upload_vec(&l.potrf, pv.data(), pv.size());
-    if (!rc) rc = upload_vec(&l.trsm, tv.data(), tv.size());
+    l.n_potrf = w.n_potrf; l.n_trsm = w.n_trsm; l.n_task = w.n_task; l.n_src = w.n_src;
+    l.phase.assign(w.phase, w.phase + w.n_phase);
+    rc = upload_vec(&l.potrf, w.potrf, (size_t)w.n_potrf);
+    if (!rc) rc = upload_vec(&l.trsm, w.trsm, (size_t)w.n_trsm);
     if (!rc) rc = upload_vec(&l.task, w.task, (size_t)w.n_task);
     if (!rc) rc = upload_vec(&l.src, w.src, (size_t)w.n_src);
     chol_level_work_free(&w);
@@ -264,17 +254,12 @@ extern "C" int cholamd_factor_levels(cholamd_device *d, double *d_arena, int lev
   if (level_hi == L - 1) HIPCHK(hipMemsetAsync(d->info, 0, 2 * sizeof(int), st));
   for (int lvl = level_hi; lvl >= level_lo; lvl--) { // mmat.rg:1227
     const level_dev &l = d->lv[lvl];
-    {
-      scoped_timer t(d, st, 0, l.n_potrf + l.n_potrf_big > 0);
-      HIPCHK((hipError_t)chol_launch_potrf(d_arena, d->ws, l.potrf, l.n_potrf, d->info, st));
-      HIPCHK((hipError_t)chol_launch_potrf_big(d_arena, d->ws, l.potrf + l.n_potrf, l.n_potrf_big, d->info, st));
+    for (const chol_phase &ph : l.phase) {
+      scoped_timer t(d, st, ph.kind, ph.n > 0);
+      if (ph.kind == 0) HIPCHK((hipError_t)chol_launch_potrf(d_arena, d->ws, l.potrf + ph.first, ph.n, d->info, st));
+      else if (ph.kind == 1) HIPCHK((hipError_t)chol_launch_trsm(d_arena, d->ws, l.trsm + ph.first, ph.n, st));
+      else HIPCHK((hipError_t)chol_launch_update(d_arena, l.task + ph.first, l.src, ph.n, st));
     }
-    {
-      scoped_timer t(d, st, 1, l.n_trsm + l.n_trsm_big > 0);
-      HIPCHK((hipError_t)chol_launch_trsm(d_arena, d->ws, l.trsm, l.n_trsm, st));
-      HIPCHK((hipError_t)chol_launch_trsm_big(d_arena, d->ws, l.trsm + l.n_trsm, l.n_trsm_big, st));
-    }
-    { scoped_timer t(d, st, 2, l.n_task > 0); HIPCHK((hipError_t)chol_launch_update(d_arena, l.task, l.src, l.n_task, st)); }
   }
   return 0;
 }

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
       const int bad = chol16_rows(a, myinv, r15);
       STAMP(2);
       if (bad && k * TS + bad <= n && lane == 0) {
-        if (atomicCAS(&info[0], 0, k * TS + bad) == 0) info[1] = d.sep;
+        if (atomicCAS(&info[0], 0, d.col0 + k * TS + bad) == 0) info[1] = d.sep;
       }
       own_block_row(a, r15, blk);
       linv4_quad(blk, myinv, x, r15 & 3);
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256) void k_potrf_big(double *__restrict__ base, do
       }
       const int bad = chol16_rows(a, myinv, r15);
       if (bad && j0 + bad <= n && lane == 0) {
-        if (atomicCAS(&info[0], 0, j0 + bad) == 0) info[1] = d.sep;
+        if (atomicCAS(&info[0], 0, d.col0 + j0 + bad) == 0) info[1] = d.sep;
       }
       own_block_row(a, r15, blk);
       linv4_quad(blk, myinv, x, r15 & 3);

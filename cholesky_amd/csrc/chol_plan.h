@@ -43,7 +43,7 @@ typedef struct {
   int64_t dinv_off;   /* workspace offset of this separator's inverted diagonal NBxNB blocks */
   int n, lda;
   int sep;            /* label (for info reporting) */
-  int pad;
+  int col0;           /* first column of this diagonal block inside its pivot (blocked big pivots) */
 } chol_potrf_desc;
 
 typedef struct {
@@ -70,12 +70,18 @@ typedef struct {
   int pad;
 } chol_upd_task;
 
+/* one batched launch: descriptors [first, first + n) of the level's array of that kind */
+typedef struct { int kind /* 0 potrf, 1 trsm, 2 update */, first, n; } chol_phase;
+
+#define CHOL_BIG_NB 256 /* column-block width of the blocked factorisation of pivots > CHOL_RR_MAXN */
+
 typedef struct {
   int level;
+  int n_phase; chol_phase *phase;          /* launches of this level, in order */
   int n_potrf; chol_potrf_desc *potrf;
   int n_trsm; chol_trsm_desc *trsm;
   int n_task; chol_upd_task *task;
-  int n_src; chol_upd_src *src;
+  int n_src; chol_upd_src *src;            /* task.src_begin/src_end index this array */
 } chol_level_work;
 
 /* solve-phase descriptors */

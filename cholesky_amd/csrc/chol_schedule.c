@@ -65,10 +65,92 @@ static void index_snapshot(const plan_t *p, int lbl, int64_t *first, int *count)
   }
 }
 
+/* growable arrays of the level work */
+typedef struct { chol_level_work *w; int cap_p, cap_t, cap_k, cap_s, cap_ph; } builder;
+
+static void push_phase(builder *B, int kind, int first, int n)
+{
+  if (n <= 0) return;
+  chol_level_work *w = B->w;
+  if (w->n_phase == B->cap_ph) { B->cap_ph = B->cap_ph ? 2 * B->cap_ph : 16; w->phase = realloc(w->phase, B->cap_ph * sizeof(chol_phase)); }
+  chol_phase ph = { kind, first, n };
+  w->phase[w->n_phase++] = ph;
+}
+static void push_potrf(builder *B, chol_potrf_desc d)
+{
+  chol_level_work *w = B->w;
+  if (w->n_potrf == B->cap_p) { B->cap_p = B->cap_p ? 2 * B->cap_p : 32; w->potrf = realloc(w->potrf, B->cap_p * sizeof(chol_potrf_desc)); }
+  w->potrf[w->n_potrf++] = d;
+}
+/* a run of `m` consecutive panel rows -> strips of CHOL_TRSM_ROWS */
+static void push_trsm_run(builder *B, int64_t l_off, int64_t dinv_off, int64_t b_off, int n, int ld, int m)
+{
+  chol_level_work *w = B->w;
+  for (int r0 = 0; r0 < m; r0 += CHOL_TRSM_ROWS) {
+    if (w->n_trsm == B->cap_t) { B->cap_t = B->cap_t ? 2 * B->cap_t : 64; w->trsm = realloc(w->trsm, B->cap_t * sizeof(chol_trsm_desc)); }
+    const int mm = m - r0 < CHOL_TRSM_ROWS ? m - r0 : CHOL_TRSM_ROWS;
+    chol_trsm_desc td = { l_off, dinv_off, b_off + r0, n, ld, mm, ld };
+    w->trsm[w->n_trsm++] = td;
+  }
+}
+static int push_src(builder *B, chol_upd_src sd)
+{
+  chol_level_work *w = B->w;
+  if (w->n_src == B->cap_s) { B->cap_s = B->cap_s ? 2 * B->cap_s : 256; w->src = realloc(w->src, B->cap_s * sizeof(chol_upd_src)); }
+  w->src[w->n_src] = sd;
+  return w->n_src++;
+}
+/* 16x16 sub-tile tasks of one m x n target whose sources are [src_begin, src_end) */
+static void push_tasks(builder *B, int64_t c_off, int ldc, int m, int n, int syrk, int src_begin, int src_end)
+{
+  chol_level_work *w = B->w;
+  const int tr = (m + 15) / 16, tc = (n + 15) / 16;
+  for (int a = 0; a < tr; a++)
+    for (int b = 0; b < tc; b++) {
+      if (syrk && b > a) continue;
+      if (w->n_task == B->cap_k) { B->cap_k = B->cap_k ? 2 * B->cap_k : 256; w->task = realloc(w->task, B->cap_k * sizeof(chol_upd_task)); }
+      chol_upd_task *t = &w->task[w->n_task++];
+      memset(t, 0, sizeof *t);
+      t->c_off = c_off + a * 16 + (int64_t)b * 16 * ldc;
+      t->ldc = ldc;
+      t->mv = (short)(m - a * 16 < 16 ? m - a * 16 : 16);
+      t->nv = (short)(n - b * 16 < 16 ? n - b * 16 : 16);
+      t->lower = (syrk && a == b);
+      t->src_begin = src_begin; t->src_end = src_end;
+      t->ar = a * 16; t->br = b * 16;
+    }
+}
+
+/* filled row runs of the ancestor blocks of panel(s): (arena offset of the run's first row in column 0
+ * of the panel, rows); tiles come in increasing row order and adjacent ones are merged */
+typedef struct { int64_t off; int m; } row_run;
+static int ancestor_runs(const plan_t *p, int h, const cholamd_filled *snap, const int64_t *first, const int *count, row_run **out)
+{
+  const int s = p->tree[h];
+  int cap = 16, n = 0;
+  row_run *r = malloc(cap * sizeof(row_run));
+  for (int hp = h / 2; hp >= 1; hp /= 2) {
+    const int b = BIDX(p, p->tree[hp], s);
+    const chol_block *Bk = &p->blk[b];
+    for (int q = 0; q < count[b]; q++) {
+      const cholamd_filled *f = &snap[first[b] + q];
+      const int64_t off = Bk->off + (f->lo_x - Bk->lo_x);
+      const int m = f->hi_x - f->lo_x + 1;
+      if (n > 0 && r[n - 1].off + r[n - 1].m == off) { r[n - 1].m += m; continue; }
+      if (n == cap) { cap *= 2; r = realloc(r, cap * sizeof(row_run)); }
+      r[n].off = off; r[n].m = m; n++;
+    }
+  }
+  *out = r;
+  return n;
+}
+
 int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_level_work *w)
 {
   memset(w, 0, sizeof *w);
   w->level = level;
+  builder Bd; memset(&Bd, 0, sizeof Bd); Bd.w = w;
+  builder *B = &Bd;
   const int L = p->levels, lbl = L - 1 - level;
   const int d = chol_split_level(world);
   if (world < 1 || (1 << d) != world || d > L - 1 || rank < 0 || rank >= world) { chol_set_error("bad partition rank %d of %d", rank, world); return CHOLAMD_ERR_ARG; }
@@ -78,47 +160,64 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
   index_snapshot(p, lbl, first, count);
   const cholamd_filled *snap = p->snap[lbl];
 
-  int cap_p = h1 - h0 + 1, cap_t = 64, cap_u = 256;
-  w->potrf = malloc(cap_p * sizeof(chol_potrf_desc));
-  w->trsm = malloc(cap_t * sizeof(chol_trsm_desc));
-  upd_tuple *tu = malloc(cap_u * sizeof(upd_tuple));
-  int ntu = 0;
-  int64_t seq = 0;
-
+  /* the separators of this level this rank works on */
+  int *hs = malloc((h1 - h0 + 1) * sizeof(int)), nh = 0, steps = 0;
   for (int h = h0; h <= h1; h++) {
-    int s = p->tree[h];
+    const int s = p->tree[h];
     if (level >= d && chol_owner_of(p, s, world) != rank) continue;
-    int bs = BIDX(p, s, s);
-    if (count[bs] == 0 || p->sep_size[s] == 0) continue;
-    const int n = p->sep_size[s], ld = p->panel_ld[s];
-    chol_potrf_desc pd = { p->panel_off[s], p->dinv_off[s], n, ld, s, 0 };
-    w->potrf[w->n_potrf++] = pd;
-    /* TRSM row runs over all ancestor blocks of panel(s): tiles come in increasing row order */
-    {
-      int64_t run_off = 0; int run_m = 0;
-      for (int hp = h / 2;; hp /= 2) {
-        int nb_tiles = 0; int64_t fb = 0; const chol_block *B = NULL;
-        if (hp >= 1) { int b = BIDX(p, p->tree[hp], s); B = &p->blk[b]; nb_tiles = count[b]; fb = first[b]; }
-        for (int q = 0; q < nb_tiles + (hp == 0); q++) {
-          int64_t off = -1; int m = 0;
-          if (hp >= 1) {
-            const cholamd_filled *f = &snap[fb + q];
-            off = B->off + (f->lo_x - B->lo_x);
-            m = f->hi_x - f->lo_x + 1;
-            if (run_m > 0 && off == run_off + run_m) { run_m += m; continue; }
-          }
-          for (int r0 = 0; r0 < run_m; r0 += CHOL_TRSM_ROWS) { /* flush the finished run in chunks */
-            if (w->n_trsm == cap_t) { cap_t *= 2; w->trsm = realloc(w->trsm, cap_t * sizeof(chol_trsm_desc)); }
-            int mm = run_m - r0 < CHOL_TRSM_ROWS ? run_m - r0 : CHOL_TRSM_ROWS;
-            chol_trsm_desc td = { p->panel_off[s], p->dinv_off[s], run_off + r0, n, ld, mm, ld };
-            w->trsm[w->n_trsm++] = td;
-          }
-          run_off = off; run_m = m;
-        }
-        if (hp == 0) break;
-      }
+    if (count[BIDX(p, s, s)] == 0 || p->sep_size[s] == 0) continue;
+    hs[nh++] = h;
+    if (p->sep_size[s] > CHOL_RR_MAXN) {
+      const int st = (p->sep_size[s] + CHOL_BIG_NB - 1) / CHOL_BIG_NB;
+      if (st > steps) steps = st;
     }
-    /* update tuples in program order: par bottom-up, gp from par to the root, tiles i, j */
+  }
+  if (steps == 0) steps = 1;
+  /* pivots: small ones (<= CHOL_RR_MAXN) whole in step 0; big ones in CHOL_BIG_NB-column blocks, each step =
+   * POTRF of the diagonal block, TRSM of every row below it (rows of the pivot and filled ancestor rows
+   * alike), rank-nb update of the remaining columns of those rows */
+  for (int st = 0; st < steps; st++) {
+    const int p0 = w->n_potrf, t0 = w->n_trsm, k0 = w->n_task;
+    for (int q = 0; q < nh; q++) {
+      const int h = hs[q], s = p->tree[h], n = p->sep_size[s], ld = p->panel_ld[s];
+      const int big = n > CHOL_RR_MAXN;
+      if (!big && st > 0) continue;
+      const int c0 = big ? st * CHOL_BIG_NB : 0;
+      if (c0 >= n) continue;
+      const int nb = big ? (n - c0 < CHOL_BIG_NB ? n - c0 : CHOL_BIG_NB) : n;
+      const int64_t diag = p->panel_off[s] + c0 + (int64_t)c0 * ld;          /* element (c0, c0) of the pivot */
+      const int64_t dinv = p->dinv_off[s] + (int64_t)(c0 / CHOL_NB) * CHOL_NB * CHOL_NB;
+      chol_potrf_desc pd = { diag, dinv, nb, ld, s, c0 };
+      push_potrf(B, pd);
+      const int64_t colbase = (int64_t)c0 * ld;                              /* column c0 of the panel */
+      const int below = n - c0 - nb;                                         /* pivot rows under the diagonal block */
+      if (below > 0) push_trsm_run(B, diag, dinv, p->panel_off[s] + (c0 + nb) + colbase, nb, ld, below);
+      row_run *runs; const int nr = ancestor_runs(p, h, snap, first, count, &runs);
+      for (int r = 0; r < nr; r++) push_trsm_run(B, diag, dinv, runs[r].off + colbase, nb, ld, runs[r].m);
+      if (below > 0) { /* trailing columns [c0+nb, n): lower triangle of the pivot rows, everything of the ancestor rows */
+        const int64_t x_piv = p->panel_off[s] + (c0 + nb) + colbase;         /* X rows = solved pivot rows, k = nb */
+        chol_upd_src sp = { x_piv, x_piv, ld, ld, nb, 0 };
+        const int sidx = push_src(B, sp);
+        push_tasks(B, p->panel_off[s] + (c0 + nb) + (int64_t)(c0 + nb) * ld, ld, below, below, 1, sidx, sidx + 1);
+        for (int r = 0; r < nr; r++) {
+          chol_upd_src sa = { runs[r].off + colbase, x_piv, ld, ld, nb, 0 };
+          const int si = push_src(B, sa);
+          push_tasks(B, runs[r].off + (int64_t)(c0 + nb) * ld, ld, runs[r].m, below, 0, si, si + 1);
+        }
+      }
+      free(runs);
+    }
+    push_phase(B, 0, p0, w->n_potrf - p0);
+    push_phase(B, 1, t0, w->n_trsm - t0);
+    push_phase(B, 2, k0, w->n_task - k0);
+  }
+  /* extend-add of the level: tuples in program order (par bottom-up, gp from par to the root, tiles i, j),
+   * grouped by target tile */
+  int cap_u = 256, ntu = 0;
+  upd_tuple *tu = malloc(cap_u * sizeof(upd_tuple));
+  int64_t seq = 0;
+  for (int q = 0; q < nh; q++) {
+    const int h = hs[q], s = p->tree[h], n = p->sep_size[s];
     for (int hp = h / 2; hp >= 1; hp /= 2) {
       int par = p->tree[hp];
       int bb = BIDX(p, par, s);
@@ -148,49 +247,29 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
       }
     }
   }
-  /* group by target tile, keeping program order inside a group */
   qsort(tu, ntu, sizeof(upd_tuple), cmp_tuple);
-  int ngroups = 0, ntask = 0;
-  for (int i = 0; i < ntu; i++)
-    if (i == 0 || tu[i].key != tu[i - 1].key) {
-      ngroups++;
-      int tr = (tu[i].m + 15) / 16, tc = (tu[i].n + 15) / 16;
-      ntask += tu[i].syrk ? tr * (tr + 1) / 2 : tr * tc;
-    }
-  w->src = malloc((ntu > 0 ? ntu : 1) * sizeof(chol_upd_src));
-  w->task = malloc((ntask > 0 ? ntask : 1) * sizeof(chol_upd_task));
-  w->n_src = ntu;
-  for (int i = 0; i < ntu; i++) {
-    chol_upd_src sd = { tu[i].a_off, tu[i].b_off, tu[i].lda, tu[i].ldb, tu[i].k, 0 };
-    w->src[i] = sd;
-  }
-  for (int i = 0; i < ntu;) {
-    int e = i + 1;
-    while (e < ntu && tu[e].key == tu[i].key) e++;
-    const upd_tuple *g = &tu[i];
-    int tr = (g->m + 15) / 16, tc = (g->n + 15) / 16;
-    for (int a = 0; a < tr; a++)
-      for (int b = 0; b < tc; b++) {
-        if (g->syrk && b > a) continue;
-        chol_upd_task *t = &w->task[w->n_task++];
-        t->c_off = g->c_off + a * 16 + (int64_t)b * 16 * g->ldc;
-        t->ldc = g->ldc;
-        t->mv = (short)(g->m - a * 16 < 16 ? g->m - a * 16 : 16);
-        t->nv = (short)(g->n - b * 16 < 16 ? g->n - b * 16 : 16);
-        t->lower = (g->syrk && a == b);
-        t->src_begin = i; t->src_end = e;
-        t->ar = a * 16; t->br = b * 16;
+  {
+    const int k0 = w->n_task;
+    for (int i = 0; i < ntu;) {
+      int e = i + 1;
+      while (e < ntu && tu[e].key == tu[i].key) e++;
+      const int sb = w->n_src;
+      for (int q = i; q < e; q++) {
+        chol_upd_src sd = { tu[q].a_off, tu[q].b_off, tu[q].lda, tu[q].ldb, tu[q].k, 0 };
+        push_src(B, sd);
       }
-    i = e;
+      push_tasks(B, tu[i].c_off, tu[i].ldc, tu[i].m, tu[i].n, tu[i].syrk, sb, w->n_src);
+      i = e;
+    }
+    push_phase(B, 2, k0, w->n_task - k0);
   }
-  (void)ngroups;
-  free(tu); free(first); free(count);
+  free(tu); free(first); free(count); free(hs);
   return 0;
 }
 
 void chol_level_work_free(chol_level_work *w)
 {
-  free(w->potrf); free(w->trsm); free(w->task); free(w->src);
+  free(w->potrf); free(w->trsm); free(w->task); free(w->src); free(w->phase);
   memset(w, 0, sizeof *w);
 }
 

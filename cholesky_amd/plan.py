@@ -166,3 +166,40 @@ def read_vector(path, n):
 def write_solution(path, x, full_precision=False):
     x = np.ascontiguousarray(x, dtype=np.float64)
     check(load().cholamd_write_solution(os.fsencode(path), x.ctypes.data, x.size, int(full_precision)), "cholamd_write_solution")
+
+
+class Problem:
+    """Generated Laplacian + nested-dissection ordering + clusters (cholamd_generate_laplacian)."""
+
+    def __init__(self, nx, ny=1, nz=1, levels=3, tile=32):
+        self.L = load()
+        h = C.c_void_p()
+        check(self.L.cholamd_generate_laplacian(nx, ny, nz, levels, tile, C.byref(h)), "cholamd_generate_laplacian")
+        self.h = h
+        self.n = self.L.cholamd_problem_n(h)
+        self.nz = self.L.cholamd_problem_nz(h)
+        self.levels = levels
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.cholamd_problem_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def write(self, prefix):
+        """<prefix>.mtx, _ord_<levels>.txt, _clust_<levels>.txt, _B.mtx in the reference's formats."""
+        check(self.L.cholamd_problem_write(self.h, os.fsencode(prefix)), "cholamd_problem_write")
+        lv = self.levels
+        return f"{prefix}.mtx", f"{prefix}_ord_{lv}.txt", f"{prefix}_clust_{lv}.txt", f"{prefix}_B.mtx"
+
+    def plan(self):
+        h = C.c_void_p()
+        check(self.L.cholamd_plan_create_from_problem(self.h, C.byref(h)), "cholamd_plan_create_from_problem")
+        return Plan(_handle=h)
+
+    def rhs(self):
+        b = np.zeros(self.n, dtype=np.float64)
+        self.L.cholamd_problem_rhs(self.h, b.ctypes.data)
+        return b

@@ -180,6 +180,28 @@ int cholamd_write_solution(const char *file, const double *x, int n, int full_pr
 int cholamd_plan_write_debug_log(const cholamd_plan *p, FILE *f);
 
 /* ----------------------------------------------------------------------------------------- */
+/* Problem generator (absent from the reference, whose orderings come from an      */
+/* external tool): d-dimensional 5-/7-point Laplacian on an nx x ny x nz grid (nz = 1 for 2-D),   */
+/* natural index x + nx*y + nx*ny*z, diagonal 2*dim, off-diagonal -1, lower triangle -- exactly    */
+/* the fixtures' matrices -- with a geometric nested-dissection ordering of `levels` tree levels  */
+/* (split the longest side at its middle plane) and cluster lists that satisfy the invariants of  */
+/* SURVEY A.3 (tiles of about `tile` dofs at interval 0, halved per interval, ONE tile at the      */
+/* interval in force when a separator is eliminated).  Outputs are in the reference's on-disk      */
+/* formats (Appendix A) so that the reference, the oracle and this library read the same files.    */
+/* ----------------------------------------------------------------------------------------- */
+typedef struct cholamd_problem cholamd_problem;
+int cholamd_generate_laplacian(int nx, int ny, int nz, int levels, int tile, cholamd_problem **out);
+void cholamd_problem_destroy(cholamd_problem *g);
+int cholamd_problem_n(const cholamd_problem *g);
+int cholamd_problem_nz(const cholamd_problem *g);
+/* writes <prefix>.mtx, <prefix>_ord_<levels>.txt, <prefix>_clust_<levels>.txt and B_<n>x1.mtx-style
+ * rhs (b_i = 1 + (7919 i mod 10)) as <prefix>_B.mtx */
+int cholamd_problem_write(const cholamd_problem *g, const char *prefix);
+/* plan straight from memory (no files) */
+int cholamd_plan_create_from_problem(const cholamd_problem *g, cholamd_plan **out);
+void cholamd_problem_rhs(const cholamd_problem *g, double *b);
+
+/* ----------------------------------------------------------------------------------------- */
 /* L-C: device side.  The arena (all per-separator panels, col-major, contiguous) lives in HBM. */
 /* ----------------------------------------------------------------------------------------- */
 typedef struct cholamd_device cholamd_device;
