@@ -26,7 +26,7 @@ struct level_dev {
   std::vector<chol_phase> phase; // launches of the level in order (big pivots are factored in column blocks)
   chol_potrf_desc *potrf = nullptr;
   chol_trsm_desc *trsm = nullptr;
-  chol_upd_task *task = nullptr;
+  chol_upd_task *task = nullptr, *task_mt = nullptr;
   chol_upd_src *src = nullptr;
 };
 struct solve_dev {
@@ -75,7 +75,7 @@ template <class T> static int upload_vec(T **dptr, const T *h, size_t n)
 
 static void free_levels(cholamd_device *d)
 {
-  for (auto &l : d->lv) { (void)hipFree(l.potrf); (void)hipFree(l.trsm); (void)hipFree(l.task); (void)hipFree(l.src); }
+  for (auto &l : d->lv) { (void)hipFree(l.potrf); (void)hipFree(l.trsm); (void)hipFree(l.task); (void)hipFree(l.task_mt); (void)hipFree(l.src); }
   d->lv.clear();
 }
 
@@ -94,6 +94,7 @@ static int build_levels(cholamd_device *d)
     rc = upload_vec(&l.potrf, w.potrf, (size_t)w.n_potrf);
     if (!rc) rc = upload_vec(&l.trsm, w.trsm, (size_t)w.n_trsm);
     if (!rc) rc = upload_vec(&l.task, w.task, (size_t)w.n_task);
+    if (!rc) rc = upload_vec(&l.task_mt, w.task_mt, (size_t)w.n_task_mt);
     if (!rc) rc = upload_vec(&l.src, w.src, (size_t)w.n_src);
     chol_level_work_free(&w);
     if (rc) return rc;
@@ -255,10 +256,11 @@ extern "C" int cholamd_factor_levels(cholamd_device *d, double *d_arena, int lev
   for (int lvl = level_hi; lvl >= level_lo; lvl--) { // mmat.rg:1227
     const level_dev &l = d->lv[lvl];
     for (const chol_phase &ph : l.phase) {
-      scoped_timer t(d, st, ph.kind, ph.n > 0);
+      scoped_timer t(d, st, ph.kind == 3 ? 2 : ph.kind, ph.n > 0);
       if (ph.kind == 0) HIPCHK((hipError_t)chol_launch_potrf(d_arena, d->ws, l.potrf + ph.first, ph.n, d->info, st));
       else if (ph.kind == 1) HIPCHK((hipError_t)chol_launch_trsm(d_arena, d->ws, l.trsm + ph.first, ph.n, st));
-      else HIPCHK((hipError_t)chol_launch_update(d_arena, l.task + ph.first, l.src, ph.n, st));
+      else if (ph.kind == 2) HIPCHK((hipError_t)chol_launch_update(d_arena, l.task + ph.first, l.src, ph.n, st));
+      else HIPCHK((hipError_t)chol_launch_update_mt(d_arena, l.task_mt + ph.first, l.src, ph.n, st));
     }
   }
   return 0;

@@ -14,6 +14,7 @@ int chol_launch_trsm_big(double *base, const double *ws, const chol_trsm_desc *d
 int chol_launch_dinv(const double *L, int n, int ldl, double *W, hipStream_t st);
 int chol_launch_trsm(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st);
 int chol_launch_update(double *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st);
+int chol_launch_update_mt(double *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st);
 int chol_launch_permute(const double *in, const int *perm, double *out, int n, int inverse, hipStream_t st);
 int chol_launch_trsv_fwd(const double *base, const chol_trsv_desc *descs, int n, double *y, hipStream_t st);
 int chol_launch_gemv_fwd(const double *base, const chol_gemv_desc *descs, const int *grp_start, const int *grp_rows, int ngroups, double *y, hipStream_t st);

@@ -20,6 +20,12 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// workgroup barrier that orders LDS traffic only (global loads / stores stay in flight across it)
+__device__ __forceinline__ void lds_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // acc(r, c) += sum_{k < K} X[r + k ldx] * Y[c + k ldy],  r < mv, c < nv (rows beyond are read as 0)
@@ -115,6 +121,86 @@ __global__ __launch_bounds__(256) void k_update(double *__restrict__ base, const
       if (r < t.mv && c < t.nv && (!t.lower || r >= c)) C[(int64_t)c * t.ldc] -= v;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// UPDATE, macro-tile form for targets larger than one MFMA tile: one workgroup per 64x64 block of a
+// target C tile.  The source panels are staged through LDS in 16-deep K chunks ([k][row] images, so
+// the MFMA operand reads are 512 contiguous bytes per k-step and conflict free), double buffered
+// with the next chunk's global loads in flight during the MFMAs; the four waves own the 2x2 grid of
+// 32x32 quadrants (4 accumulators each), so every staged operand feeds two MFMAs: 8x the arithmetic
+// intensity of k_update.  Same task / source lists, same program-order accumulation.
+// ------------------------------------------------------------------------------------------------
+#define MT 64
+#define MKB 16
+__global__ __launch_bounds__(256) void k_update_mt(double *__restrict__ base, const chol_upd_task *__restrict__ tasks,
+                                                   const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd)
+{
+  __shared__ double sA[2][MKB][MT];
+  __shared__ double sB[2][MKB][MT];
+  const int tt = threadIdx.x, lane = tt & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tt >> 6);
+  const int tid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per_xcd || tid >= ntask) return;
+  const chol_upd_task t = tasks[tid];
+  const int r15 = lane & 15, g = lane >> 4;
+  const int wr = wave & 1, wc = wave >> 1;
+  const int srow = tt & 63, skq = tt >> 6; // staging: this thread moves row `srow`, k = skq, skq+4, skq+8, skq+12
+  const bool sva = srow < t.mv, svb = srow < t.nv;
+  d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (d4){ 0.0, 0.0, 0.0, 0.0 };
+  int buf = 0;
+  for (int s = t.src_begin; s < t.src_end; ++s) {
+    const chol_upd_src sd = srcs[s];
+    const double *A = base + sd.a_off + t.ar + srow;
+    const double *Bp = base + sd.b_off + t.br + srow;
+    const int K = sd.k;
+    double ra[4], rb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { // first chunk of this source
+      const int k = skq + 4 * i;
+      ra[i] = (sva && k < K) ? A[(int64_t)k * sd.lda] : 0.0;
+      rb[i] = (svb && k < K) ? Bp[(int64_t)k * sd.ldb] : 0.0;
+    }
+    for (int k0 = 0; k0 < K; k0 += MKB) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { sA[buf][skq + 4 * i][srow] = ra[i]; sB[buf][skq + 4 * i][srow] = rb[i]; }
+      if (k0 + MKB < K) { // next chunk's loads fly during this chunk's MFMAs
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int k = k0 + MKB + skq + 4 * i;
+          ra[i] = (sva && k < K) ? A[(int64_t)k * sd.lda] : 0.0;
+          rb[i] = (svb && k < K) ? Bp[(int64_t)k * sd.ldb] : 0.0;
+        }
+      }
+      lds_barrier(); // chunk visible; the other buffer is free again (everyone is past its reads)
+#pragma unroll
+      for (int kk = 0; kk < MKB / 4; ++kk) {
+        const double x0 = sA[buf][4 * kk + g][32 * wr + r15], x1 = sA[buf][4 * kk + g][32 * wr + 16 + r15];
+        const double y0 = sB[buf][4 * kk + g][32 * wc + r15], y1 = sB[buf][4 * kk + g][32 * wc + 16 + r15];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, x0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, x0, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, x1, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, x1, acc[1][1], 0, 0, 0);
+      }
+      buf ^= 1;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = 32 * wr + 16 * i + r15;
+      double *C = base + t.c_off + r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 32 * wc + 16 * j + g + 4 * q;
+        if (r < t.mv && c < t.nv && (!t.lower || r >= c)) C[(int64_t)c * t.ldc] -= acc[i][j][q];
+      }
+    }
 }
 
 // ================================================================================================
@@ -366,12 +452,6 @@ __device__ __forceinline__ void lds_inc(int *cnt, int lane)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// workgroup barrier that orders LDS traffic only (global loads / stores stay in flight across it)
-__device__ __forceinline__ void lds_barrier()
-{
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ base, double *__restrict__ ws,
                                                          const chol_potrf_desc *__restrict__ descs, int *__restrict__ info)
 {
@@ -1082,6 +1162,13 @@ int chol_launch_update(double *base, const chol_upd_task *tasks, const chol_upd_
   if (ntask <= 0) return 0;
   const int per_xcd = (ntask + 7) / 8;
   hipLaunchKernelGGL(k_update, dim3(per_xcd * 8), dim3(256), 0, st, base, tasks, srcs, ntask, per_xcd);
+  return (int)hipGetLastError();
+}
+int chol_launch_update_mt(double *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st)
+{
+  if (ntask <= 0) return 0;
+  const int per_xcd = (ntask + 7) / 8;
+  hipLaunchKernelGGL(k_update_mt, dim3(per_xcd * 8), dim3(256), 0, st, base, tasks, srcs, ntask, per_xcd);
   return (int)hipGetLastError();
 }
 int chol_launch_permute(const double *in, const int *perm, double *out, int n, int inverse, hipStream_t st)

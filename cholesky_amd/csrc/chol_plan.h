@@ -71,7 +71,7 @@ typedef struct {
 } chol_upd_task;
 
 /* one batched launch: descriptors [first, first + n) of the level's array of that kind */
-typedef struct { int kind /* 0 potrf, 1 trsm, 2 update */, first, n; } chol_phase;
+typedef struct { int kind /* 0 potrf, 1 trsm, 2 update (16x16 tasks), 3 update (64x64 macro-tile tasks) */, first, n; } chol_phase;
 
 #define CHOL_BIG_NB 256 /* column-block width of the blocked factorisation of pivots > CHOL_RR_MAXN */
 
@@ -80,7 +80,8 @@ typedef struct {
   int n_phase; chol_phase *phase;          /* launches of this level, in order */
   int n_potrf; chol_potrf_desc *potrf;
   int n_trsm; chol_trsm_desc *trsm;
-  int n_task; chol_upd_task *task;
+  int n_task; chol_upd_task *task;         /* 16x16 sub-tile tasks (k_update) */
+  int n_task_mt; chol_upd_task *task_mt;   /* 64x64 macro-tile tasks (k_update_mt): targets larger than 16x16 */
   int n_src; chol_upd_src *src;            /* task.src_begin/src_end index this array */
 } chol_level_work;
 

@@ -66,7 +66,12 @@ static void index_snapshot(const plan_t *p, int lbl, int64_t *first, int *count)
 }
 
 /* growable arrays of the level work */
-typedef struct { chol_level_work *w; int cap_p, cap_t, cap_k, cap_s, cap_ph; } builder;
+typedef struct { int64_t c_off; int ldc, m, n, syrk, src_begin, src_end; } upd_target;
+typedef struct { chol_level_work *w; int cap_p, cap_t, cap_k, cap_km, cap_s, cap_ph; upd_target *pend; int n_pend, cap_pend; } builder;
+/* a phase whose 16x16 sub-tile count reaches this goes to 64x64 macro tiles for its larger targets:
+ * below it the 16x16 split-K workgroups are what fills the 256 CUs, above it their 4x operand
+ * re-reads are what costs */
+#define CHOL_MT_MIN_TILES 8192
 
 static void push_phase(builder *B, int kind, int first, int n)
 {
@@ -100,25 +105,55 @@ static int push_src(builder *B, chol_upd_src sd)
   w->src[w->n_src] = sd;
   return w->n_src++;
 }
-/* 16x16 sub-tile tasks of one m x n target whose sources are [src_begin, src_end) */
-static void push_tasks(builder *B, int64_t c_off, int ldc, int m, int n, int syrk, int src_begin, int src_end)
+/* tasks of one m x n target whose sources are [src_begin, src_end): 16x16 sub-tiles for small targets
+ * (k_update: the four waves split K), 64x64 macro tiles otherwise (k_update_mt: LDS-staged panels) */
+static void emit_tasks(builder *B, int macro, int64_t c_off, int ldc, int m, int n, int syrk, int src_begin, int src_end)
 {
   chol_level_work *w = B->w;
-  const int tr = (m + 15) / 16, tc = (n + 15) / 16;
+  const int ts = macro ? 64 : 16;
+  const int tr = (m + ts - 1) / ts, tc = (n + ts - 1) / ts;
   for (int a = 0; a < tr; a++)
     for (int b = 0; b < tc; b++) {
       if (syrk && b > a) continue;
-      if (w->n_task == B->cap_k) { B->cap_k = B->cap_k ? 2 * B->cap_k : 256; w->task = realloc(w->task, B->cap_k * sizeof(chol_upd_task)); }
-      chol_upd_task *t = &w->task[w->n_task++];
+      chol_upd_task *t;
+      if (macro) {
+        if (w->n_task_mt == B->cap_km) { B->cap_km = B->cap_km ? 2 * B->cap_km : 256; w->task_mt = realloc(w->task_mt, B->cap_km * sizeof(chol_upd_task)); }
+        t = &w->task_mt[w->n_task_mt++];
+      } else {
+        if (w->n_task == B->cap_k) { B->cap_k = B->cap_k ? 2 * B->cap_k : 256; w->task = realloc(w->task, B->cap_k * sizeof(chol_upd_task)); }
+        t = &w->task[w->n_task++];
+      }
       memset(t, 0, sizeof *t);
-      t->c_off = c_off + a * 16 + (int64_t)b * 16 * ldc;
+      t->c_off = c_off + a * ts + (int64_t)b * ts * ldc;
       t->ldc = ldc;
-      t->mv = (short)(m - a * 16 < 16 ? m - a * 16 : 16);
-      t->nv = (short)(n - b * 16 < 16 ? n - b * 16 : 16);
+      t->mv = (short)(m - a * ts < ts ? m - a * ts : ts);
+      t->nv = (short)(n - b * ts < ts ? n - b * ts : ts);
       t->lower = (syrk && a == b);
       t->src_begin = src_begin; t->src_end = src_end;
-      t->ar = a * 16; t->br = b * 16;
+      t->ar = a * ts; t->br = b * ts;
     }
+}
+
+/* targets of the current update phase; flush_targets() chooses the tile shape once the phase is complete */
+static void push_tasks(builder *B, int64_t c_off, int ldc, int m, int n, int syrk, int src_begin, int src_end)
+{
+  if (B->n_pend == B->cap_pend) { B->cap_pend = B->cap_pend ? 2 * B->cap_pend : 256; B->pend = realloc(B->pend, B->cap_pend * sizeof(upd_target)); }
+  upd_target t = { c_off, ldc, m, n, syrk, src_begin, src_end };
+  B->pend[B->n_pend++] = t;
+}
+static void flush_targets(builder *B)
+{
+  int64_t fine = 0;
+  for (int i = 0; i < B->n_pend; i++) {
+    const int64_t tr = (B->pend[i].m + 15) / 16, tc = (B->pend[i].n + 15) / 16;
+    fine += B->pend[i].syrk ? tr * (tr + 1) / 2 : tr * tc;
+  }
+  const int big = fine >= CHOL_MT_MIN_TILES;
+  for (int i = 0; i < B->n_pend; i++) {
+    const upd_target *t = &B->pend[i];
+    emit_tasks(B, big && (t->m > 16 || t->n > 16), t->c_off, t->ldc, t->m, t->n, t->syrk, t->src_begin, t->src_end);
+  }
+  B->n_pend = 0;
 }
 
 /* filled row runs of the ancestor blocks of panel(s): (arena offset of the run's first row in column 0
@@ -177,7 +212,7 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
    * POTRF of the diagonal block, TRSM of every row below it (rows of the pivot and filled ancestor rows
    * alike), rank-nb update of the remaining columns of those rows */
   for (int st = 0; st < steps; st++) {
-    const int p0 = w->n_potrf, t0 = w->n_trsm, k0 = w->n_task;
+    const int p0 = w->n_potrf, t0 = w->n_trsm, k0 = w->n_task, km0 = w->n_task_mt;
     for (int q = 0; q < nh; q++) {
       const int h = hs[q], s = p->tree[h], n = p->sep_size[s], ld = p->panel_ld[s];
       const int big = n > CHOL_RR_MAXN;
@@ -209,7 +244,9 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
     }
     push_phase(B, 0, p0, w->n_potrf - p0);
     push_phase(B, 1, t0, w->n_trsm - t0);
+    flush_targets(B);
     push_phase(B, 2, k0, w->n_task - k0);
+    push_phase(B, 3, km0, w->n_task_mt - km0);
   }
   /* extend-add of the level: tuples in program order (par bottom-up, gp from par to the root, tiles i, j),
    * grouped by target tile */
@@ -249,7 +286,7 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
   }
   qsort(tu, ntu, sizeof(upd_tuple), cmp_tuple);
   {
-    const int k0 = w->n_task;
+    const int k0 = w->n_task, km0 = w->n_task_mt;
     for (int i = 0; i < ntu;) {
       int e = i + 1;
       while (e < ntu && tu[e].key == tu[i].key) e++;
@@ -261,15 +298,17 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
       push_tasks(B, tu[i].c_off, tu[i].ldc, tu[i].m, tu[i].n, tu[i].syrk, sb, w->n_src);
       i = e;
     }
+    flush_targets(B);
     push_phase(B, 2, k0, w->n_task - k0);
+    push_phase(B, 3, km0, w->n_task_mt - km0);
   }
-  free(tu); free(first); free(count); free(hs);
+  free(tu); free(first); free(count); free(hs); free(B->pend); B->pend = NULL; B->cap_pend = 0;
   return 0;
 }
 
 void chol_level_work_free(chol_level_work *w)
 {
-  free(w->potrf); free(w->trsm); free(w->task); free(w->src); free(w->phase);
+  free(w->potrf); free(w->trsm); free(w->task); free(w->task_mt); free(w->src); free(w->phase);
   memset(w, 0, sizeof *w);
 }
 
@@ -353,7 +392,7 @@ int cholamd_plan_level_work_counts(const cholamd_plan *p, int level, int rank, i
   chol_level_work w;
   int rc = chol_build_level_work(p, level, rank, world, &w);
   if (rc) return rc;
-  out[0] = w.n_potrf; out[1] = w.n_trsm; out[2] = w.n_task; out[3] = w.n_src;
+  out[0] = w.n_potrf; out[1] = w.n_trsm; out[2] = w.n_task + w.n_task_mt; out[3] = w.n_src;
   chol_level_work_free(&w);
   return 0;
 }
