@@ -233,11 +233,18 @@ __global__ __launch_bounds__(256) void k_update_mt(double *__restrict__ base, co
 __device__ unsigned long long g_stamps[16];
 #define STAMP_DECL unsigned long long st_[8], acc_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
 #define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_[i]) :: "memory"); __builtin_amdgcn_sched_barrier(0); if ((i) > 0) acc_[i] += st_[i] - st_[(i) - 1]; } while (0)
+__device__ unsigned long long g_trace[12][20][8]; // [wave][step][stamp]: absolute times, k_potrf_rr only
+#define STAMPK(i) do { STAMP(i); if (lane == 0 && k < 20) g_trace[wave][k][i] = st_[i]; } while (0)
 #define STAMP_FLUSH do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) g_stamps[i_] = acc_[i_]; } while (0)
 #define STAMP_FLUSH2 do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) g_stamps[8 + i_] = acc_[i_]; } while (0)
+#ifndef STAMP_WAVE
+#define STAMP_WAVE 0
+#endif
 #else
+#define STAMP_WAVE 0
 #define STAMP_DECL
 #define STAMP(i)
+#define STAMPK(i)
 #define STAMP_FLUSH
 #define STAMP_FLUSH2
 #endif
@@ -337,8 +344,10 @@ __device__ __forceinline__ d4 tile_solve(d4 t, const double (&Lr)[3], double yd)
 __device__ __forceinline__ void store_linv16(double *Wb, const double (&Lr)[3], double yd, int r15, int g)
 {
   d4 id;
+  int rr = r15;
+  asm volatile("" : "+v"(rr)); // built where it is used: a hoisted identity tile costs 8 registers in the callers' loops
 #pragma unroll
-  for (int q = 0; q < 4; ++q) id[q] = (r15 == g + 4 * q) ? 1.0 : 0.0;
+  for (int q = 0; q < 4; ++q) id[q] = (rr == g + 4 * q) ? 1.0 : 0.0;
   const d4 xi = tile_solve(id, Lr, yd); // xi(r, c) = Linv(c, r)
 #pragma unroll
   for (int q = 0; q < 4; ++q) Wb[r15 * TS + g + 4 * q] = xi[q];
@@ -357,11 +366,16 @@ __device__ __forceinline__ d4 solve16(d4 t, const double (&w)[4])
 __device__ __forceinline__ void own_block_row(const double (&a)[TS], int r15, double (&blk)[4])
 {
   const int b = r15 >> 2;
+  // every stage is laundered through an empty asm statement: otherwise the select chain is turned into a
+  // dynamically indexed load of a[], which puts the whole row array (and its stores in chol16_rows) in scratch
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     double v = a[k];
+    asm volatile("" : "+v"(v));
     v = (b == 1) ? a[4 + k] : v;
+    asm volatile("" : "+v"(v));
     v = (b == 2) ? a[8 + k] : v;
+    asm volatile("" : "+v"(v));
     v = (b == 3) ? a[12 + k] : v;
     blk[k] = v;
   }
@@ -387,6 +401,37 @@ __device__ __forceinline__ void rr_owner(int idx, int &w, int &slot)
 }
 // position of a tile wave among the heavy ones (-1 for the two light waves)
 __device__ __forceinline__ int rr_heavy_index(int w) { return (w & 3) == 3 ? -1 : w - (w >> 2); }
+// number of indices in [0, cnt) that rr_owner() gives to tile wave w (hw = rr_heavy_index(w)): the wave's
+// slots [0, rr_count) hold exactly those tiles
+__device__ __forceinline__ int rr_count(int cnt, int w, int hw)
+{
+  const int cyc = cnt / 51, rem = cnt % 51;
+  if (hw >= 0) return cyc * 5 + (rem > hw) + (rem > 11 + hw) + (rem > 20 + hw) + (rem > 31 + hw) + (rem > 40 + hw);
+  const int o = w == 3 ? 9 : 10;
+  return cyc * 3 + (rem > o) + (rem > 20 + o) + (rem > 40 + o);
+}
+// two independent tile_solve chains interleaved: the 7 operand-dependent MFMAs of one hide in the latency of
+// the other.  Each solved register goes to LDS (l0/l1, accumulator layout, + 64 per register) and to global
+// memory (g0/g1, + 4 columns per register; nullptr = row past n) as soon as it exists, so it is not kept live.
+__device__ __forceinline__ void tile_solve2(d4 u0, d4 u1, const double (&Lr)[3], double yd, double *l0, double *l1,
+                                            double *g0, double *g1, int64_t lda4)
+{
+  const d4 z = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const d4 s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(yd, u0[b], z, 0, 0, 0);
+    const d4 s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(yd, u1[b], z, 0, 0, 0);
+    const double x0 = s0[b], x1 = s1[b];
+    if (b < 3) {
+      u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Lr[b], -x0, u0, 0, 0, 0);
+      u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Lr[b], -x1, u1, 0, 0, 0);
+    }
+    l0[b * 64] = x0;
+    l1[b * 64] = x1;
+    if (g0) g0[b * lda4] = x0;
+    if (g1) g1[b * lda4] = x1;
+  }
+}
 
 // tile index -> (i, j) of the column-major enumeration of the lower triangle of a T x T tile grid
 __device__ __forceinline__ void tile_of_index(int idx, int T, int &ti, int &tj)
@@ -424,7 +469,8 @@ __device__ __forceinline__ void tile_of_index(int idx, int T, int &ti, int &tj)
 // then acquired; no s_barrier inside the loop (the factor wave would have to take part in it).
 // ------------------------------------------------------------------------------------------------
 #define RR_NW 11     /* tile waves */
-#define RR_SLOTS 15  /* most tiles a tile wave holds (see rr_owner) */
+#define RR_SLOTS 12  /* most tiles a tile wave owns: columns >= 2 of a 17 x 17 tile grid, 120 tiles (see rr_owner) */
+#define RR_RSLOTS 11 /* ... of which live in registers; slot 11 (n > 256 only, columns 2-3: dead after step 2) lives in LDS */
 #define RR_THREADS ((RR_NW + 1) * 64)
 // Note (measured): waves of a workgroup are dealt to the four SIMDs round-robin, so waves 0, 4 and 8
 // share a SIMD, and fp64 MFMA runs on the same DP units as fp64 VALU: the tile waves' 64-cycle MFMAs
@@ -452,20 +498,40 @@ __device__ __forceinline__ void lds_inc(int *cnt, int lane)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// tile (ti, tj) of the lower triangle of the n x n matrix A in accumulator layout; the last partial diagonal
+// tile is padded with the identity, everything else past n and above the diagonal with zeros
+__device__ __forceinline__ d4 load_tile(const double *A, int lda, int n, int ti, int tj, int r15, int g)
+{
+  const int row = ti * TS + r15;
+  const bool rowok = row < n;
+  const double *src = A + row + (int64_t)(tj * TS + g) * lda;
+  d4 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = g + 4 * q, col = tj * TS + c;
+    double e = (row == col) ? 1.0 : 0.0;
+    if (rowok && col < n) e = (ti > tj || c <= r15) ? src[(int64_t)(4 * q) * lda] : 0.0;
+    v[q] = e;
+  }
+  return v;
+}
 __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ base, double *__restrict__ ws,
                                                          const chol_potrf_desc *__restrict__ descs, int *__restrict__ info)
 {
   // tiles in LDS are stored like accumulator registers: element (r, c) at c * 16 + r, so lane (r15, g)
   // register q sits at q * 64 + lp with lp = g * 16 + r15 (conflict free, and directly an MFMA operand)
-  __shared__ double sRaw[RR_MAXT][TS * TS]; // raw (fully updated, unsolved) tiles of the next panel column
-  __shared__ double sSol[RR_MAXT][TS * TS]; // solved panel P of the current step
-  __shared__ double sDg[2][TS * TS];        // diagonal tiles on their way to the factor wave (parity of j)
-  __shared__ double sL[2][TS][TS + 1];      // L(k,k), [r][c], parity of k
-  __shared__ double sYd[2][4][TS];          // Ydiag(k), [k][c], parity of k
-  __shared__ double sConv[TS][TS + 1];      // factor wave: accumulator layout -> row per lane
+  __shared__ double sRaw[RR_MAXT][TS * TS];    // raw (fully updated, unsolved) tiles of the next panel column
+  __shared__ double sSol[2][RR_MAXT][TS * TS]; // solved panel P of step k (parity of k)
+  __shared__ double sDg[2][TS * TS];           // diagonal tiles on their way to the factor wave (parity of j)
+  __shared__ double sLW[2][2 * TS][TS + 1];    // parity of k: rows 0-15 = L(k,k) [r][c], rows 16-31 = L(k,k)^-T [k][c] = Linv(c,k)
+  __shared__ double sConv[2 * TS][TS + 1];     // factor wave: accumulator layout -> row per lane; rows 16-31 = identity
+  __shared__ double sOv[RR_NHEAVY][TS * TS];   // slot RR_RSLOTS of the heavy waves
   __shared__ unsigned short sIJ[RR_SLOTS * RR_NW + 16];
-  __shared__ int sFlag[4];                  // fL, fP, cSol, cUpd
+  __shared__ int sFlag[8];                     // fL, fP, cSol, cUpd, cRaw, fA, fD
   int *const fL = &sFlag[0], *const fP = &sFlag[1], *const cSol = &sFlag[2], *const cUpd = &sFlag[3];
+  int *const cRaw = &sFlag[4]; // raw tiles parked in sRaw so far (column j contributes T - 1 - j)
+  int *const fA = &sFlag[5];   // j: raw tile (j, j-1) is in sRaw[j]
+  int *const fD = &sFlag[6];   // j: diagonal tile (j, j), updated through step j-2, is in sDg[j & 1]
 
   const chol_potrf_desc d = descs[blockIdx.x];
   double *A = base + d.a_off;
@@ -479,12 +545,19 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
   const int lp0 = g * TS + r15;
 
   for (int t = threadIdx.x; t < RR_SLOTS * RR_NW; t += RR_THREADS) sIJ[t] = (unsigned short)0xffff;
-  if (threadIdx.x < 4) sFlag[threadIdx.x] = 0;
+  if (threadIdx.x < 8) sFlag[threadIdx.x] = (threadIdx.x == 5 || threadIdx.x == 6) ? 1 : 0; // (1,0) and (1,1) are parked by the prologue
+  if (threadIdx.x < TS * TS) sConv[TS + (threadIdx.x >> 4)][threadIdx.x & 15] = (threadIdx.x >> 4) == (threadIdx.x & 15) ? 1.0 : 0.0;
   __syncthreads();
-  for (int t = threadIdx.x; t < ntl; t += RR_THREADS) {
+  // Columns 0 and 1 never live in registers (column 0 receives no update, column 1 exactly one): the
+  // prologue parks them in LDS.  The tiles of columns >= 2 are dealt in REVERSE column-major order (last
+  // column first), so at step k a wave's live tiles (column > k) are its slots [0, rr_count), evenly spread
+  // over the waves, and walking the slots downwards visits column k+1 -- next step's panel, the look-ahead
+  // tiles first -- before the rest
+  const int ntl2 = (T - 2) * (T - 1) / 2; // tiles of columns >= 2 (0 for T <= 2)
+  for (int t = threadIdx.x + 2 * T - 1; t < ntl; t += RR_THREADS) {
     int ti, tj, ow, os;
     tile_of_index(t, T, ti, tj);
-    rr_owner(t, ow, os);
+    rr_owner(ntl - 1 - t, ow, os);
     sIJ[os * RR_NW + ow] = (unsigned short)(ti | (tj << 8));
   }
   __syncthreads();
@@ -492,54 +565,53 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
   if (wave == 0) {
     // ================================================================== factor wave
     __builtin_amdgcn_s_setprio(3);
-    lds_wait_ge(cUpd, RR_NW); // prologue of the tile waves done: (0,0) and (1,1) are in sDg
+    lds_wait_ge(cUpd, RR_NW); // prologue of the tile waves done: (0,0), (1,1) are in sDg, column 0 in sRaw
     d4 dk; // diagonal tile of the current step, accumulator layout
 #pragma unroll
     for (int q = 0; q < 4; ++q) dk[q] = sDg[0][q * 64 + lp0];
     STAMP_DECL;
     for (int k = 0; k < T; ++k) {
-      STAMP(0);
-      // ---- a. factor (k,k)
-      double a[TS], blk[4], x[4], myinv;
+      STAMPK(0);
+      // ---- a. factor (k,k), one row per lane.  Lanes 16-31 carry the rows of the identity through the same
+      //         column operations: they come out as the rows of L(k,k)^-T -- the explicit inverse every panel
+      //         solve of this step (and the TRSM kernels later) multiplies with -- at no extra instruction
+      double a[TS], unused;
 #pragma unroll
       for (int q = 0; q < 4; ++q) sConv[r15][g + 4 * q] = dk[q];
 #pragma unroll
-      for (int c = 0; c < TS; ++c) a[c] = sConv[r15][c];
-      STAMP(1);
-      const int bad = chol16_rows(a, myinv, r15);
-      STAMP(2);
+      for (int c = 0; c < TS; ++c) a[c] = sConv[lane & 31][c];
+      STAMPK(1);
+      const int bad = chol16_rows(a, unused, r15);
+      STAMPK(2);
       if (bad && k * TS + bad <= n && lane == 0) {
         if (atomicCAS(&info[0], 0, d.col0 + k * TS + bad) == 0) info[1] = d.sep;
       }
-      own_block_row(a, r15, blk);
-      linv4_quad(blk, myinv, x, r15 & 3);
       const int par = k & 1;
-      if (lane < TS) {
-        const int b4 = lane & ~3, qi = lane & 3;
+      // sLW / sSol of this parity were last read in step k-2: every tile wave has left it
+      lds_wait_ge(cUpd, RR_NW * k);
+      if (lane < 2 * TS) {
 #pragma unroll
-        for (int c = 0; c < TS; ++c) sL[par][lane][c] = a[c]; // entries above the diagonal are finite junk nobody uses
-#pragma unroll
-        for (int m = 0; m < 4; ++m) sYd[par][qi][b4 + m] = x[m]; // Ydiag(c = 4b+m, k = qi) = Linv_bb(m, qi)
+        for (int c = 0; c < TS; ++c) sLW[par][lane][c] = a[c]; // L: entries above the diagonal are finite junk nobody uses
       }
       lds_set(fL, k + 1, lane);
-      STAMP(3);
+      STAMPK(3);
       if (k + 1 >= T) break;
-      // ---- b. everything the tile waves owed from step k-1 is in LDS
-      lds_wait_ge(cUpd, RR_NW * (k + 1));
-      STAMP(4);
+      // ---- b. the two look-ahead tiles of step k-1's trailing update are in LDS (their owners do them first)
+      lds_wait_ge(fA, k + 1);
+      lds_wait_ge(fD, k + 1);
+      STAMPK(4);
       // ---- c. solve (k+1, k) and publish it
-      double Lr[3];
+      double wv[4];
 #pragma unroll
-      for (int b = 0; b < 3; ++b) Lr[b] = sL[par][r15][g + 4 * b];
-      const double yd = sYd[par][g][r15];
+      for (int st = 0; st < 4; ++st) wv[st] = sLW[par][TS + 4 * st + g][r15];
       d4 raw, dn;
 #pragma unroll
       for (int q = 0; q < 4; ++q) { raw[q] = sRaw[k + 1][q * 64 + lp0]; dn[q] = sDg[(k + 1) & 1][q * 64 + lp0]; }
-      const d4 p = tile_solve(raw, Lr, yd);
+      const d4 p = solve16(raw, wv);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) sSol[k + 1][q * 64 + lp0] = p[q];
+      for (int q = 0; q < 4; ++q) sSol[par][k + 1][q * 64 + lp0] = p[q];
       lds_set(fP, k + 1, lane);
-      STAMP(5);
+      STAMPK(5);
       // ---- d. (k+1,k+1) -= P P^T: both operands are the accumulator registers of P
 #pragma unroll
       for (int st = 0; st < 4; ++st) dn = __builtin_amdgcn_mfma_f64_16x16x4f64(p[st], -p[st], dn, 0, 0, 0);
@@ -552,131 +624,174 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
           for (int q = 0; q < 4; ++q) dst[(int64_t)(4 * q) * lda] = p[q];
         }
       }
-      STAMP(6);
+      STAMPK(6);
     }
     STAMP_FLUSH;
   } else {
     // ================================================================== tile waves
-    d4 tile[RR_SLOTS];
+    d4 tile[RR_RSLOTS];
     const int w = wave - 1;
+    const int hw = rr_heavy_index(w);
     int ijp[RR_SLOTS]; // packed (i | j << 8) per slot, wave uniform
 #pragma unroll
     for (int s = 0; s < RR_SLOTS; ++s) ijp[s] = __builtin_amdgcn_readfirstlane((int)sIJ[s * RR_NW + w]);
-    // ---- prologue: load the owned tiles; park column 0 and the first two diagonal tiles
+    // ---- prologue: columns 0 and 1 go straight to LDS -- (0,0), (1,1) -> sDg, (i,0) -> sRaw[i],
+    //      (i,1), i >= 2 -> sSol[1][i] (free until the panel solve of step 1) -- then the register tiles
+    for (int u = w; u < 2 * T - 1; u += RR_NW) {
+      const int tj = u < T ? 0 : 1, ti = u < T ? u : u - T + 1;
+      const d4 v = load_tile(A, lda, n, ti, tj, r15, g);
+      double *park = ti == tj ? &sDg[ti][0] : tj == 0 ? &sRaw[ti][0] : &sSol[1][ti][0];
 #pragma unroll
-    for (int s = 0; s < RR_SLOTS; ++s) {
+      for (int q = 0; q < 4; ++q) park[q * 64 + lp0] = v[q];
+      if (tj == 0 && ti > 0) lds_inc(cRaw, lane);
+    }
+#pragma unroll
+    for (int s = 0; s < RR_RSLOTS; ++s) {
       d4 v = { 0.0, 0.0, 0.0, 0.0 };
-      if (ijp[s] != 0xffff) {
-        const int ti = ijp[s] & 0xff, tj = ijp[s] >> 8;
-        const int row = ti * TS + r15;
-        const bool rowok = row < n;
-        const double *src = A + row + (int64_t)(tj * TS + g) * lda;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c = g + 4 * q, col = tj * TS + c;
-          double e = (row == col) ? 1.0 : 0.0; // identity padding of the last partial diagonal tile
-          if (rowok && col < n) e = (ti > tj || c <= r15) ? src[(int64_t)(4 * q) * lda] : 0.0;
-          v[q] = e;
-        }
-        double *park = nullptr;
-        if (ti == tj && ti < 2) park = &sDg[ti][0];
-        else if (tj == 0) park = &sRaw[ti][0];
-        if (park) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) park[q * 64 + lp0] = v[q];
-        }
-      }
+      if (ijp[s] != 0xffff) v = load_tile(A, lda, n, ijp[s] & 0xff, ijp[s] >> 8, r15, g);
       tile[s] = v;
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ijp[RR_RSLOTS] != 0xffff) { // heavy waves only (rr_owner)
+      const d4 v = load_tile(A, lda, n, ijp[RR_RSLOTS] & 0xff, ijp[RR_RSLOTS] >> 8, r15, g);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sOv[hw][q * 64 + lp0] = v[q];
     }
     lds_inc(cUpd, lane);
     STAMP_DECL;
     for (int k = 0; k < T; ++k) {
-      STAMP(0);
+      STAMPK(0);
       int lp = lp0; // opaque once per step: keeps per-slot LDS addresses from being hoisted and spilled
       asm volatile("" : "+v"(lp));
+      int k2 = k + 2; // opaque: otherwise "ti == k + 2" makes the flag value a per-slot constant, hoisted and spilled
+      asm volatile("" : "+s"(k2));
       const int par = k & 1;
       // ---- 1. panel solve out of LDS (needs L(k,k) and every raw tile of column k)
       lds_wait_ge(fL, k + 1);
-      STAMP(1);
-      lds_wait_ge(cUpd, RR_NW * (k + 1));
-      STAMP(2);
-      {
-        double Lr[3];
+      STAMPK(1);
+      lds_wait_ge(cRaw, (k + 1) * (T - 1) - k * (k + 1) / 2);
+      STAMPK(2);
+      if (hw >= 0) {
+        // panel tile i goes to heavy wave i mod 9 (at most two each: T <= 17); the light waves keep the
+        // factor wave's SIMD quiet.  X = T Linv^T: four accumulating MFMAs per tile, two tiles interleaved
+        const int i0 = k + 2 + ((hw + RR_NHEAVY - ((k + 2) % RR_NHEAVY)) % RR_NHEAVY), i1 = i0 + RR_NHEAVY;
+        if (i0 < T) {
+          double wv[4];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) Lr[b] = sL[par][r15][g + 4 * b];
-        const double yd = sYd[par][g][r15];
-        const int hw = rr_heavy_index(w);
-        // panel tile i goes to heavy wave i mod 9; the light waves keep the factor wave's SIMD quiet
-        for (int i = hw < 0 ? T : k + 2 + ((hw + RR_NHEAVY - ((k + 2) % RR_NHEAVY)) % RR_NHEAVY); i < T; i += RR_NHEAVY) {
-          d4 raw;
+          for (int st = 0; st < 4; ++st) wv[st] = sLW[par][TS + 4 * st + g][r15];
+          const int i1c = i1 < T ? i1 : i0;
+          d4 raw0, raw1, x0 = { 0.0, 0.0, 0.0, 0.0 }, x1 = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
-          for (int q = 0; q < 4; ++q) raw[q] = sRaw[i][q * 64 + lp];
-          const d4 x = tile_solve(raw, Lr, yd);
-          const int row = i * TS + r15;
-          double *dst = A + row + (int64_t)(k * TS + g) * lda;
+          for (int q = 0; q < 4; ++q) { raw0[q] = sRaw[i0][q * 64 + lp]; raw1[q] = sRaw[i1c][q * 64 + lp]; }
+#pragma unroll
+          for (int st = 0; st < 4; ++st) {
+            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[st], raw0[st], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[st], raw1[st], x1, 0, 0, 0);
+          }
+          const int row0 = i0 * TS + r15, row1 = i1 * TS + r15;
+          double *const col = A + (int64_t)(k * TS + g) * lda;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            sSol[i][q * 64 + lp] = x[q];
-            if (row < n) dst[(int64_t)(4 * q) * lda] = x[q];
+            sSol[par][i0][q * 64 + lp] = x0[q];
+            if (row0 < n) col[row0 + (int64_t)(4 * q) * lda] = x0[q];
+          }
+          if (i1 < T) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              sSol[par][i1][q * 64 + lp] = x1[q];
+              if (row1 < n) col[row1 + (int64_t)(4 * q) * lda] = x1[q];
+            }
           }
         }
       }
       // ---- 2. the whole panel is solved
-      STAMP(3);
+      STAMPK(3);
       lds_inc(cSol, lane);
       lds_wait_ge(cSol, RR_NW * (k + 1));
-      STAMP(4);
+      STAMPK(4);
       if (k + 1 < T) lds_wait_ge(fP, k + 1);
-      STAMP(5);
-      // ---- 3. trailing update, slots from the top down, early exit at the first tile of column <= k
-      const double *const sS = &sSol[0][0];
+      STAMPK(5);
+      // ---- 3. trailing update of the live slots [0, top], walked downwards: column k+1 first
+      const double *const sS = &sSol[par][0][0];
+      if (k == 0) { // column 1 out of LDS: its only update, (2,1) -- the look-ahead tile -- first
+        for (int i = 2 + w; i < T; i += RR_NW) {
+          d4 acc;
 #pragma unroll
-      for (int s = RR_SLOTS - 1; s >= 0; --s) {
-        if (ijp[s] != 0xffff) {
-          const int ti = ijp[s] & 0xff, tj = ijp[s] >> 8;
-          if (tj <= k) break; // this and every lower slot hold finished columns
-          if (!(ti == tj && tj == k + 1)) { // (k+1,k+1) went to the factor wave one step ago
-            d4 acc = tile[s];
+          for (int q = 0; q < 4; ++q) acc[q] = sSol[1][i][q * 64 + lp];
 #pragma unroll
-            for (int st = 0; st < 4; ++st)
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sS[tj * (TS * TS) + st * 64 + lp], -sS[ti * (TS * TS) + st * 64 + lp], acc, 0, 0, 0);
-            tile[s] = acc;
-            double *park = nullptr;
-            if (tj == k + 1) park = &sRaw[ti][0];                        // last update: next panel column
-            else if (ti == tj && tj == k + 2) park = &sDg[tj & 1][0];    // diagonal tile, one step ahead
-            if (park) {
+          for (int st = 0; st < 4; ++st)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sS[1 * (TS * TS) + st * 64 + lp], -sS[i * (TS * TS) + st * 64 + lp], acc, 0, 0, 0);
 #pragma unroll
-              for (int q = 0; q < 4; ++q) park[q * 64 + lp] = acc[q];
-            }
-          }
+          for (int q = 0; q < 4; ++q) sRaw[i][q * 64 + lp] = acc[q];
+          lds_inc(cRaw, lane);
+          if (i == 2) lds_set(fA, 2, lane);
+        }
+      }
+      const int live = (T - k - 1) * (T - k) / 2;
+      const int top = rr_count(live < ntl2 ? live : ntl2, w, hw) - 1;
+      // one tile: acc -= P(ti) P(tj)^T, then park it if this was its last update; true if it was parked
+#define RR_UPDATE(acc_, ti_, tj_)                                                                                  \
+  {                                                                                                                \
+    _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                               \
+      acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(sS[(tj_) * (TS * TS) + st * 64 + lp], -sS[(ti_) * (TS * TS) + st * 64 + lp], acc_, 0, 0, 0); \
+    if ((tj_) == k + 1) { /* last update: next panel column */                                                    \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) sRaw[ti_][q * 64 + lp] = acc_[q];                              \
+      lds_inc(cRaw, lane);                                                                                         \
+      if ((ti_) == k + 2) lds_set(fA, k2, lane); /* look-ahead: the factor wave solves it itself */                \
+    } else if ((ti_) == (tj_) && (tj_) == k + 2) { /* diagonal tile, one step ahead */                            \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) sDg[(tj_) & 1][q * 64 + lp] = acc_[q];                         \
+      lds_set(fD, k2, lane);                                                                                       \
+    }                                                                                                              \
+  }
+      if (top >= RR_RSLOTS) { // the LDS-resident slot holds the wave's earliest columns: first in line
+        const int ti = ijp[RR_RSLOTS] & 0xff, tj = ijp[RR_RSLOTS] >> 8;
+        if (!(ti == tj && tj == k + 1)) {
+          d4 acc;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = sOv[hw][q * 64 + lp];
+          RR_UPDATE(acc, ti, tj);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sOv[hw][q * 64 + lp] = acc[q];
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      // ---- the light waves solve no panel tiles: one of them writes L(k,k) and Linv(k,k) back to global
-      //      memory after its (short) update chain, off every other wave's path (sL / sYd of this parity
-      //      stay valid until every tile wave has finished step k)
-      if (w == ((k & 1) ? 7 : 3)) {
-        double Lr[3];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) Lr[b] = sL[par][r15][g + 4 * b];
-        const double yd = sYd[par][g][r15];
-        const double l3 = sL[par][r15][g + 12];
+      for (int sg = (RR_RSLOTS - 1) / 4; sg >= 0; --sg) {
+        if (top >= 4 * sg) {
+#pragma unroll
+          for (int s = (4 * sg + 3 < RR_RSLOTS ? 4 * sg + 3 : RR_RSLOTS - 1); s >= 4 * sg; --s) {
+            if (s <= top) {
+              const int ti = ijp[s] & 0xff, tj = ijp[s] >> 8;
+              if (!(ti == tj && tj == k + 1)) { // (k+1,k+1) went to the factor wave one step ago
+                d4 acc = tile[s];
+                RR_UPDATE(acc, ti, tj);
+                tile[s] = acc;
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+#undef RR_UPDATE
+      // ---- the light waves solve no panel tiles: one of them copies L(k,k) and Linv(k,k) from LDS to global
+      //      memory after its (short) update chain, off every other wave's path (sLW of this parity stays
+      //      valid until every tile wave has finished step k)
+      if (w == ((k & 1) ? 7 : 3)) {
         const int row = k * TS + r15;
         double *dst = A + row + (int64_t)(k * TS + g) * lda;
-        if (row < n) {
+        double *Wb = W + (int64_t)k * TS * TS;
 #pragma unroll
-          for (int b = 0; b < 3; ++b)
-            if (g + 4 * b <= r15) dst[(int64_t)(4 * b) * lda] = Lr[b];
-          if (g + 12 <= r15) dst[(int64_t)12 * lda] = l3;
+        for (int b = 0; b < 4; ++b) {
+          const double lv = sLW[par][r15][g + 4 * b], wv = sLW[par][TS + g + 4 * b][r15];
+          if (row < n && g + 4 * b <= r15) dst[(int64_t)(4 * b) * lda] = lv;
+          Wb[(g + 4 * b) * TS + r15] = wv; // Wb[k * 16 + c] = Linv(c, k): the layout solve16() reads
         }
-        store_linv16(W + (int64_t)k * TS * TS, Lr, yd, r15, g);
       }
       // ---- 4.
-      STAMP(6);
+      STAMPK(6);
       lds_inc(cUpd, lane);
     }
-    if (w == 0) { STAMP_FLUSH2; }
+    if (w == STAMP_WAVE) { STAMP_FLUSH2; }
   }
 }
 

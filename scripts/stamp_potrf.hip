@@ -31,5 +31,17 @@ int main(int argc, char **argv)
   printf("tile wave 0:\n");
   unsigned long long tt = 0; for (int i = 1; i < 7; i++) tt += st[8 + i];
   for (int i = 1; i < 7; i++) printf("  %-22s %10.1f ticks/step %5.1f%%\n", n2[i], (double)st[8 + i] / T, 100.0 * st[8 + i] / tt);
+  if (argc > 2) { // per-step timeline: start of each step relative to the factor wave's step 0, per wave
+    static unsigned long long tr[12][20][8];
+    hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_trace), sizeof tr);
+    const unsigned long long t0 = tr[0][0][0];
+    printf("step: factor[start chol16-done fL LAwait-done fP] | tile waves: fL-seen solve-done cSol-done upd-done (w0, w3 light, w10)\n");
+    for (int k = 0; k < T && k < 20; k++) {
+      printf("%2d: F %7lld %7lld %7lld %7lld %7lld |", k, (long long)(tr[0][k][0] - t0), (long long)(tr[0][k][2] - t0), (long long)(tr[0][k][3] - t0), (long long)(tr[0][k][4] - t0), (long long)(tr[0][k][5] - t0));
+      const int ws[3] = { 1, 4, 11 };
+      for (int j = 0; j < 3; j++) { const int w = ws[j]; printf(" [%7lld %7lld %7lld %7lld]", (long long)(tr[w][k][1] - t0), (long long)(tr[w][k][3] - t0), (long long)(tr[w][k][4] - t0), (long long)(tr[w][k][6] - t0)); }
+      printf("\n");
+    }
+  }
   return 0;
 }
