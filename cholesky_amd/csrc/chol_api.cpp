@@ -256,9 +256,10 @@ extern "C" int cholamd_factor_levels(cholamd_device *d, double *d_arena, int lev
   for (int lvl = level_hi; lvl >= level_lo; lvl--) { // mmat.rg:1227
     const level_dev &l = d->lv[lvl];
     for (const chol_phase &ph : l.phase) {
-      scoped_timer t(d, st, ph.kind == 3 ? 2 : ph.kind, ph.n > 0);
+      scoped_timer t(d, st, ph.kind == 3 ? 2 : ph.kind == 4 ? 1 : ph.kind, ph.n > 0);
       if (ph.kind == 0) HIPCHK((hipError_t)chol_launch_potrf(d_arena, d->ws, l.potrf + ph.first, ph.n, d->info, st));
       else if (ph.kind == 1) HIPCHK((hipError_t)chol_launch_trsm(d_arena, d->ws, l.trsm + ph.first, ph.n, st));
+      else if (ph.kind == 4) HIPCHK((hipError_t)chol_launch_trsm_w(d_arena, d->ws, l.trsm + ph.first, ph.n, st));
       else if (ph.kind == 2) HIPCHK((hipError_t)chol_launch_update(d_arena, l.task + ph.first, l.src, ph.n, st));
       else HIPCHK((hipError_t)chol_launch_update_mt(d_arena, l.task_mt + ph.first, l.src, ph.n, st));
     }
@@ -413,7 +414,8 @@ static int run_trsm(const double *Lp, int n, int ldl, const std::vector<chol_trs
     }
   rc = sc.put(&dd, v.data(), v.size(), st);
   if (rc) return rc;
-  if (n <= CHOL_RR_MAXN) HIPCHK((hipError_t)chol_launch_trsm(nullptr, nullptr, dd, (int)v.size(), st));
+  if (n <= CHOL_TRSM_W_MAXN) HIPCHK((hipError_t)chol_launch_trsm_w(nullptr, nullptr, dd, (int)v.size(), st));
+  else if (n <= CHOL_RR_MAXN) HIPCHK((hipError_t)chol_launch_trsm(nullptr, nullptr, dd, (int)v.size(), st));
   else HIPCHK((hipError_t)chol_launch_trsm_big(nullptr, nullptr, dd, (int)v.size(), st));
   HIPCHK(hipStreamSynchronize(st));
   return 0;

@@ -1062,6 +1062,153 @@ __global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// TRSM for pivot blocks of at most CHOL_TRSM_W_MAXN columns: ONE WAVE per 16-row strip,
+// the four strips of a workgroup share one pivot block (the schedule pads every block's strips to a
+// multiple of four; descriptors with m = 0 are placeholders).
+//   * The block's L tiles and the Linv(J,J) tiles go to LDS once, by LDS-DMA (global_load_lds, 1 KiB
+//     per wave-instruction, no registers): every request of the workgroup is in flight before the
+//     first wait, so the strip pays the memory latency (the pivot was written by another workgroup,
+//     usually on another XCD: > 1 us) once instead of once per step.
+//   * The strip's column tiles stay in registers.  Step J: X_J = T_0 Linv(J,J)^T (4 MFMAs), then
+//     T_j -= X_J L(j, J)^T for j > J, X_J used as the MFMA operand straight out of its accumulator
+//     registers; one straight-line instantiation per tile count.
+//   * One wave issues an MFMA per 64 cycles at best, so the strip costs 4 T (T + 1) / 2 x 64 cycles plus the
+//     staging: faster than the four-waves-per-strip kernel up to 64 columns, slower beyond (hence the limit).
+// ------------------------------------------------------------------------------------------------
+#define TW_MAXT ((CHOL_TRSM_W_MAXN + TS - 1) / TS)
+// the solve of one strip of T tiles: tiles in registers, operands out of the staged LDS image (s0 = slot 0 + lane)
+template <int T> __device__ __forceinline__ void trsm_w_solve(d4 (&tile)[TW_MAXT], const double *s0, double *__restrict__ B, int n, int ldb,
+                                                              bool vrow, int r15, int g)
+{
+#pragma unroll
+  for (int J = 0; J < T; ++J) {
+    const double *sd = s0 + (J * T - J * (J - 1) / 2) * (TS * TS); // slot (J, J)
+    double wv[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) wv[st] = sd[st * 64];
+    const d4 x = solve16(tile[J], wv);
+    if (vrow) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = J * TS + g + 4 * q;
+        if (J + 1 < T || col < n) B[r15 + (int64_t)col * ldb] = x[q];
+      }
+    }
+    double nx[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      nx[st] = -x[st];
+      asm volatile("" : "+v"(nx[st])); // negated once per step, not once per MFMA
+    }
+#pragma unroll
+    for (int j = J + 1; j < T; ++j) {
+      d4 acc = tile[j];
+#pragma unroll
+      for (int st = 0; st < 4; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sd[(j - J) * (TS * TS) + st * 64], nx[st], acc, 0, 0, 0);
+      tile[j] = acc;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_trsm_w(double *__restrict__ base, const double *__restrict__ ws,
+                                                const chol_trsm_desc *__restrict__ descs, int ndesc)
+{
+  // slot(J2, J) = J T - J (J - 1) / 2 + (J2 - J), J2 >= J: tile L(J2, J) as the MFMA Y operand (element (c, k) at
+  // (k / 4) * 64 + (k % 4) * 16 + c, i.e. accumulator-register order); the diagonal slots hold Linv(J,J) in the
+  // layout solve16() reads (the workspace layout, copied verbatim)
+  __shared__ double sT[TW_MAXT * (TW_MAXT + 1) / 2][TS * TS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int id0 = blockIdx.x * 4;
+  const chol_trsm_desc d0 = descs[id0];
+  const double *Lm = base + d0.l_off;
+  const double *W = ws + d0.dinv_off;
+  const int n = d0.n, ldl = d0.ldl;
+  const int T = (n + TS - 1) / TS;
+  const int r15 = lane & 15, g = lane >> 4, lp = lane;
+  int64_t b_off = d0.b_off;
+  int m = 0, ldb = d0.ldb;
+  if (id0 + wave < ndesc) {
+    const chol_trsm_desc d = descs[id0 + wave];
+    b_off = d.b_off; m = d.m; ldb = d.ldb;
+  }
+  double *B = base + b_off;
+  const bool vrow = r15 < m;
+  STAMP_DECL;
+  STAMP(0);
+
+  // ---- the LDS-DMA pairs rows (r, r+1): with n odd the pair (n-1, n) is fetched from (n-2, n-1) (in bounds,
+  //      finite) and row n-1 of the last row tile is patched afterwards from this register
+  const bool needfix = (n & 1) && tid < TS * (T - 1);
+  double fix = 0.0;
+  if (needfix) fix = Lm[(n - 1) + (int64_t)tid * ldl]; // column tid = 16 J + c of row n-1
+  // ---- stage: wave w takes the half-tiles (slot, half) with slot = (w >> 1) mod 2, half = w & 1
+  {
+    const int half = wave & 1;
+    const int pi = half * 64 + lane;                            // element pair (2 pi, 2 pi + 1) of the tile image
+    const int st = pi >> 5, gg = (pi >> 3) & 3, re = (pi & 7) * 2;
+    int J = 0, J2 = wave >> 1, slot = wave >> 1;
+    while (J < T && J2 >= T) { J2 = J2 - T + J + 1; ++J; }
+    while (J < T) {
+      const double *src;
+      if (J2 == J) src = W + (int64_t)J * TS * TS + 2 * pi;
+      else {
+        const int row = J2 * TS + re;
+        src = Lm + (row + 1 < n ? row : n - 2) + (int64_t)(J * TS + 4 * st + gg) * ldl;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)&sT[slot][half * 128], 16, 0, 0);
+      J2 += 2; slot += 2;
+      while (J < T && J2 >= T) { J2 = J2 - T + J + 1; ++J; }
+    }
+  }
+  // ---- the strip's tiles (clamped, unconditional loads + select)
+  d4 tile[TW_MAXT];
+  {
+    const int rb = min(r15, max(m - 1, 0));
+#pragma unroll
+    for (int J = 0; J < TW_MAXT; ++J) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tile[J][q] = B[rb + (int64_t)min(J * TS + g + 4 * q, n - 1) * ldb];
+    }
+  }
+  STAMP(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(2);
+  __syncthreads(); // every wave's LDS-DMA has landed
+  if (needfix) {
+    const int J = tid >> 4, c = tid & 15, rr = (n - 1) & 15;
+    sT[J * T - J * (J - 1) / 2 + (T - 1 - J)][(c >> 2) * 64 + (c & 3) * TS + rr] = fix;
+  }
+  __syncthreads();
+  if (m <= 0) return;
+  // the loads above are unconditional (clamped addresses) and only now masked: a load under its predicate gets
+  // a branch and a vmcnt(0) of its own, 36 memory latencies in a row
+#pragma unroll
+  for (int J = 0; J < TW_MAXT; ++J) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double v = tile[J][q];
+      asm volatile("" : "+v"(v));
+      tile[J][q] = (vrow && J * TS + g + 4 * q < n) ? v : 0.0;
+    }
+  }
+  STAMP(3);
+
+  // ---- the solve, one straight-line instantiation per tile count (run-time guards per tile cost register
+  //      copies at every join and keep the LDS operand reads from running ahead of the MFMAs)
+  const double *const s0 = &sT[0][lp];
+  switch (T) {
+  case 1: trsm_w_solve<1>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  case 2: trsm_w_solve<2>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  case 3: trsm_w_solve<3>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  case 4: trsm_w_solve<4>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  default: break;
+  }
+  STAMP(4);
+  if (blockIdx.x == 0 && wave == 0) { STAMP_FLUSH; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // TRSM for pivots larger than CHOL_RR_MAXN: one independent wave per 16-row strip (4 strips per
 // workgroup), left-looking from global memory: T_J = B_J - X_<J L(J,<J)^T, X_J = T_J L(J,J)^-T.
 // ------------------------------------------------------------------------------------------------
@@ -1264,6 +1411,12 @@ int chol_launch_trsm(double *base, const double *ws, const chol_trsm_desc *descs
 { // strips of pivots up to CHOL_RR_MAXN
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k_trsm_rr, dim3(n), dim3(256), 0, st, base, ws, descs);
+  return (int)hipGetLastError();
+}
+int chol_launch_trsm_w(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st)
+{ // strips of pivot blocks up to CHOL_TRSM_W_MAXN columns, one wave each; every aligned group of four descriptors shares one block
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_trsm_w, dim3((n + 3) / 4), dim3(256), 0, st, base, ws, descs, n);
   return (int)hipGetLastError();
 }
 int chol_launch_trsm_big(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st)

@@ -53,6 +53,7 @@ typedef struct {
   int n, ldl, m, ldb; /* m rows (<= CHOL_TRSM_ROWS) */
 } chol_trsm_desc;
 
+#define CHOL_TRSM_W_MAXN 64 /* widest pivot block the one-wave-per-strip TRSM kernel takes (4 tiles); measured against k_trsm_rr: 6.6 vs 8.0 us at 32, 8.4 vs 9.6 at 64, 12.6 vs 11.1 at 128 */
 #define CHOL_TRSM_ROWS 16
 
 typedef struct {
@@ -71,9 +72,10 @@ typedef struct {
 } chol_upd_task;
 
 /* one batched launch: descriptors [first, first + n) of the level's array of that kind */
-typedef struct { int kind /* 0 potrf, 1 trsm, 2 update (16x16 tasks), 3 update (64x64 macro-tile tasks) */, first, n; } chol_phase;
+typedef struct { int kind /* 0 potrf, 1 trsm, 2 update (16x16 tasks), 3 update (64x64 macro-tile tasks), 4 trsm (every strip's pivot block <= CHOL_TRSM_W_MAXN wide) */, first, n; } chol_phase;
 
-#define CHOL_BIG_NB 256 /* column-block width of the blocked factorisation of pivots > CHOL_RR_MAXN */
+#define CHOL_SPLIT_MIN 144 /* pivots wider than this are factored in column blocks (chol_schedule.c); measured on lapl_3375: 258 us unsplit, 240 us at 144/144 */
+#define CHOL_SPLIT_NB 144  /* ... of at most this many columns */
 
 typedef struct {
   int level;

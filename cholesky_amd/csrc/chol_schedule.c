@@ -68,6 +68,17 @@ static void index_snapshot(const plan_t *p, int lbl, int64_t *first, int *count)
 /* growable arrays of the level work */
 typedef struct { int64_t c_off; int ldc, m, n, syrk, src_begin, src_end; } upd_target;
 typedef struct { chol_level_work *w; int cap_p, cap_t, cap_k, cap_km, cap_s, cap_ph; upd_target *pend; int n_pend, cap_pend; } builder;
+/* Blocking of a pivot at the schedule level.  The POTRF kernel takes pivots up to CHOL_RR_MAXN whole, but one
+ * workgroup's MFMA throughput bounds the early steps of a large one (the trailing update of step 0 of a
+ * 17 x 17 tile grid is 120 tile updates on one CU); a pivot wider than CHOL_SPLIT_MIN is therefore factored
+ * in equal column blocks of at most CHOL_SPLIT_NB columns (a multiple of 16), with the TRSM of the rows below
+ * and the rank-nb update of the trailing columns spread over the whole chip between the blocks. */
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
+static int split_min(void) { static int v = -1; if (v < 0) v = env_int("CHOLAMD_SPLIT_MIN", CHOL_SPLIT_MIN); return v; }
+static int split_nb(void) { static int v = -1; if (v < 0) { v = env_int("CHOLAMD_SPLIT_NB", CHOL_SPLIT_NB); if (v > CHOL_RR_MAXN) v = CHOL_RR_MAXN; v = (v + 15) / 16 * 16; if (v < 16) v = 16; } return v; }
+static int pivot_blocks(int n) { return n > split_min() || n > CHOL_RR_MAXN ? (n + split_nb() - 1) / split_nb() : 1; }
+static int pivot_block_width(int n) { const int nb = pivot_blocks(n); return nb == 1 ? n : ((n + nb - 1) / nb + 15) / 16 * 16; }
+
 /* a phase whose 16x16 sub-tile count reaches this goes to 64x64 macro tiles for its larger targets:
  * below it the 16x16 split-K workgroups are what fills the 256 CUs, above it their 4x operand
  * re-reads are what costs */
@@ -95,6 +106,17 @@ static void push_trsm_run(builder *B, int64_t l_off, int64_t dinv_off, int64_t b
     if (w->n_trsm == B->cap_t) { B->cap_t = B->cap_t ? 2 * B->cap_t : 64; w->trsm = realloc(w->trsm, B->cap_t * sizeof(chol_trsm_desc)); }
     const int mm = m - r0 < CHOL_TRSM_ROWS ? m - r0 : CHOL_TRSM_ROWS;
     chol_trsm_desc td = { l_off, dinv_off, b_off + r0, n, ld, mm, ld };
+    w->trsm[w->n_trsm++] = td;
+  }
+}
+/* k_trsm_w gives the four strips of a workgroup one pivot block: after the strips of a block, placeholders
+ * (m = 0) fill the group of four, counted from the first strip of the phase */
+static void pad_trsm_group(builder *B, int phase_first, int64_t l_off, int64_t dinv_off, int64_t b_off, int n, int ld)
+{
+  chol_level_work *w = B->w;
+  while ((w->n_trsm - phase_first) % 4 != 0) {
+    if (w->n_trsm == B->cap_t) { B->cap_t = B->cap_t ? 2 * B->cap_t : 64; w->trsm = realloc(w->trsm, B->cap_t * sizeof(chol_trsm_desc)); }
+    chol_trsm_desc td = { l_off, dinv_off, b_off, n, ld, 0, ld };
     w->trsm[w->n_trsm++] = td;
   }
 }
@@ -202,24 +224,20 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
     if (level >= d && chol_owner_of(p, s, world) != rank) continue;
     if (count[BIDX(p, s, s)] == 0 || p->sep_size[s] == 0) continue;
     hs[nh++] = h;
-    if (p->sep_size[s] > CHOL_RR_MAXN) {
-      const int st = (p->sep_size[s] + CHOL_BIG_NB - 1) / CHOL_BIG_NB;
-      if (st > steps) steps = st;
-    }
+    if (pivot_blocks(p->sep_size[s]) > steps) steps = pivot_blocks(p->sep_size[s]);
   }
   if (steps == 0) steps = 1;
-  /* pivots: small ones (<= CHOL_RR_MAXN) whole in step 0; big ones in CHOL_BIG_NB-column blocks, each step =
+  /* pivots: small ones whole in step 0; big ones in pivot_block_width()-column blocks, each step =
    * POTRF of the diagonal block, TRSM of every row below it (rows of the pivot and filled ancestor rows
    * alike), rank-nb update of the remaining columns of those rows */
   for (int st = 0; st < steps; st++) {
     const int p0 = w->n_potrf, t0 = w->n_trsm, k0 = w->n_task, km0 = w->n_task_mt;
     for (int q = 0; q < nh; q++) {
       const int h = hs[q], s = p->tree[h], n = p->sep_size[s], ld = p->panel_ld[s];
-      const int big = n > CHOL_RR_MAXN;
-      if (!big && st > 0) continue;
-      const int c0 = big ? st * CHOL_BIG_NB : 0;
+      const int bw = pivot_block_width(n);
+      const int c0 = st * bw;
       if (c0 >= n) continue;
-      const int nb = big ? (n - c0 < CHOL_BIG_NB ? n - c0 : CHOL_BIG_NB) : n;
+      const int nb = n - c0 < bw ? n - c0 : bw;
       const int64_t diag = p->panel_off[s] + c0 + (int64_t)c0 * ld;          /* element (c0, c0) of the pivot */
       const int64_t dinv = p->dinv_off[s] + (int64_t)(c0 / CHOL_NB) * CHOL_NB * CHOL_NB;
       chol_potrf_desc pd = { diag, dinv, nb, ld, s, c0 };
@@ -229,6 +247,7 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
       if (below > 0) push_trsm_run(B, diag, dinv, p->panel_off[s] + (c0 + nb) + colbase, nb, ld, below);
       row_run *runs; const int nr = ancestor_runs(p, h, snap, first, count, &runs);
       for (int r = 0; r < nr; r++) push_trsm_run(B, diag, dinv, runs[r].off + colbase, nb, ld, runs[r].m);
+      if (nb <= CHOL_TRSM_W_MAXN) pad_trsm_group(B, t0, diag, dinv, diag, nb, ld);
       if (below > 0) { /* trailing columns [c0+nb, n): lower triangle of the pivot rows, everything of the ancestor rows */
         const int64_t x_piv = p->panel_off[s] + (c0 + nb) + colbase;         /* X rows = solved pivot rows, k = nb */
         chol_upd_src sp = { x_piv, x_piv, ld, ld, nb, 0 };
@@ -243,7 +262,11 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
       free(runs);
     }
     push_phase(B, 0, p0, w->n_potrf - p0);
-    push_phase(B, 1, t0, w->n_trsm - t0);
+    { /* strips whose pivot block is narrow enough take the one-wave-per-strip kernel */
+      int wide = 0;
+      for (int i = t0; i < w->n_trsm; i++) if (w->trsm[i].n > CHOL_TRSM_W_MAXN) wide = 1;
+      push_phase(B, wide ? 1 : 4, t0, w->n_trsm - t0);
+    }
     flush_targets(B);
     push_phase(B, 2, k0, w->n_task - k0);
     push_phase(B, 3, km0, w->n_task_mt - km0);
@@ -392,7 +415,9 @@ int cholamd_plan_level_work_counts(const cholamd_plan *p, int level, int rank, i
   chol_level_work w;
   int rc = chol_build_level_work(p, level, rank, world, &w);
   if (rc) return rc;
-  out[0] = w.n_potrf; out[1] = w.n_trsm; out[2] = w.n_task + w.n_task_mt; out[3] = w.n_src;
+  int strips = 0; /* without the placeholders that fill the groups of four */
+  for (int i = 0; i < w.n_trsm; i++) strips += w.trsm[i].m > 0;
+  out[0] = w.n_potrf; out[1] = strips; out[2] = w.n_task + w.n_task_mt; out[3] = w.n_src;
   chol_level_work_free(&w);
   return 0;
 }
