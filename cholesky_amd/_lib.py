@@ -91,6 +91,7 @@ def load():
     L.cholamd_plan_arena_to_dense.argtypes = [vp, vp, vp]
     L.cholamd_plan_fill_host_part.argtypes = [vp, vp, ci, ci, C.POINTER(i64)]
     L.cholamd_plan_level_work_counts.argtypes = [vp, ci, ci, ci, vp]
+    L.cholamd_plan_program_check.argtypes = [vp]
     L.cholamd_plan_write_matrix.argtypes = [vp, vp, C.c_char_p, ci]
     L.cholamd_plan_write_debug_log.argtypes = [vp, vp]
     L.cholamd_device_create.argtypes = [vp, ci, C.POINTER(vp)]

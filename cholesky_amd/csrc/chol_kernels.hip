@@ -86,9 +86,10 @@ __global__ void k_scatter(double *__restrict__ arena, const int64_t *__restrict_
 // Task ids are remapped so that consecutive tasks (sub-tiles of one target, sharing their source
 // panels) run on the same XCD and hit in its L2.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_update(double *__restrict__ base, const chol_upd_task *__restrict__ tasks,
+__global__ __launch_bounds__(256) void k_update(double *__restrict__ base_, double *const *__restrict__ arena_slot, const chol_upd_task *__restrict__ tasks,
                                                 const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd)
 {
+  double *const __restrict__ base = arena_slot ? *arena_slot : base_; // graph launches read the arena from a device cell
   __shared__ double sAcc[3][4][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -133,9 +134,10 @@ __global__ __launch_bounds__(256) void k_update(double *__restrict__ base, const
 // ------------------------------------------------------------------------------------------------
 #define MT 64
 #define MKB 16
-__global__ __launch_bounds__(256) void k_update_mt(double *__restrict__ base, const chol_upd_task *__restrict__ tasks,
+__global__ __launch_bounds__(256) void k_update_mt(double *__restrict__ base_, double *const *__restrict__ arena_slot, const chol_upd_task *__restrict__ tasks,
                                                    const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd)
 {
+  double *const __restrict__ base = arena_slot ? *arena_slot : base_; // graph launches read the arena from a device cell
   __shared__ double sA[2][MKB][MT];
   __shared__ double sB[2][MKB][MT];
   const int tt = threadIdx.x, lane = tt & 63;
@@ -515,9 +517,10 @@ __device__ __forceinline__ d4 load_tile(const double *A, int lda, int n, int ti,
   }
   return v;
 }
-__global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ base, double *__restrict__ ws,
+__global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ base_, double *const *__restrict__ arena_slot, double *__restrict__ ws,
                                                          const chol_potrf_desc *__restrict__ descs, int *__restrict__ info)
 {
+  double *const __restrict__ base = arena_slot ? *arena_slot : base_; // graph launches read the arena from a device cell
   // tiles in LDS are stored like accumulator registers: element (r, c) at c * 16 + r, so lane (r15, g)
   // register q sits at q * 64 + lp with lp = g * 16 + r15 (conflict free, and directly an MFMA operand)
   __shared__ double sRaw[RR_MAXT][TS * TS];    // raw (fully updated, unsolved) tiles of the next panel column
@@ -932,9 +935,10 @@ __global__ __launch_bounds__(64) void k_dinv(const double *__restrict__ Lp, int 
 // memory / L2 ahead of the barrier.
 // ------------------------------------------------------------------------------------------------
 #define TRSM_SLOTS 5 /* ceil(17 / 4) */
-__global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base, const double *__restrict__ ws,
+__global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base_, double *const *__restrict__ arena_slot, const double *__restrict__ ws,
                                                  const chol_trsm_desc *__restrict__ descs)
 {
+  double *const __restrict__ base = arena_slot ? *arena_slot : base_; // graph launches read the arena from a device cell
   __shared__ double sX[3][TS * TS]; // [J mod 3][c * 16 + r]: solved column tiles, accumulator-register order
   const chol_trsm_desc d = descs[blockIdx.x];
   const double *Lm = base + d.l_off;
@@ -1109,9 +1113,10 @@ template <int T> __device__ __forceinline__ void trsm_w_solve(d4 (&tile)[TW_MAXT
     }
   }
 }
-__global__ __launch_bounds__(256) void k_trsm_w(double *__restrict__ base, const double *__restrict__ ws,
+__global__ __launch_bounds__(256) void k_trsm_w(double *__restrict__ base_, double *const *__restrict__ arena_slot, const double *__restrict__ ws,
                                                 const chol_trsm_desc *__restrict__ descs, int ndesc)
 {
+  double *const __restrict__ base = arena_slot ? *arena_slot : base_; // graph launches read the arena from a device cell
   // slot(J2, J) = J T - J (J - 1) / 2 + (J2 - J), J2 >= J: tile L(J2, J) as the MFMA Y operand (element (c, k) at
   // (k / 4) * 64 + (k % 4) * 16 + c, i.e. accumulator-register order); the diagonal slots hold Linv(J,J) in the
   // layout solve16() reads (the workspace layout, copied verbatim)
@@ -1381,6 +1386,12 @@ __global__ __launch_bounds__(256) void k_bwd(const double *__restrict__ base, co
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
+__global__ void k_set_slot(double **slot, double *arena) { *slot = arena; }
+int chol_launch_set_slot(double **slot, double *arena, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_set_slot, dim3(1), dim3(1), 0, st, slot, arena);
+  return (int)hipGetLastError();
+}
 int chol_launch_scatter(double *arena, const int64_t *dst, const double *val, int64_t nnz, hipStream_t st)
 {
   if (nnz <= 0) return 0;
@@ -1389,10 +1400,14 @@ int chol_launch_scatter(double *arena, const int64_t *dst, const double *val, in
   hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(256), 0, st, arena, dst, val, nnz);
   return (int)hipGetLastError();
 }
+// the cell the next launches read their arena pointer from (nullptr = the pointer argument); set only while
+// cholamd_factor's launch graph is being captured
+static thread_local double *const *g_arena_slot = nullptr;
+void chol_launch_set_arena_slot(double *const *slot) { g_arena_slot = slot; }
 int chol_launch_potrf(double *base, double *ws, const chol_potrf_desc *descs, int n, int *info, hipStream_t st)
 { // pivots up to CHOL_RR_MAXN: register-resident kernel, one 1024-thread workgroup each
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(k_potrf_rr, dim3(n), dim3(RR_THREADS), 0, st, base, ws, descs, info);
+  hipLaunchKernelGGL(k_potrf_rr, dim3(n), dim3(RR_THREADS), 0, st, base, g_arena_slot, ws, descs, info);
   return (int)hipGetLastError();
 }
 int chol_launch_potrf_big(double *base, double *ws, const chol_potrf_desc *descs, int n, int *info, hipStream_t st)
@@ -1410,13 +1425,13 @@ int chol_launch_dinv(const double *L, int n, int ldl, double *W, hipStream_t st)
 int chol_launch_trsm(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st)
 { // strips of pivots up to CHOL_RR_MAXN
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(k_trsm_rr, dim3(n), dim3(256), 0, st, base, ws, descs);
+  hipLaunchKernelGGL(k_trsm_rr, dim3(n), dim3(256), 0, st, base, g_arena_slot, ws, descs);
   return (int)hipGetLastError();
 }
 int chol_launch_trsm_w(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st)
 { // strips of pivot blocks up to CHOL_TRSM_W_MAXN columns, one wave each; every aligned group of four descriptors shares one block
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(k_trsm_w, dim3((n + 3) / 4), dim3(256), 0, st, base, ws, descs, n);
+  hipLaunchKernelGGL(k_trsm_w, dim3((n + 3) / 4), dim3(256), 0, st, base, g_arena_slot, ws, descs, n);
   return (int)hipGetLastError();
 }
 int chol_launch_trsm_big(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st)
@@ -1429,14 +1444,14 @@ int chol_launch_update(double *base, const chol_upd_task *tasks, const chol_upd_
 {
   if (ntask <= 0) return 0;
   const int per_xcd = (ntask + 7) / 8;
-  hipLaunchKernelGGL(k_update, dim3(per_xcd * 8), dim3(256), 0, st, base, tasks, srcs, ntask, per_xcd);
+  hipLaunchKernelGGL(k_update, dim3(per_xcd * 8), dim3(256), 0, st, base, g_arena_slot, tasks, srcs, ntask, per_xcd);
   return (int)hipGetLastError();
 }
 int chol_launch_update_mt(double *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st)
 {
   if (ntask <= 0) return 0;
   const int per_xcd = (ntask + 7) / 8;
-  hipLaunchKernelGGL(k_update_mt, dim3(per_xcd * 8), dim3(256), 0, st, base, tasks, srcs, ntask, per_xcd);
+  hipLaunchKernelGGL(k_update_mt, dim3(per_xcd * 8), dim3(256), 0, st, base, g_arena_slot, tasks, srcs, ntask, per_xcd);
   return (int)hipGetLastError();
 }
 int chol_launch_permute(const double *in, const int *perm, double *out, int n, int inverse, hipStream_t st)

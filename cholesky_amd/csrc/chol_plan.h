@@ -72,7 +72,13 @@ typedef struct {
 } chol_upd_task;
 
 /* one batched launch: descriptors [first, first + n) of the level's array of that kind */
-typedef struct { int kind /* 0 potrf, 1 trsm, 2 update (16x16 tasks), 3 update (64x64 macro-tile tasks), 4 trsm (every strip's pivot block <= CHOL_TRSM_W_MAXN wide) */, first, n; } chol_phase;
+typedef struct {
+  int kind;  /* 0 potrf, 1 trsm, 2 update (16x16 tasks), 3 update (64x64 macro-tile tasks), 4 trsm (every strip's pivot block <= CHOL_TRSM_W_MAXN wide) */
+  int first, n;
+  /* two-stream program only (chol_build_program): the stream the launch goes to, the events (ids from 1, 0 = none)
+   * it waits for and the one recorded after it */
+  int lane, wait[2], record;
+} chol_phase;
 
 #define CHOL_SPLIT_MIN 144 /* pivots wider than this are factored in column blocks (chol_schedule.c); measured on lapl_3375: 258 us unsplit, 240 us at 144/144 */
 #define CHOL_SPLIT_NB 144  /* ... of at most this many columns */
@@ -129,6 +135,8 @@ int chol_plan_finish(struct cholamd_plan *p, int nz, const int *a_row, const int
 const chol_block *chol_plan_block(const struct cholamd_plan *p, int r, int c);
 int chol_ntiles(const struct cholamd_plan *p, int sep, int interval);
 /* Build the device work lists of one tree level for (rank, world); caller frees with chol_level_work_free */
+/* the whole factorisation as one list of launches on two streams (single GPU, all levels): see chol_schedule.c */
+int chol_build_program(const struct cholamd_plan *p, chol_level_work *w, int *n_event);
 int chol_build_level_work(const struct cholamd_plan *p, int level, int rank, int world, chol_level_work *out);
 void chol_level_work_free(chol_level_work *w);
 int chol_owner_of(const struct cholamd_plan *p, int label, int world); /* -1: shared top of the tree */

@@ -169,6 +169,10 @@ int cholamd_plan_fill_host_part(const cholamd_plan *p, double *arena, int rank, 
 /* sizes of the device work lists of one tree level for (rank, world): potrf descriptors, trsm
  * strips, update tasks, update sources */
 int cholamd_plan_level_work_counts(const cholamd_plan *p, int level, int rank, int world, int out[4]);
+/* host-side self-check of the two-stream launch program cholamd_factor() runs on one GPU: same POTRF blocks,
+ * TRSM strips and (target tile, source) pairs as the per-level lists, every event recorded before it is awaited;
+ * 0 = consistent, otherwise cholamd_last_error() names the first difference */
+int cholamd_plan_program_check(const cholamd_plan *p);
 /* dense N x N col-major image of an arena (zeros outside allocated blocks) and back */
 int cholamd_plan_arena_to_dense(const cholamd_plan *p, const double *arena, double *dense);
 /* write_matrix (mmat.rg:102-147): banner, "M N nnz", "row col %0.8g" per non-zero, block by

@@ -20,7 +20,7 @@ int main(int argc, char **argv)
   for (int rep = 0; rep < 3; rep++) {
     hipMemcpy(dB, B.data(), B.size() * 8, hipMemcpyHostToDevice);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k_trsm_rr, dim3(strips), dim3(256), 0, 0, (double *)nullptr, (const double *)nullptr, dd);
+    hipLaunchKernelGGL(k_trsm_rr, dim3(strips), dim3(256), 0, 0, (double *)nullptr, (double *const *)nullptr, (const double *)nullptr, dd);
     hipEventRecord(e1);
     hipDeviceSynchronize();
   }

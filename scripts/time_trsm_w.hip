@@ -23,8 +23,8 @@ int main(int argc, char **argv)
       hipMemcpy(dB, B.data(), B.size() * 8, hipMemcpyHostToDevice);
       hipDeviceSynchronize();
       hipEventRecord(e0);
-      if (which == 0) hipLaunchKernelGGL(k_trsm_w, dim3((strips + 3) / 4), dim3(256), 0, 0, (double *)nullptr, (const double *)nullptr, dd, strips);
-      else hipLaunchKernelGGL(k_trsm_rr, dim3(strips), dim3(256), 0, 0, (double *)nullptr, (const double *)nullptr, dd);
+      if (which == 0) hipLaunchKernelGGL(k_trsm_w, dim3((strips + 3) / 4), dim3(256), 0, 0, (double *)nullptr, (double *const *)nullptr, (const double *)nullptr, dd, strips);
+      else hipLaunchKernelGGL(k_trsm_rr, dim3(strips), dim3(256), 0, 0, (double *)nullptr, (double *const *)nullptr, (const double *)nullptr, dd);
       hipEventRecord(e1);
       hipDeviceSynchronize();
       float ms; hipEventElapsedTime(&ms, e0, e1);
