@@ -45,6 +45,8 @@ struct cholamd_device {
   bool solve_ready = false;
   double *ws = nullptr;
   int *info = nullptr;      // [0] first failing column, [1] separator
+  int *progress = nullptr;  // fused POTRF+TRSM launches: columns published per pivot block (epoch * 64 + columns)
+  int epoch = 0;
   int64_t *a_dst = nullptr; double *a_val = nullptr; int *perm = nullptr; double *ytmp = nullptr;
   bool timing = false;
   std::vector<timed_launch> tl;
@@ -165,6 +167,8 @@ extern "C" int cholamd_device_create(const cholamd_plan *plan, int device_id, ch
     hipError_t e = hipMalloc((void **)&d->ws, (size_t)(plan->ws_doubles > 0 ? plan->ws_doubles : 1) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&d->info, 2 * sizeof(int));
     if (e == hipSuccess) e = hipMemset(d->info, 0, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&d->progress, (size_t)(plan->nsep + 1) * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(d->progress, 0, (size_t)(plan->nsep + 1) * sizeof(int));
     if (e != hipSuccess) { chol_set_error("hipMalloc: %s", hipGetErrorString(e)); rc = CHOLAMD_ERR_HIP; }
   }
   if (!rc) rc = upload_vec(&d->a_dst, plan->a_dst, (size_t)plan->nnz_a);
@@ -181,7 +185,7 @@ extern "C" void cholamd_device_destroy(cholamd_device *d)
   (void)hipSetDevice(d->dev);
   free_levels(d);
   for (auto &s : d->sv) { (void)hipFree(s.trsv); (void)hipFree(s.fw); (void)hipFree(s.bw); (void)hipFree(s.grp_start); (void)hipFree(s.grp_rows); (void)hipFree(s.bw_start); }
-  (void)hipFree(d->ws); (void)hipFree(d->info); (void)hipFree(d->a_dst); (void)hipFree(d->a_val); (void)hipFree(d->perm); (void)hipFree(d->ytmp);
+  (void)hipFree(d->ws); (void)hipFree(d->info); (void)hipFree(d->progress); (void)hipFree(d->a_dst); (void)hipFree(d->a_val); (void)hipFree(d->perm); (void)hipFree(d->ytmp);
   for (auto &t : d->tl) { d->pool.push_back(t.a); d->pool.push_back(t.b); }
   for (auto e : d->pool) (void)hipEventDestroy(e);
   for (auto e : d->prog_ev) (void)hipEventDestroy(e);
@@ -299,7 +303,11 @@ extern "C" int cholamd_device_get_timing(cholamd_device *d, float ms_by_kind[4],
 // ---- the hot path ---------------------------------------------------------------------------
 static int launch_phase(cholamd_device *d, const level_dev &l, const chol_phase &ph, double *d_arena, hipStream_t st)
 {
-  if (ph.kind == 0) HIPCHK((hipError_t)chol_launch_potrf(d_arena, d->ws, l.potrf + ph.first, ph.n, d->info, st));
+  if (ph.kind == 5) {
+    if (d->epoch >= (1 << 24)) { HIPCHK(hipMemsetAsync(d->progress, 0, (size_t)(d->plan->nsep + 1) * sizeof(int), st)); d->epoch = 0; }
+    d->epoch++;
+    HIPCHK((hipError_t)chol_launch_potrf_trsm(d_arena, d->ws, l.potrf + ph.first, ph.n, l.trsm + ph.first2, ph.n2, d->info, d->progress, d->epoch * 64, st));
+  } else if (ph.kind == 0) HIPCHK((hipError_t)chol_launch_potrf(d_arena, d->ws, l.potrf + ph.first, ph.n, d->info, st));
   else if (ph.kind == 1) HIPCHK((hipError_t)chol_launch_trsm(d_arena, d->ws, l.trsm + ph.first, ph.n, st));
   else if (ph.kind == 4) HIPCHK((hipError_t)chol_launch_trsm_w(d_arena, d->ws, l.trsm + ph.first, ph.n, st));
   else if (ph.kind == 2) HIPCHK((hipError_t)chol_launch_update(d_arena, l.task + ph.first, l.src, ph.n, st));
@@ -317,7 +325,7 @@ extern "C" int cholamd_factor_levels(cholamd_device *d, double *d_arena, int lev
   for (int lvl = level_hi; lvl >= level_lo; lvl--) { // mmat.rg:1227
     const level_dev &l = d->lv[lvl];
     for (const chol_phase &ph : l.phase) {
-      scoped_timer t(d, st, ph.kind == 3 ? 2 : ph.kind == 4 ? 1 : ph.kind, ph.n > 0);
+      scoped_timer t(d, st, ph.kind == 3 ? 2 : ph.kind == 4 ? 1 : ph.kind == 5 ? 0 : ph.kind, ph.n > 0);
       int rc = launch_phase(d, l, ph, d_arena, st);
       if (rc) return rc;
     }

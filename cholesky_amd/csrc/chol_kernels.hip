@@ -517,10 +517,17 @@ __device__ __forceinline__ d4 load_tile(const double *A, int lda, int n, int ti,
   }
   return v;
 }
-__global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ base_, double *const *__restrict__ arena_slot, double *__restrict__ ws,
-                                                         const chol_potrf_desc *__restrict__ descs, int *__restrict__ info)
+// global store of the factor: plain, or -- in the fused POTRF+TRSM launch, where other workgroups read it while the
+// kernel runs -- an agent-scope (write-through, device-coherent) store
+template <bool PUB> __device__ __forceinline__ void gstore(double *p, double v)
 {
-  double *const __restrict__ base = arena_slot ? *arena_slot : base_; // graph launches read the arena from a device cell
+  if (PUB) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool PUB>
+__device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double *__restrict__ ws, const chol_potrf_desc d, int *__restrict__ info,
+                                              int *__restrict__ progress, int progress_base)
+{
   // tiles in LDS are stored like accumulator registers: element (r, c) at c * 16 + r, so lane (r15, g)
   // register q sits at q * 64 + lp with lp = g * 16 + r15 (conflict free, and directly an MFMA operand)
   __shared__ double sRaw[RR_MAXT][TS * TS];    // raw (fully updated, unsolved) tiles of the next panel column
@@ -536,7 +543,6 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
   int *const fA = &sFlag[5];   // j: raw tile (j, j-1) is in sRaw[j]
   int *const fD = &sFlag[6];   // j: diagonal tile (j, j), updated through step j-2, is in sDg[j & 1]
 
-  const chol_potrf_desc d = descs[blockIdx.x];
   double *A = base + d.a_off;
   double *W = ws + d.dinv_off;
   const int n = d.n, lda = d.lda;
@@ -619,14 +625,6 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
 #pragma unroll
       for (int st = 0; st < 4; ++st) dn = __builtin_amdgcn_mfma_f64_16x16x4f64(p[st], -p[st], dn, 0, 0, 0);
       dk = dn;
-      { // L(k+1, k) to global memory (fire and forget)
-        const int row = (k + 1) * TS + r15;
-        double *dst = A + row + (int64_t)(k * TS + g) * lda;
-        if (row < n) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) dst[(int64_t)(4 * q) * lda] = p[q];
-        }
-      }
       STAMPK(6);
     }
     STAMP_FLUSH;
@@ -640,20 +638,30 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
     for (int s = 0; s < RR_SLOTS; ++s) ijp[s] = __builtin_amdgcn_readfirstlane((int)sIJ[s * RR_NW + w]);
     // ---- prologue: columns 0 and 1 go straight to LDS -- (0,0), (1,1) -> sDg, (i,0) -> sRaw[i],
     //      (i,1), i >= 2 -> sSol[1][i] (free until the panel solve of step 1) -- then the register tiles
-    for (int u = w; u < 2 * T - 1; u += RR_NW) {
-      const int tj = u < T ? 0 : 1, ti = u < T ? u : u - T + 1;
-      const d4 v = load_tile(A, lda, n, ti, tj, r15, g);
-      double *park = ti == tj ? &sDg[ti][0] : tj == 0 ? &sRaw[ti][0] : &sSol[1][ti][0];
+    //      Every load of the prologue is issued before the first wait: three tiles of columns 0 / 1 per wave at
+    //      most (2 T - 1 <= 33 tiles over 11 waves), then the register tiles.
+    d4 stage[3];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) park[q * 64 + lp0] = v[q];
-      if (tj == 0 && ti > 0) lds_inc(cRaw, lane);
+    for (int it = 0; it < 3; ++it) {
+      const int u = min(w + it * RR_NW, 2 * T - 2);
+      stage[it] = load_tile(A, lda, n, u < T ? u : u - T + 1, u < T ? 0 : 1, r15, g);
     }
 #pragma unroll
     for (int s = 0; s < RR_RSLOTS; ++s) {
       d4 v = { 0.0, 0.0, 0.0, 0.0 };
       if (ijp[s] != 0xffff) v = load_tile(A, lda, n, ijp[s] & 0xff, ijp[s] >> 8, r15, g);
       tile[s] = v;
-      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int u = w + it * RR_NW;
+      if (u < 2 * T - 1) {
+        const int tj = u < T ? 0 : 1, ti = u < T ? u : u - T + 1;
+        double *park = ti == tj ? &sDg[ti][0] : tj == 0 ? &sRaw[ti][0] : &sSol[1][ti][0];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) park[q * 64 + lp0] = stage[it][q];
+        if (tj == 0 && ti > 0) lds_inc(cRaw, lane);
+      }
     }
     if (ijp[RR_RSLOTS] != 0xffff) { // heavy waves only (rr_owner)
       const d4 v = load_tile(A, lda, n, ijp[RR_RSLOTS] & 0xff, ijp[RR_RSLOTS] >> 8, r15, g);
@@ -696,13 +704,13 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             sSol[par][i0][q * 64 + lp] = x0[q];
-            if (row0 < n) col[row0 + (int64_t)(4 * q) * lda] = x0[q];
+            if (row0 < n) gstore<PUB>(&col[row0 + (int64_t)(4 * q) * lda], x0[q]);
           }
           if (i1 < T) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               sSol[par][i1][q * 64 + lp] = x1[q];
-              if (row1 < n) col[row1 + (int64_t)(4 * q) * lda] = x1[q];
+              if (row1 < n) gstore<PUB>(&col[row1 + (int64_t)(4 * q) * lda], x1[q]);
             }
           }
         }
@@ -786,16 +794,36 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           const double lv = sLW[par][r15][g + 4 * b], wv = sLW[par][TS + g + 4 * b][r15];
-          if (row < n && g + 4 * b <= r15) dst[(int64_t)(4 * b) * lda] = lv;
-          Wb[(g + 4 * b) * TS + r15] = wv; // Wb[k * 16 + c] = Linv(c, k): the layout solve16() reads
+          if (row < n && g + 4 * b <= r15) gstore<PUB>(&dst[(int64_t)(4 * b) * lda], lv);
+          gstore<PUB>(&Wb[(g + 4 * b) * TS + r15], wv); // Wb[k * 16 + c] = Linv(c, k): the layout solve16() reads
+        }
+        if (k + 1 < T && row + TS < n) { // L(k+1, k), solved by the factor wave, is still in LDS
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gstore<PUB>(&dst[TS + (int64_t)(4 * q) * lda], sSol[par][k + 1][q * 64 + lp]);
         }
       }
-      // ---- 4.
+      // ---- 4.  Fused launch: the wave's stores of column k have landed before it counts itself out of the
+      //      step, and the last wave out tells the TRSM workgroups that column k and Linv(k,k) can be read
       STAMPK(6);
-      lds_inc(cUpd, lane);
+      if (PUB) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        int old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(cUpd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old + 1 == RR_NW * (k + 2) && lane == 0) __hip_atomic_store(progress, progress_base + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        lds_inc(cUpd, lane);
+      }
     }
     if (w == STAMP_WAVE) { STAMP_FLUSH2; }
   }
+}
+
+__global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ base_, double *const *__restrict__ arena_slot, double *__restrict__ ws,
+                                                         const chol_potrf_desc *__restrict__ descs, int *__restrict__ info)
+{
+  double *const __restrict__ base = arena_slot ? *arena_slot : base_; // graph launches read the arena from a device cell
+  potrf_rr_body<false>(base, ws, descs[blockIdx.x], info, nullptr, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -935,28 +963,47 @@ __global__ __launch_bounds__(64) void k_dinv(const double *__restrict__ Lp, int 
 // memory / L2 ahead of the barrier.
 // ------------------------------------------------------------------------------------------------
 #define TRSM_SLOTS 5 /* ceil(17 / 4) */
-__global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base_, double *const *__restrict__ arena_slot, const double *__restrict__ ws,
-                                                 const chol_trsm_desc *__restrict__ descs)
+// loads of the factor in the fused POTRF+TRSM launch: agent-scope, so that they see what the POTRF workgroup
+// published while this kernel runs (never a stale line of this XCD's L2)
+template <bool PUB> __device__ __forceinline__ double gload(const double *p)
 {
-  double *const __restrict__ base = arena_slot ? *arena_slot : base_; // graph launches read the arena from a device cell
-  __shared__ double sX[3][TS * TS]; // [J mod 3][c * 16 + r]: solved column tiles, accumulator-register order
-  const chol_trsm_desc d = descs[blockIdx.x];
+  if (PUB) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+// wait until the pivot's POTRF workgroup has published `target` columns.  The POTRF workgroups of a launch have the
+// lowest block indices, are dispatched first and wait for nobody; the spin is bounded all the same: after ~50 ms it
+// gives up and reports through info (the factorisation then fails loudly instead of hanging the GPU).
+__device__ __forceinline__ int wait_progress(const int *progress, int target, int seen, int *info)
+{
+  if (seen >= target) return seen;
+  int v = 0;
+  for (int it = 0; it < (1 << 16); ++it) {
+    v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (v >= target) return v;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if ((threadIdx.x & 63) == 0) atomicCAS(&info[0], 0, -7); // internal error: no progress
+  return target;
+}
+// one strip, four waves (wave = 0..3 of the strip's group); sX = the group's three LDS tiles
+template <bool PUB, int SLOTS>
+__device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const double *__restrict__ ws, const chol_trsm_desc d, double (*sX)[TS * TS],
+                                             int wave, int lane, const int *__restrict__ progress, int progress_base, int *__restrict__ info)
+{
   const double *Lm = base + d.l_off;
   const double *W = ws + d.dinv_off;
   double *B = base + d.b_off;
   const int n = d.n, m = d.m, ldl = d.ldl, ldb = d.ldb;
   const int T = (n + TS - 1) / TS;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r15 = lane & 15, g = lane >> 4;
   const int lp = g * TS + r15;
   const bool vrow = r15 < m;
 
-  d4 tile[TRSM_SLOTS];
-  int64_t voff[TRSM_SLOTS]; // lane part of the address of L(J2 * 16 + r15, g): rows past n are clamped (their
+  d4 tile[SLOTS];
+  int64_t voff[SLOTS]; // lane part of the address of L(J2 * 16 + r15, g): rows past n are clamped (their
                             // products only reach output columns >= n, which are never stored)
 #pragma unroll
-  for (int s = 0; s < TRSM_SLOTS; ++s) {
+  for (int s = 0; s < SLOTS; ++s) {
     const int J = wave + 4 * s;
     d4 v = { 0.0, 0.0, 0.0, 0.0 };
     if (J < T) {
@@ -972,17 +1019,19 @@ __global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base_, dou
   // L tiles (J2, J) of the updates of step J (uniform branch per slot, one scalar base per step)
 #define LOAD_L(J_, buf_)                                                                                \
   if ((J_) < T) {                                                                                       \
+    if (PUB) seen = wait_progress(progress, progress_base + (J_) + 1, seen, info);                      \
     const double *lb_ = Lm + (int64_t)((J_) * TS) * ldl;                                                \
-    _Pragma("unroll") for (int s = 0; s < TRSM_SLOTS; ++s) {                                            \
+    _Pragma("unroll") for (int s = 0; s < SLOTS; ++s) {                                            \
       const int J2_ = wave + 4 * s;                                                                     \
       if (J2_ > (J_) && J2_ < T) {                                                                      \
-        _Pragma("unroll") for (int st = 0; st < 4; ++st) buf_[s][st] = lb_[voff[s] + (int64_t)(4 * st) * ldl]; \
+        _Pragma("unroll") for (int st = 0; st < 4; ++st) buf_[s][st] = gload<PUB>(&lb_[voff[s] + (int64_t)(4 * st) * ldl]); \
       }                                                                                                 \
     }                                                                                                   \
   }
 #define LOAD_W(J_, buf_)                                                                                \
   {                                                                                                     \
-    _Pragma("unroll") for (int st = 0; st < 4; ++st) buf_[st] = W[(int64_t)(J_) * TS * TS + (4 * st + g) * TS + r15]; \
+    if (PUB) seen = wait_progress(progress, progress_base + (J_) + 1, seen, info);                      \
+    _Pragma("unroll") for (int st = 0; st < 4; ++st) buf_[st] = gload<PUB>(&W[(int64_t)(J_) * TS * TS + (4 * st + g) * TS + r15]); \
   }
 #define PUBLISH_X(J_, x_)                                                                               \
   {                                                                                                     \
@@ -1001,14 +1050,15 @@ __global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base_, dou
   }
   // operands are fetched two steps ahead; vmcnt retires in order, so the inverse the next solve waits
   // for is issued before the L tiles of the same step
-  double lpre[3][TRSM_SLOTS][4], wpre[3][4];
+  int seen = 0; // last progress value read (fused launch)
+  double lpre[3][SLOTS][4], wpre[3][4];
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       wpre[u][st] = 0.0;
 #pragma unroll
-      for (int s = 0; s < TRSM_SLOTS; ++s) lpre[u][s][st] = 0.0;
+      for (int s = 0; s < SLOTS; ++s) lpre[u][s][st] = 0.0;
     }
   }
   if (wave == 0) LOAD_W(0, wpre[0]);
@@ -1021,7 +1071,7 @@ __global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base_, dou
   }
   STAMP_DECL;
 #pragma unroll
-  for (int J = 0; J < RR_MAXT; ++J) {
+  for (int J = 0; J < 4 * SLOTS; ++J) {
     if (J < T) {
       STAMP(0);
       const bool next_owner = (J + 1 < T) && (((J + 1) & 3) == wave);
@@ -1031,7 +1081,7 @@ __global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base_, dou
         // critical chain: bring tile J+1 up to date, solve it, publish it -- nothing else before the
         // next barrier; this wave's other updates with X_J are deferred to the next step
         const int s1 = (J + 1) >> 2;
-        if (s1 < TRSM_SLOTS) {
+        if (s1 < SLOTS) {
           APPLY_X(J, s1);
           const d4 x = solve16(tile[s1], wpre[(J + 1) % 3]);
           tile[s1] = x;
@@ -1040,13 +1090,13 @@ __global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base_, dou
       } else {
         if (J >= 1 && (J & 3) == wave) { // owner of the previous look-ahead: catch up with X_{J-1}
 #pragma unroll
-          for (int s = 0; s < TRSM_SLOTS; ++s) {
+          for (int s = 0; s < SLOTS; ++s) {
             const int J2 = wave + 4 * s;
             if (J2 > J && J2 < T) APPLY_X(J - 1, s);
           }
         }
 #pragma unroll
-        for (int s = 0; s < TRSM_SLOTS; ++s) {
+        for (int s = 0; s < SLOTS; ++s) {
           const int J2 = wave + 4 * s;
           if (J2 > J + 1 && J2 < T) APPLY_X(J, s);
         }
@@ -1063,6 +1113,45 @@ __global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base_, dou
 #undef LOAD_W
 #undef PUBLISH_X
 #undef APPLY_X
+}
+
+__global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base_, double *const *__restrict__ arena_slot, const double *__restrict__ ws,
+                                                 const chol_trsm_desc *__restrict__ descs)
+{
+  double *const __restrict__ base = arena_slot ? *arena_slot : base_; // graph launches read the arena from a device cell
+  __shared__ double sX[3][TS * TS]; // [J mod 3][c * 16 + r]: solved column tiles, accumulator-register order
+  trsm_rr_body<false, TRSM_SLOTS>(base, ws, descs[blockIdx.x], sX, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, nullptr, 0, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused POTRF + TRSM launch of one column-block step of a level.  Workgroups [0, n_potrf) factor one
+// pivot block each (potrf_rr_body) and publish, column by column, how far L and Linv are in global
+// memory; the others take three 16-row strips of one pivot block each (four waves per strip, trsm_rr_body)
+// and follow their pivot's POTRF two columns behind instead of waiting for the whole level's POTRF
+// launch to end: the TRSM launch (7-14 us, latency-bound) and one kernel boundary per step disappear
+// from the critical path.  Data handed over inside the launch is written with agent-scope stores and
+// read with agent-scope loads (device-coherent across the XCDs' L2s); the progress word is written
+// after the workgroup's stores of that column have completed (s_waitcnt vmcnt(0)).
+// ------------------------------------------------------------------------------------------------
+#define FUSED_SLOTS ((CHOL_FUSE_MAXN / TS + 3) / 4) /* column tiles per wave of a strip: the registers of a 768-thread workgroup hold three */
+__global__ __launch_bounds__(RR_THREADS) void k_potrf_trsm(double *__restrict__ base_, double *const *__restrict__ arena_slot, double *__restrict__ ws,
+                                                           const chol_potrf_desc *__restrict__ pdescs, int n_potrf,
+                                                           const chol_trsm_desc *__restrict__ tdescs, int n_trsm, int *__restrict__ info,
+                                                           int *__restrict__ progress, int progress_base)
+{
+  double *const __restrict__ base = arena_slot ? *arena_slot : base_;
+  if ((int)blockIdx.x < n_potrf) {
+    potrf_rr_body<true>(base, ws, pdescs[blockIdx.x], info, progress + blockIdx.x, progress_base);
+  } else {
+    __shared__ double sX[3][3][TS * TS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2;
+    const int id = ((int)blockIdx.x - n_potrf) * 3 + grp;
+    // every group runs the same number of barriers: the strips of a workgroup share one pivot block
+    chol_trsm_desc d = tdescs[min(id, n_trsm - 1)];
+    if (id >= n_trsm) d.m = 0;
+    trsm_rr_body<true, FUSED_SLOTS>(base, ws, d, sX[grp], wave & 3, threadIdx.x & 63, progress + d.flag, progress_base, info);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1426,6 +1515,14 @@ int chol_launch_trsm(double *base, const double *ws, const chol_trsm_desc *descs
 { // strips of pivots up to CHOL_RR_MAXN
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k_trsm_rr, dim3(n), dim3(256), 0, st, base, g_arena_slot, ws, descs);
+  return (int)hipGetLastError();
+}
+int chol_launch_potrf_trsm(double *base, double *ws, const chol_potrf_desc *pdescs, int n_potrf, const chol_trsm_desc *tdescs, int n_trsm,
+                           int *info, int *progress, int progress_base, hipStream_t st)
+{ // fused launch: POTRF workgroups first (lowest block indices), then groups of three strips
+  if (n_potrf <= 0) return 0;
+  hipLaunchKernelGGL(k_potrf_trsm, dim3(n_potrf + (n_trsm + 2) / 3), dim3(RR_THREADS), 0, st, base, g_arena_slot, ws, pdescs, n_potrf, tdescs, n_trsm,
+                     info, progress, progress_base);
   return (int)hipGetLastError();
 }
 int chol_launch_trsm_w(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st)

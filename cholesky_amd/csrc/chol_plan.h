@@ -51,9 +51,11 @@ typedef struct {
   int64_t dinv_off;
   int64_t b_off;      /* first row of this row chunk inside the panel */
   int n, ldl, m, ldb; /* m rows (<= CHOL_TRSM_ROWS) */
+  int flag, pad;      /* fused POTRF+TRSM launch: index of the pivot block's POTRF descriptor in the same launch */
 } chol_trsm_desc;
 
 #define CHOL_TRSM_W_MAXN 64 /* widest pivot block the one-wave-per-strip TRSM kernel takes (4 tiles); measured against k_trsm_rr: 6.6 vs 8.0 us at 32, 8.4 vs 9.6 at 64, 12.6 vs 11.1 at 128 */
+#define CHOL_FUSE_MAXN 192 /* widest pivot block of a fused POTRF+TRSM launch (12 column tiles: three per wave of a strip) */
 #define CHOL_TRSM_ROWS 16
 
 typedef struct {
@@ -73,8 +75,9 @@ typedef struct {
 
 /* one batched launch: descriptors [first, first + n) of the level's array of that kind */
 typedef struct {
-  int kind;  /* 0 potrf, 1 trsm, 2 update (16x16 tasks), 3 update (64x64 macro-tile tasks), 4 trsm (every strip's pivot block <= CHOL_TRSM_W_MAXN wide) */
-  int first, n;
+  int kind;  /* 0 potrf, 1 trsm, 2 update (16x16 tasks), 3 update (64x64 macro-tile tasks), 4 trsm (every strip's pivot block <= CHOL_TRSM_W_MAXN wide),
+              * 5 fused potrf (first, n) + trsm (first2, n2) */
+  int first, n, first2, n2;
   /* two-stream program only (chol_build_program): the stream the launch goes to, the events (ids from 1, 0 = none)
    * it waits for and the one recorded after it */
   int lane, wait[2], record;

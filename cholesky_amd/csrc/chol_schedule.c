@@ -90,7 +90,7 @@ static void push_phase(builder *B, int kind, int first, int n)
   if (n <= 0) return;
   chol_level_work *w = B->w;
   if (w->n_phase == B->cap_ph) { B->cap_ph = B->cap_ph ? 2 * B->cap_ph : 16; w->phase = realloc(w->phase, B->cap_ph * sizeof(chol_phase)); }
-  chol_phase ph = { kind, first, n, 0, { 0, 0 }, 0 };
+  chol_phase ph = { kind, first, n, 0, 0, 0, { 0, 0 }, 0 };
   w->phase[w->n_phase++] = ph;
 }
 static void push_potrf(builder *B, chol_potrf_desc d)
@@ -100,24 +100,24 @@ static void push_potrf(builder *B, chol_potrf_desc d)
   w->potrf[w->n_potrf++] = d;
 }
 /* a run of `m` consecutive panel rows -> strips of CHOL_TRSM_ROWS */
-static void push_trsm_run(builder *B, int64_t l_off, int64_t dinv_off, int64_t b_off, int n, int ld, int m)
+static void push_trsm_run(builder *B, int64_t l_off, int64_t dinv_off, int64_t b_off, int n, int ld, int m, int flag)
 {
   chol_level_work *w = B->w;
   for (int r0 = 0; r0 < m; r0 += CHOL_TRSM_ROWS) {
     if (w->n_trsm == B->cap_t) { B->cap_t = B->cap_t ? 2 * B->cap_t : 64; w->trsm = realloc(w->trsm, B->cap_t * sizeof(chol_trsm_desc)); }
     const int mm = m - r0 < CHOL_TRSM_ROWS ? m - r0 : CHOL_TRSM_ROWS;
-    chol_trsm_desc td = { l_off, dinv_off, b_off + r0, n, ld, mm, ld };
+    chol_trsm_desc td = { l_off, dinv_off, b_off + r0, n, ld, mm, ld, flag, 0 };
     w->trsm[w->n_trsm++] = td;
   }
 }
-/* k_trsm_w gives the four strips of a workgroup one pivot block: after the strips of a block, placeholders
- * (m = 0) fill the group of four, counted from the first strip of the phase */
-static void pad_trsm_group(builder *B, int phase_first, int64_t l_off, int64_t dinv_off, int64_t b_off, int n, int ld)
+/* k_trsm_w (four strips) and the fused POTRF+TRSM launch (three) give the strips of a workgroup one pivot block:
+ * after the strips of a block, placeholders (m = 0) fill the group, counted from the first strip of the phase */
+static void pad_trsm_group(builder *B, int phase_first, int group, int64_t l_off, int64_t dinv_off, int64_t b_off, int n, int ld, int flag)
 {
   chol_level_work *w = B->w;
-  while ((w->n_trsm - phase_first) % 4 != 0) {
+  while ((w->n_trsm - phase_first) % group != 0) {
     if (w->n_trsm == B->cap_t) { B->cap_t = B->cap_t ? 2 * B->cap_t : 64; w->trsm = realloc(w->trsm, B->cap_t * sizeof(chol_trsm_desc)); }
-    chol_trsm_desc td = { l_off, dinv_off, b_off, n, ld, 0, ld };
+    chol_trsm_desc td = { l_off, dinv_off, b_off, n, ld, 0, ld, flag, 0 };
     w->trsm[w->n_trsm++] = td;
   }
 }
@@ -234,6 +234,8 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
     if (pivot_blocks(p->sep_size[s]) > steps) steps = pivot_blocks(p->sep_size[s]);
   }
   if (steps == 0) steps = 1;
+  int fuse = !getenv("CHOLAMD_NO_FUSE"); /* POTRF + TRSM of a step in one launch, if every block fits its TRSM role */
+  for (int q = 0; q < nh; q++) if (pivot_block_width(p->sep_size[p->tree[hs[q]]]) > CHOL_FUSE_MAXN) fuse = 0;
   /* pivots: small ones whole in step 0; big ones in pivot_block_width()-column blocks, each step =
    * POTRF of the diagonal block, TRSM of every row below it (rows of the pivot and filled ancestor rows
    * alike), rank-nb update of the remaining columns of those rows */
@@ -251,10 +253,12 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
       push_potrf(B, pd);
       const int64_t colbase = (int64_t)c0 * ld;                              /* column c0 of the panel */
       const int below = n - c0 - nb;                                         /* pivot rows under the diagonal block */
-      if (below > 0) push_trsm_run(B, diag, dinv, p->panel_off[s] + (c0 + nb) + colbase, nb, ld, below);
+      const int flag = w->n_potrf - 1 - p0; /* this block's POTRF descriptor within the step */
+      if (below > 0) push_trsm_run(B, diag, dinv, p->panel_off[s] + (c0 + nb) + colbase, nb, ld, below, flag);
       row_run *runs; const int nr = ancestor_runs(p, h, snap, first, count, &runs);
-      for (int r = 0; r < nr; r++) push_trsm_run(B, diag, dinv, runs[r].off + colbase, nb, ld, runs[r].m);
-      if (nb <= CHOL_TRSM_W_MAXN) pad_trsm_group(B, t0, diag, dinv, diag, nb, ld);
+      for (int r = 0; r < nr; r++) push_trsm_run(B, diag, dinv, runs[r].off + colbase, nb, ld, runs[r].m, flag);
+      if (fuse) pad_trsm_group(B, t0, 3, diag, dinv, diag, nb, ld, flag);
+      else if (nb <= CHOL_TRSM_W_MAXN) pad_trsm_group(B, t0, 4, diag, dinv, diag, nb, ld, flag);
       if (below > 0) { /* trailing columns [c0+nb, n): lower triangle of the pivot rows, everything of the ancestor rows */
         const int64_t x_piv = p->panel_off[s] + (c0 + nb) + colbase;         /* X rows = solved pivot rows, k = nb */
         chol_upd_src sp = { x_piv, x_piv, ld, ld, nb, 0 };
@@ -268,8 +272,13 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
       }
       free(runs);
     }
-    push_phase(B, 0, p0, w->n_potrf - p0);
-    { /* strips whose pivot block is narrow enough take the one-wave-per-strip kernel */
+    if (fuse) { /* one launch: the strips follow their pivot's POTRF column by column */
+      if (w->n_phase == B->cap_ph) { B->cap_ph = B->cap_ph ? 2 * B->cap_ph : 16; w->phase = realloc(w->phase, B->cap_ph * sizeof(chol_phase)); }
+      chol_phase ph = { 5, p0, w->n_potrf - p0, t0, w->n_trsm - t0, 0, { 0, 0 }, 0 };
+      if (ph.n > 0) w->phase[w->n_phase++] = ph;
+    } else {
+      push_phase(B, 0, p0, w->n_potrf - p0);
+      /* strips whose pivot block is narrow enough take the one-wave-per-strip kernel */
       int wide = 0;
       for (int i = t0; i < w->n_trsm; i++) if (w->trsm[i].n > CHOL_TRSM_W_MAXN) wide = 1;
       push_phase(B, wide ? 1 : 4, t0, w->n_trsm - t0);
@@ -367,7 +376,7 @@ static void push_step(builder *B, int kind, int first, int n, int lane, int wait
   chol_level_work *w = B->w;
   if (n <= 0) kind = -1; /* an empty launch still carries its waits and its event */
   if (w->n_phase == B->cap_ph) { B->cap_ph = B->cap_ph ? 2 * B->cap_ph : 16; w->phase = realloc(w->phase, B->cap_ph * sizeof(chol_phase)); }
-  chol_phase ph = { kind, first, n, lane, { wait0, wait1 }, record };
+  chol_phase ph = { kind, first, n, 0, 0, lane, { wait0, wait1 }, record };
   w->phase[w->n_phase++] = ph;
 }
 /* the update launches (16x16 and macro-tile) of the targets pushed since (k0, km0) */
@@ -510,10 +519,10 @@ int chol_build_program(const plan_t *p, chol_level_work *w, int *n_event)
         const int64_t colbase = (int64_t)c0 * ld;
         const int below = n - c0 - nb;
         const int ts = w->n_trsm;
-        if (below > 0) push_trsm_run(B, diag, dinv, p->panel_off[s] + (c0 + nb) + colbase, nb, ld, below);
+        if (below > 0) push_trsm_run(B, diag, dinv, p->panel_off[s] + (c0 + nb) + colbase, nb, ld, below, -1);
         row_run *runs; const int nr = ancestor_runs_of(p, h, 1, snap, first, count, &runs);
-        for (int r = 0; r < nr; r++) push_trsm_run(B, diag, dinv, runs[r].off + colbase, nb, ld, runs[r].m);
-        if (nb <= CHOL_TRSM_W_MAXN && w->n_trsm > ts) pad_trsm_group(B, t0, diag, dinv, diag, nb, ld);
+        for (int r = 0; r < nr; r++) push_trsm_run(B, diag, dinv, runs[r].off + colbase, nb, ld, runs[r].m, -1);
+        if (nb <= CHOL_TRSM_W_MAXN && w->n_trsm > ts) pad_trsm_group(B, t0, 4, diag, dinv, diag, nb, ld, -1);
         if (below > 0) {
           const int64_t x_piv = p->panel_off[s] + (c0 + nb) + colbase;
           chol_upd_src sp = { x_piv, x_piv, ld, ld, nb, 0 };
@@ -548,8 +557,8 @@ int chol_build_program(const plan_t *p, chol_level_work *w, int *n_event)
         const int below = n - c0 - nb;
         const int ts = w->n_trsm;
         row_run *runs; const int nr = ancestor_runs_of(p, h, 2, snap, first, count, &runs);
-        for (int r = 0; r < nr; r++) push_trsm_run(B, diag, dinv, runs[r].off + colbase, nb, ld, runs[r].m);
-        if (nb <= CHOL_TRSM_W_MAXN && w->n_trsm > ts) pad_trsm_group(B, tb0, diag, dinv, diag, nb, ld);
+        for (int r = 0; r < nr; r++) push_trsm_run(B, diag, dinv, runs[r].off + colbase, nb, ld, runs[r].m, -1);
+        if (nb <= CHOL_TRSM_W_MAXN && w->n_trsm > ts) pad_trsm_group(B, tb0, 4, diag, dinv, diag, nb, ld, -1);
         if (below > 0) {
           const int64_t x_piv = p->panel_off[s] + (c0 + nb) + colbase;
           for (int r = 0; r < nr; r++) {
