@@ -165,6 +165,19 @@ def main():
     if rank == 0:
         calls, flops = plan.counts()
         kinds = {"potrf": float(flops[0]), "trsm": float(flops[1]), "update": float(flops[2] + flops[3])}
+        # the library fuses the POTRF and TRSM of a column-block step into one launch (k_potrf_trsm), timed as
+        # "potrf"; separate TRSM launches only exist with CHOLAMD_NO_FUSE
+        fused = timing["trsm"][1] == 0
+        if fused:
+            kinds["potrf"] += kinds["trsm"]
+        # algorithmic bytes of those launches: every pivot block and every filled ancestor row of its panel is read
+        # and written once (16 B per entry), the pivot once more by the strips solving against it (8 B)
+        blocks = plan.blocks
+        sizes = {int(b[1]): int(b[4] - b[2] + 1) for b in blocks if b[0] == b[1]}
+        piv_entries = sum(n * (n + 1) // 2 for n in sizes.values())
+        anc_entries = sum(int(b[4] - b[2] + 1) * sizes[int(b[1])] for b in blocks if b[0] != b[1])
+        alg_bytes = {"potrf": 16.0 * piv_entries + (16.0 * anc_entries + 8.0 * piv_entries if fused else 0.0),
+                     "trsm": 16.0 * anc_entries + 8.0 * piv_entries, "update": None}
         dom = max(("potrf", "trsm", "update"), key=lambda k: timing[k][0])
         ms, n_launch = timing[dom]
         avg_s = ms / max(n_launch, 1) * 1e-3
@@ -181,12 +194,12 @@ def main():
                        "n": plan.n, "levels": plan.levels, "separators": plan.nsep, "F_ref_flops": plan.flops,
                        "B_alg_bytes": plan.alg_bytes, "parallelism": f"subtree-sharded x{world}" if world > 1 else "single GPU",
                        "factor_info": list(info)},
-            "roofline": {"bound": "mfma", "kernel": f"k_{dom}", "achieved": None if achieved is None else round(achieved, 5),
+            "roofline": {"bound": "mfma", "kernel": {"potrf": "k_potrf_trsm" if fused else "k_potrf_rr", "trsm": "k_trsm_rr", "update": "k_update"}[dom], "achieved": None if achieved is None else round(achieved, 5),
                          "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": None if achieved is None else round(achieved / PEAK_FP64_TFLOPS, 6),
-                         "traffic": pmc_traffic({"potrf": "k_potrf_rr", "trsm": "k_trsm_rr", "update": "k_update"}[dom]) if world == 1 else None,
+                         "traffic": pmc_traffic({"potrf": "k_potrf_trsm" if fused else "k_potrf_rr", "trsm": "k_trsm_rr", "update": "k_update"}[dom]) if world == 1 else None,
                          "traffic_note": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r1/pmc_summary.json (separate rocprofv3 --pmc passes of this command); algorithmic bytes of the same launch in alg_bytes_per_launch",
-                         "alg_bytes_per_launch": (16.0 * sum(int(n) * (int(n) + 1) // 2 for n in plan.sep_sizes) / max(launches_per_factor, 1)) if dom == "potrf" else None,
+                         "alg_bytes_per_launch": (alg_bytes[dom] / max(launches_per_factor, 1)) if alg_bytes[dom] else None,
                          "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": launches_per_factor,
                          "alg_flops_per_launch": flops_per_launch,
                          "whole_step_frac_of_fp64_peak": round(value * 1e-3 / PEAK_FP64_TFLOPS, 6),

@@ -78,9 +78,10 @@ __global__ void k_scatter(double *__restrict__ arena, const int64_t *__restrict_
 
 // ------------------------------------------------------------------------------------------------
 // UPDATE: one workgroup (4 waves) per 16x16 output sub-tile of a target C tile.  The tile's sources
-// are walked in the reference's program order; the four waves split every source's K range (the
-// tasks are latency bound: K / 4 dependent MFMAs each fed by two L2 loads, so 4x the loads in flight
-// is 4x less time), partial sums meet in LDS and are added in a fixed order (deterministic).
+// are walked in the reference's program order; the four waves split every source's K range, or -- from
+// four sources on -- the sources themselves (the tasks are latency bound: dependent descriptor ->
+// operand -> MFMA chains, so 4x the chains in flight is 4x less time); partial sums meet in LDS and
+// are added in a fixed order (deterministic).
 //   C <- C - sum_s A_s B_s^T   (cblas_dgemm NoTrans/Trans alpha=-1 beta=1, blas.rg:139;
 //                               cblas_dsyrk Lower alpha=-1 beta=1, blas.rg:187 for `lower` tiles)
 // Task ids are remapped so that consecutive tasks (sub-tiles of one target, sharing their source
@@ -96,15 +97,34 @@ __global__ __launch_bounds__(256) void k_update(double *__restrict__ base_, doub
   const int tid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if ((blockIdx.x >> 3) >= per_xcd || tid >= ntask) return;
   const chol_upd_task t = tasks[tid];
+  // the C sub-tile is requested first (wave 0; clamped addresses, masked at the store): read at the end, each of
+  // its four columns would be a memory round trip of its own on the tail of every task
+  const int r = lane & 15, g = lane >> 4;
+  double cv[4] = { 0.0, 0.0, 0.0, 0.0 };
+  double *C = base + t.c_off;
+  if (wave == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cv[q] = *(const volatile double *)(C + min(r, t.mv - 1) + (int64_t)min(g + 4 * q, t.nv - 1) * t.ldc);
+  }
   d4 acc = { 0.0, 0.0, 0.0, 0.0 };
-  for (int s = t.src_begin; s < t.src_end; ++s) {
-    const chol_upd_src sd = srcs[s];
-    const int kc = ((((sd.k + 3) >> 2) + 3) >> 2) << 2; // K per wave, a multiple of 4
-    const int k_lo = wave * kc;
-    if (k_lo < sd.k) {
-      const int kn = min(kc, sd.k - k_lo);
-      acc = rank_k_16x16(acc, base + sd.a_off + t.ar + (int64_t)k_lo * sd.lda, sd.lda, t.mv,
-                         base + sd.b_off + t.br + (int64_t)k_lo * sd.ldb, sd.ldb, t.nv, kn, lane);
+  const int nsrc = t.src_end - t.src_begin;
+  if (nsrc >= 4) {
+    // many sources (a target high in the tree collects one per descendant): the waves take whole sources
+    // round-robin, so four descriptor -> operand load chains are in flight instead of one
+    for (int s = t.src_begin + wave; s < t.src_end; s += 4) {
+      const chol_upd_src sd = srcs[s];
+      acc = rank_k_16x16(acc, base + sd.a_off + t.ar, sd.lda, t.mv, base + sd.b_off + t.br, sd.ldb, t.nv, sd.k, lane);
+    }
+  } else {
+    for (int s = t.src_begin; s < t.src_end; ++s) {
+      const chol_upd_src sd = srcs[s];
+      const int kc = ((((sd.k + 3) >> 2) + 3) >> 2) << 2; // K per wave, a multiple of 4
+      const int k_lo = wave * kc;
+      if (k_lo < sd.k) {
+        const int kn = min(kc, sd.k - k_lo);
+        acc = rank_k_16x16(acc, base + sd.a_off + t.ar + (int64_t)k_lo * sd.lda, sd.lda, t.mv,
+                           base + sd.b_off + t.br + (int64_t)k_lo * sd.ldb, sd.ldb, t.nv, kn, lane);
+      }
     }
   }
   if (wave > 0) {
@@ -113,13 +133,11 @@ __global__ __launch_bounds__(256) void k_update(double *__restrict__ base_, doub
   }
   __syncthreads();
   if (wave == 0) {
-    const int r = lane & 15;
-    double *C = base + t.c_off + r;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int c = (lane >> 4) + 4 * q;
+      const int c = g + 4 * q;
       const double v = ((acc[q] + sAcc[0][q][lane]) + sAcc[1][q][lane]) + sAcc[2][q][lane];
-      if (r < t.mv && c < t.nv && (!t.lower || r >= c)) C[(int64_t)c * t.ldc] -= v;
+      if (r < t.mv && c < t.nv && (!t.lower || r >= c)) C[r + (int64_t)c * t.ldc] = cv[q] - v;
     }
   }
 }
@@ -191,6 +209,18 @@ __global__ __launch_bounds__(256) void k_update_mt(double *__restrict__ base_, d
       buf ^= 1;
     }
   }
+  // epilogue: all sixteen C values of the lane are requested before the first is used (clamped addresses, masked
+  // stores); as read-modify-writes in a row each one would wait for its own memory round trip
+  double cv[2][2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = min(32 * wr + 16 * i + r15, t.mv - 1), c = min(32 * wc + 16 * j + g + 4 * q, t.nv - 1);
+        cv[i][j][q] = *(const volatile double *)(base + t.c_off + r + (int64_t)c * t.ldc);
+      }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -200,7 +230,7 @@ __global__ __launch_bounds__(256) void k_update_mt(double *__restrict__ base_, d
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c = 32 * wc + 16 * j + g + 4 * q;
-        if (r < t.mv && c < t.nv && (!t.lower || r >= c)) C[(int64_t)c * t.ldc] -= acc[i][j][q];
+        if (r < t.mv && c < t.nv && (!t.lower || r >= c)) C[(int64_t)c * t.ldc] = cv[i][j][q] - acc[i][j][q];
       }
     }
 }
