@@ -238,14 +238,13 @@ __global__ __launch_bounds__(256) void k_update_mt(double *__restrict__ base_, d
 // ================================================================================================
 // Dense pivot kernels.  Diagonal blocks are TS = 16 wide (one fp64 MFMA tile).
 //
-// Triangular solves X = T L^-T against a 16x16 diagonal block never form the 16x16 inverse (its
-// serial chain is as long as the Cholesky of the block).  L is cut into 4x4 blocks; only the four
-// 4x4 diagonal blocks are inverted (chain length 4, the four blocks side by side in the quads of a
-// wave) and the solve is 7 dependent MFMAs (tile_solve below): for block column b = 0..3
-//     X_b = T_b Linv_bb^T                    one MFMA, Y operand = "Ydiag"
-//     T_{>b} -= X_b L(:, 4b..4b+3)^T         one MFMA, Y operand = register b of L in tile layout
-// Ydiag(c, k) = Linv_{c/4,c/4}(c % 4, k) is what the workspace holds per diagonal block
-// (W[blk * 256 + k * 16 + c], 64 doubles used) for the TRSM kernels.
+// Triangular solves X = T L^-T against a 16x16 diagonal block use the explicit inverse of the block:
+// X = T Linv^T is four accumulating MFMAs (solve16).  The register-resident POTRF gets Linv for free (the
+// rows of the identity ride through its row-per-lane Cholesky in otherwise idle lanes); the workspace holds
+// it per diagonal block as W[blk * 256 + k * 16 + c] = Linv(c, k), the layout solve16 reads.  The kernels
+// that do not run that Cholesky (k_potrf_big, k_dinv for the BLAS-level TRSM) cut L into 4x4 blocks instead:
+// the four 4x4 diagonal blocks are inverted side by side in the quads of a wave (linv4_quad, "Ydiag"), the
+// solve is 7 dependent MFMAs (tile_solve), and Linv = tile_solve(I) (store_linv16).
 //
 // Register-resident design for pivots up to CHOL_RR_MAXN = 272 (17 tiles): the MI355X register
 // file (512 KB per CU) is the only on-chip memory that holds a 259 x 259 fp64 lower triangle
@@ -474,31 +473,33 @@ __device__ __forceinline__ void tile_of_index(int idx, int T, int &ti, int &tj)
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_potrf_rr: register-resident POTRF, one 768-thread workgroup per pivot (n <= CHOL_RR_MAXN).
+// POTRF role (potrf_rr_body; k_potrf_rr, k_potrf_trsm): register-resident, one 768-thread workgroup per
+// pivot block (n <= CHOL_RR_MAXN).
 //
-// Roles.  Wave 0 = factor wave, waves 1..11 = tile waves.  The lower triangle of 16x16 tiles is
-// enumerated column-major and dealt round-robin to the tile waves (slot s of tile wave w holds tile
-// s * 11 + w); a tile stays in registers (accumulator layout) while it still receives updates.
+// Roles.  Wave 0 = factor wave, waves 1..11 = tile waves.  Columns 0 and 1 of the 16x16 tile grid are parked
+// in LDS by the prologue; the tiles of columns >= 2 are dealt to the tile waves in reverse column-major
+// order (rr_owner) and stay in registers (accumulator layout) while they still receive updates.
 //
 // Step k (block column k):
-//   factor wave   a. Cholesky of the diagonal tile (k,k) (row per lane) + 4x4 block inverses,
-//                    publishes L(k,k) / Ydiag(k) in LDS                                [flag fL]
-//                 b. waits until every tile wave has finished the updates of step k-1   [cnt cUpd]
-//                 c. solves the sub-diagonal tile (k+1,k) itself (7 MFMAs), publishes it [flag fP]
-//                 d. applies it to the diagonal tile (k+1,k+1) it already holds (4 MFMAs) and
-//                    goes straight to step k+1: the chain a-c-d never waits for a tile wave's
-//                    dispatch, only for the (coarse) cUpd counter.
-//   tile waves    1. solve the remaining panel tiles (i,k), i >= k+2, out of LDS: raw tiles of a
-//                    column are parked in LDS by their owners after their last update, so the solve
-//                    is a plain loop (tile i -> wave i mod 11) with no register-array dispatch
+//   factor wave   a. Cholesky of the diagonal tile (k,k), one row per lane; lanes 16-31 carry the rows of
+//                    the identity and come out as L(k,k)^-T.  Publishes both in LDS (sLW)     [flag fL]
+//                 b. waits for the two look-ahead tiles of step k-1's trailing update       [flags fA, fD]
+//                 c. solves the sub-diagonal tile (k+1,k) itself (4 MFMAs), publishes it      [flag fP]
+//                 d. applies it to the diagonal tile (k+1,k+1) it already holds (4 MFMAs) and goes
+//                    straight to step k+1; it re-uses an LDS buffer only after every tile wave has left
+//                    the step that read it (cUpd, two steps back)
+//   tile waves    1. wait for fL and for the raw tiles of column k (counter cRaw); the heavy waves solve
+//                    the panel tiles (i,k), i >= k+2, out of LDS with the explicit inverse (two tiles
+//                    interleaved, tile i -> heavy wave i mod 9)
 //                 2. software barrier (LDS counter cSol) + fP
-//                 3. trailing update of their register tiles, slots walked from the top down with
-//                    one early exit (the active tiles are a suffix of the enumeration); a tile that
-//                    just got its last update is parked: column k+1 -> sRaw, diagonal (k+2,k+2) ->
-//                    sDg (handed to the factor wave one step ahead)
-//                 4. cUpd += 1
-// All hand-offs are LDS words written after a workgroup-scope release fence and polled relaxed,
-// then acquired; no s_barrier inside the loop (the factor wave would have to take part in it).
+//                 3. trailing update of their live register tiles, next panel column first; a tile that
+//                    just got its last update is parked: column k+1 -> sRaw (+cRaw, fA for the look-ahead
+//                    tile), diagonal (k+2,k+2) -> sDg (fD)
+//                 4. one light wave copies L(k,k), L(k,k)^-T and L(k+1,k) from LDS to global memory;
+//                    cUpd += 1 (fused launch: after the wave's stores have completed; the last wave out
+//                    publishes the column to the TRSM workgroups)
+// All hand-offs are LDS words polled relaxed behind `s_waitcnt lgkmcnt(0)`; no s_barrier inside the loop
+// (the factor wave would have to take part in it), nothing that drains vmcnt on the critical chain.
 // ------------------------------------------------------------------------------------------------
 #define RR_NW 11     /* tile waves */
 #define RR_SLOTS 12  /* most tiles a tile wave owns: columns >= 2 of a 17 x 17 tile grid, 120 tiles (see rr_owner) */
