@@ -171,7 +171,9 @@ static void flush_targets(builder *B)
     const int64_t tr = (B->pend[i].m + 15) / 16, tc = (B->pend[i].n + 15) / 16;
     fine += B->pend[i].syrk ? tr * (tr + 1) / 2 : tr * tc;
   }
-  const int big = fine >= CHOL_MT_MIN_TILES;
+  static int mt_min = -1;
+  if (mt_min < 0) mt_min = env_int("CHOLAMD_MT_MIN_TILES", CHOL_MT_MIN_TILES);
+  const int big = fine >= mt_min;
   for (int i = 0; i < B->n_pend; i++) {
     const upd_target *t = &B->pend[i];
     emit_tasks(B, big && (t->m > 16 || t->n > 16), t->c_off, t->ldc, t->m, t->n, t->syrk, t->src_begin, t->src_end);
