@@ -45,8 +45,8 @@ struct cholamd_device {
   bool solve_ready = false;
   double *ws = nullptr;
   int *info = nullptr;      // [0] first failing column, [1] separator
-  int *progress = nullptr;  // fused POTRF+TRSM launches: columns published per pivot block (epoch * 64 + columns)
-  int epoch = 0;
+  int *progress = nullptr;  // fused launches: columns published per pivot block (epoch * 64 + columns); [nsep + 1] = TRSM workgroups finished
+  int epoch = 0, done_total = 0;
   int64_t *a_dst = nullptr; double *a_val = nullptr; int *perm = nullptr; double *ytmp = nullptr;
   bool timing = false;
   std::vector<timed_launch> tl;
@@ -167,8 +167,8 @@ extern "C" int cholamd_device_create(const cholamd_plan *plan, int device_id, ch
     hipError_t e = hipMalloc((void **)&d->ws, (size_t)(plan->ws_doubles > 0 ? plan->ws_doubles : 1) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&d->info, 2 * sizeof(int));
     if (e == hipSuccess) e = hipMemset(d->info, 0, 2 * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc((void **)&d->progress, (size_t)(plan->nsep + 1) * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(d->progress, 0, (size_t)(plan->nsep + 1) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&d->progress, (size_t)(plan->nsep + 2) * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(d->progress, 0, (size_t)(plan->nsep + 2) * sizeof(int));
     if (e != hipSuccess) { chol_set_error("hipMalloc: %s", hipGetErrorString(e)); rc = CHOLAMD_ERR_HIP; }
   }
   if (!rc) rc = upload_vec(&d->a_dst, plan->a_dst, (size_t)plan->nnz_a);
@@ -304,9 +304,11 @@ extern "C" int cholamd_device_get_timing(cholamd_device *d, float ms_by_kind[4],
 static int launch_phase(cholamd_device *d, const level_dev &l, const chol_phase &ph, double *d_arena, hipStream_t st)
 {
   if (ph.kind == 5) {
-    if (d->epoch >= (1 << 24)) { HIPCHK(hipMemsetAsync(d->progress, 0, (size_t)(d->plan->nsep + 1) * sizeof(int), st)); d->epoch = 0; }
+    if (d->epoch >= (1 << 24)) { HIPCHK(hipMemsetAsync(d->progress, 0, (size_t)(d->plan->nsep + 2) * sizeof(int), st)); d->epoch = 0; d->done_total = 0; }
     d->epoch++;
-    HIPCHK((hipError_t)chol_launch_potrf_trsm(d_arena, d->ws, l.potrf + ph.first, ph.n, l.trsm + ph.first2, ph.n2, d->info, d->progress, d->epoch * 64, st));
+    d->done_total += (ph.n2 + 2) / 3; // TRSM workgroups of this launch
+    HIPCHK((hipError_t)chol_launch_potrf_trsm(d_arena, d->ws, l.potrf + ph.first, ph.n, l.trsm + ph.first2, ph.n2, l.task + ph.first3, l.src, ph.n3,
+                                              d->info, d->progress, d->epoch * 64, d->progress + d->plan->nsep + 1, d->done_total, st));
   } else if (ph.kind == 0) HIPCHK((hipError_t)chol_launch_potrf(d_arena, d->ws, l.potrf + ph.first, ph.n, d->info, st));
   else if (ph.kind == 1) HIPCHK((hipError_t)chol_launch_trsm(d_arena, d->ws, l.trsm + ph.first, ph.n, st));
   else if (ph.kind == 4) HIPCHK((hipError_t)chol_launch_trsm_w(d_arena, d->ws, l.trsm + ph.first, ph.n, st));

@@ -13,7 +13,8 @@ int chol_launch_scatter(double *arena, const int64_t *dst, const double *val, in
 int chol_launch_potrf(double *base, double *ws, const chol_potrf_desc *descs, int n, int *info, hipStream_t st);
 int chol_launch_potrf_big(double *base, double *ws, const chol_potrf_desc *descs, int n, int *info, hipStream_t st);
 int chol_launch_potrf_trsm(double *base, double *ws, const chol_potrf_desc *pdescs, int n_potrf, const chol_trsm_desc *tdescs, int n_trsm,
-                           int *info, int *progress, int progress_base, hipStream_t st);
+                           const chol_upd_task *tasks, const chol_upd_src *srcs, int n_task,
+                           int *info, int *progress, int progress_base, int *done, int done_target, hipStream_t st);
 int chol_launch_trsm_w(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st);
 int chol_launch_trsm_big(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st);
 int chol_launch_dinv(const double *L, int n, int ldl, double *W, hipStream_t st);

@@ -27,9 +27,40 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 
+// Data handed from one workgroup to another INSIDE a launch (fused POTRF+TRSM+update launch) is written with
+// agent-scope stores (write-through, device-coherent) and read with agent-scope loads, so that it is seen across
+// the XCDs' L2s while the kernel runs; PUB = false is a plain access.
+template <bool PUB> __device__ __forceinline__ void gstore(double *p, double v)
+{
+  if (PUB) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool PUB> __device__ __forceinline__ double gload(const double *p)
+{
+  if (PUB) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+
+// wait until a progress word written by workgroups of the same launch reaches `target` (columns published by a
+// pivot's POTRF workgroup; TRSM workgroups finished).  Producers have lower block indices than their consumers,
+// are dispatched first and never wait for a consumer; the spin is bounded all the same: after ~50 ms it
+// gives up and reports through info (the factorisation then fails loudly instead of hanging the GPU).
+__device__ __forceinline__ int wait_progress(const int *progress, int target, int seen, int *info)
+{
+  if (seen >= target) return seen;
+  int v = 0;
+  for (int it = 0; it < (1 << 16); ++it) {
+    v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (v >= target) return v;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if ((threadIdx.x & 63) == 0) atomicCAS(&info[0], 0, -7); // internal error: no progress
+  return target;
+}
 // ------------------------------------------------------------------------------------------------
 // acc(r, c) += sum_{k < K} X[r + k ldx] * Y[c + k ldy],  r < mv, c < nv (rows beyond are read as 0)
 // ------------------------------------------------------------------------------------------------
+template <bool PUB = false>
 __device__ __forceinline__ d4 rank_k_16x16(d4 acc, const double *__restrict__ X, int ldx, int mv,
                                            const double *__restrict__ Y, int ldy, int nv, int K, int lane)
 {
@@ -41,16 +72,16 @@ __device__ __forceinline__ d4 rank_k_16x16(d4 acc, const double *__restrict__ X,
   for (; k0 + 32 <= K; k0 += 32) { // eight MFMAs per trip, sixteen loads in flight
     double x[8], y[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { x[u] = vx ? px[(int64_t)(4 * u) * ldx] : 0.0; y[u] = vy ? py[(int64_t)(4 * u) * ldy] : 0.0; }
+    for (int u = 0; u < 8; ++u) { x[u] = vx ? gload<PUB>(&px[(int64_t)(4 * u) * ldx]) : 0.0; y[u] = vy ? gload<PUB>(&py[(int64_t)(4 * u) * ldy]) : 0.0; }
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y[u], x[u], acc, 0, 0, 0);
     px += 32 * (int64_t)ldx; py += 32 * (int64_t)ldy;
   }
   for (; k0 + 16 <= K; k0 += 16) { // four MFMAs per trip, eight loads in flight
-    double x0 = vx ? px[0] : 0.0, y0 = vy ? py[0] : 0.0;
-    double x1 = vx ? px[4 * (int64_t)ldx] : 0.0, y1 = vy ? py[4 * (int64_t)ldy] : 0.0;
-    double x2 = vx ? px[8 * (int64_t)ldx] : 0.0, y2 = vy ? py[8 * (int64_t)ldy] : 0.0;
-    double x3 = vx ? px[12 * (int64_t)ldx] : 0.0, y3 = vy ? py[12 * (int64_t)ldy] : 0.0;
+    double x0 = vx ? gload<PUB>(&px[0]) : 0.0, y0 = vy ? gload<PUB>(&py[0]) : 0.0;
+    double x1 = vx ? gload<PUB>(&px[4 * (int64_t)ldx]) : 0.0, y1 = vy ? gload<PUB>(&py[4 * (int64_t)ldy]) : 0.0;
+    double x2 = vx ? gload<PUB>(&px[8 * (int64_t)ldx]) : 0.0, y2 = vy ? gload<PUB>(&py[8 * (int64_t)ldy]) : 0.0;
+    double x3 = vx ? gload<PUB>(&px[12 * (int64_t)ldx]) : 0.0, y3 = vy ? gload<PUB>(&py[12 * (int64_t)ldy]) : 0.0;
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, x0, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, x1, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y2, x2, acc, 0, 0, 0);
@@ -59,7 +90,7 @@ __device__ __forceinline__ d4 rank_k_16x16(d4 acc, const double *__restrict__ X,
   }
   for (; k0 < K; k0 += 4) {
     const bool vk = k0 + kq < K;
-    double x = (vx && vk) ? px[0] : 0.0, y = (vy && vk) ? py[0] : 0.0;
+    double x = (vx && vk) ? gload<PUB>(&px[0]) : 0.0, y = (vy && vk) ? gload<PUB>(&py[0]) : 0.0;
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, acc, 0, 0, 0);
     px += 4 * (int64_t)ldx; py += 4 * (int64_t)ldy;
   }
@@ -87,33 +118,32 @@ __global__ void k_scatter(double *__restrict__ arena, const int64_t *__restrict_
 // Task ids are remapped so that consecutive tasks (sub-tiles of one target, sharing their source
 // panels) run on the same XCD and hit in its L2.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_update(double *__restrict__ base_, double *const *__restrict__ arena_slot, const chol_upd_task *__restrict__ tasks,
-                                                const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd)
+// one task = one 16x16 output sub-tile, four waves (wave = 0..3 of the task's group); sAcc = the group's LDS slots.
+// `live` = false: a placeholder that only keeps the workgroup's barrier count uniform.  `wait` (fused launch): the
+// counter of finished TRSM workgroups and the value it must reach before the sources may be read -- the task
+// descriptor and the C sub-tile are requested before that wait.
+template <bool PUB>
+__device__ __forceinline__ void update_task_body(double *__restrict__ base, const chol_upd_task t, const chol_upd_src *__restrict__ srcs, double (*sAcc)[4][64],
+                                                 int wave, int lane, bool live, const int *wait, int wait_target, int *info)
 {
-  double *const __restrict__ base = arena_slot ? *arena_slot : base_; // graph launches read the arena from a device cell
-  __shared__ double sAcc[3][4][64];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if ((blockIdx.x >> 3) >= per_xcd || tid >= ntask) return;
-  const chol_upd_task t = tasks[tid];
   // the C sub-tile is requested first (wave 0; clamped addresses, masked at the store): read at the end, each of
   // its four columns would be a memory round trip of its own on the tail of every task
   const int r = lane & 15, g = lane >> 4;
   double cv[4] = { 0.0, 0.0, 0.0, 0.0 };
   double *C = base + t.c_off;
-  if (wave == 0) {
+  if (live && wave == 0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) cv[q] = *(const volatile double *)(C + min(r, t.mv - 1) + (int64_t)min(g + 4 * q, t.nv - 1) * t.ldc);
   }
+  if (PUB && wait) (void)wait_progress(wait, wait_target, 0, info);
   d4 acc = { 0.0, 0.0, 0.0, 0.0 };
-  const int nsrc = t.src_end - t.src_begin;
+  const int nsrc = live ? t.src_end - t.src_begin : 0;
   if (nsrc >= 4) {
     // many sources (a target high in the tree collects one per descendant): the waves take whole sources
     // round-robin, so four descriptor -> operand load chains are in flight instead of one
     for (int s = t.src_begin + wave; s < t.src_end; s += 4) {
       const chol_upd_src sd = srcs[s];
-      acc = rank_k_16x16(acc, base + sd.a_off + t.ar, sd.lda, t.mv, base + sd.b_off + t.br, sd.ldb, t.nv, sd.k, lane);
+      acc = rank_k_16x16<PUB>(acc, base + sd.a_off + t.ar, sd.lda, t.mv, base + sd.b_off + t.br, sd.ldb, t.nv, sd.k, lane);
     }
   } else {
     for (int s = t.src_begin; s < t.src_end; ++s) {
@@ -122,7 +152,7 @@ __global__ __launch_bounds__(256) void k_update(double *__restrict__ base_, doub
       const int k_lo = wave * kc;
       if (k_lo < sd.k) {
         const int kn = min(kc, sd.k - k_lo);
-        acc = rank_k_16x16(acc, base + sd.a_off + t.ar + (int64_t)k_lo * sd.lda, sd.lda, t.mv,
+        acc = rank_k_16x16<PUB>(acc, base + sd.a_off + t.ar + (int64_t)k_lo * sd.lda, sd.lda, t.mv,
                            base + sd.b_off + t.br + (int64_t)k_lo * sd.ldb, sd.ldb, t.nv, kn, lane);
       }
     }
@@ -131,8 +161,8 @@ __global__ __launch_bounds__(256) void k_update(double *__restrict__ base_, doub
 #pragma unroll
     for (int q = 0; q < 4; ++q) sAcc[wave - 1][q][lane] = acc[q];
   }
-  __syncthreads();
-  if (wave == 0) {
+  lds_barrier(); // the group's partial sums are in LDS (uniform over the workgroup: one barrier per task)
+  if (live && wave == 0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int c = g + 4 * q;
@@ -140,6 +170,15 @@ __global__ __launch_bounds__(256) void k_update(double *__restrict__ base_, doub
       if (r < t.mv && c < t.nv && (!t.lower || r >= c)) C[r + (int64_t)c * t.ldc] = cv[q] - v;
     }
   }
+}
+__global__ __launch_bounds__(256) void k_update(double *__restrict__ base_, double *const *__restrict__ arena_slot, const chol_upd_task *__restrict__ tasks,
+                                                const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd)
+{
+  double *const __restrict__ base = arena_slot ? *arena_slot : base_; // graph launches read the arena from a device cell
+  __shared__ double sAcc[3][4][64];
+  const int tid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || tid >= ntask) return;
+  update_task_body<false>(base, tasks[tid], srcs, sAcc, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, true, nullptr, 0, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -505,6 +544,15 @@ __device__ __forceinline__ void tile_of_index(int idx, int T, int &ti, int &tj)
 #define RR_SLOTS 12  /* most tiles a tile wave owns: columns >= 2 of a 17 x 17 tile grid, 120 tiles (see rr_owner) */
 #define RR_RSLOTS 11 /* ... of which live in registers; slot 11 (n > 256 only, columns 2-3: dead after step 2) lives in LDS */
 #define RR_THREADS ((RR_NW + 1) * 64)
+/* LDS image of the POTRF role, in doubles */
+#define RR_OFF_SOL (RR_MAXT * TS * TS)
+#define RR_OFF_DG (RR_OFF_SOL + 2 * RR_MAXT * TS * TS)
+#define RR_OFF_LW (RR_OFF_DG + 2 * TS * TS)
+#define RR_OFF_CONV (RR_OFF_LW + 2 * 2 * TS * (TS + 1))
+#define RR_OFF_OV (RR_OFF_CONV + 2 * TS * (TS + 1))
+#define RR_OFF_IJ (RR_OFF_OV + RR_NHEAVY * TS * TS)
+#define RR_OFF_FLAG (RR_OFF_IJ + (RR_SLOTS * RR_NW + 16 + 3) / 4)
+#define RR_SMEM_DOUBLES (RR_OFF_FLAG + 4)
 // Note (measured): waves of a workgroup are dealt to the four SIMDs round-robin, so waves 0, 4 and 8
 // share a SIMD, and fp64 MFMA runs on the same DP units as fp64 VALU: the tile waves' 64-cycle MFMAs
 // on the factor wave's SIMD stretch its scalar chain (chol16 3.4k -> 4.9k cycles).  Leaving waves 4 and
@@ -548,27 +596,21 @@ __device__ __forceinline__ d4 load_tile(const double *A, int lda, int n, int ti,
   }
   return v;
 }
-// global store of the factor: plain, or -- in the fused POTRF+TRSM launch, where other workgroups read it while the
-// kernel runs -- an agent-scope (write-through, device-coherent) store
-template <bool PUB> __device__ __forceinline__ void gstore(double *p, double v)
-{
-  if (PUB) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
 template <bool PUB>
 __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double *__restrict__ ws, const chol_potrf_desc d, int *__restrict__ info,
-                                              int *__restrict__ progress, int progress_base)
+                                              int *__restrict__ progress, int progress_base, double *smem)
 {
   // tiles in LDS are stored like accumulator registers: element (r, c) at c * 16 + r, so lane (r15, g)
   // register q sits at q * 64 + lp with lp = g * 16 + r15 (conflict free, and directly an MFMA operand)
-  __shared__ double sRaw[RR_MAXT][TS * TS];    // raw (fully updated, unsolved) tiles of the next panel column
-  __shared__ double sSol[2][RR_MAXT][TS * TS]; // solved panel P of step k (parity of k)
-  __shared__ double sDg[2][TS * TS];           // diagonal tiles on their way to the factor wave (parity of j)
-  __shared__ double sLW[2][2 * TS][TS + 1];    // parity of k: rows 0-15 = L(k,k) [r][c], rows 16-31 = L(k,k)^-T [k][c] = Linv(c,k)
-  __shared__ double sConv[2 * TS][TS + 1];     // factor wave: accumulator layout -> row per lane; rows 16-31 = identity
-  __shared__ double sOv[RR_NHEAVY][TS * TS];   // slot RR_RSLOTS of the heavy waves
-  __shared__ unsigned short sIJ[RR_SLOTS * RR_NW + 16];
-  __shared__ int sFlag[8];                     // fL, fP, cSol, cUpd, cRaw, fA, fD
+  // the workgroup's LDS image (RR_SMEM_DOUBLES doubles, carved by the caller: the roles of the fused launch share it)
+  double (*const sRaw)[TS * TS] = (double (*)[TS * TS])(smem);                         // [RR_MAXT] raw (fully updated, unsolved) tiles of the next panel column
+  double (*const sSol)[RR_MAXT][TS * TS] = (double (*)[RR_MAXT][TS * TS])(smem + RR_OFF_SOL); // [2] solved panel P of step k (parity of k)
+  double (*const sDg)[TS * TS] = (double (*)[TS * TS])(smem + RR_OFF_DG);              // [2] diagonal tiles on their way to the factor wave (parity of j)
+  double (*const sLW)[2 * TS][TS + 1] = (double (*)[2 * TS][TS + 1])(smem + RR_OFF_LW); // [2] parity of k: rows 0-15 = L(k,k) [r][c], rows 16-31 = L(k,k)^-T [k][c] = Linv(c,k)
+  double (*const sConv)[TS + 1] = (double (*)[TS + 1])(smem + RR_OFF_CONV);            // [2 TS] factor wave: accumulator layout -> row per lane; rows 16-31 = identity
+  double (*const sOv)[TS * TS] = (double (*)[TS * TS])(smem + RR_OFF_OV);              // [RR_NHEAVY] slot RR_RSLOTS of the heavy waves
+  unsigned short *const sIJ = (unsigned short *)(smem + RR_OFF_IJ);                    // [RR_SLOTS * RR_NW + 16]
+  int *const sFlag = (int *)(smem + RR_OFF_FLAG);                                      // [8] fL, fP, cSol, cUpd, cRaw, fA, fD
   int *const fL = &sFlag[0], *const fP = &sFlag[1], *const cSol = &sFlag[2], *const cUpd = &sFlag[3];
   int *const cRaw = &sFlag[4]; // raw tiles parked in sRaw so far (column j contributes T - 1 - j)
   int *const fA = &sFlag[5];   // j: raw tile (j, j-1) is in sRaw[j]
@@ -854,7 +896,8 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
                                                          const chol_potrf_desc *__restrict__ descs, int *__restrict__ info)
 {
   double *const __restrict__ base = arena_slot ? *arena_slot : base_; // graph launches read the arena from a device cell
-  potrf_rr_body<false>(base, ws, descs[blockIdx.x], info, nullptr, 0);
+  __shared__ double smem[RR_SMEM_DOUBLES];
+  potrf_rr_body<false>(base, ws, descs[blockIdx.x], info, nullptr, 0, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -994,28 +1037,6 @@ __global__ __launch_bounds__(64) void k_dinv(const double *__restrict__ Lp, int 
 // memory / L2 ahead of the barrier.
 // ------------------------------------------------------------------------------------------------
 #define TRSM_SLOTS 5 /* ceil(17 / 4) */
-// loads of the factor in the fused POTRF+TRSM launch: agent-scope, so that they see what the POTRF workgroup
-// published while this kernel runs (never a stale line of this XCD's L2)
-template <bool PUB> __device__ __forceinline__ double gload(const double *p)
-{
-  if (PUB) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return *p;
-}
-// wait until the pivot's POTRF workgroup has published `target` columns.  The POTRF workgroups of a launch have the
-// lowest block indices, are dispatched first and wait for nobody; the spin is bounded all the same: after ~50 ms it
-// gives up and reports through info (the factorisation then fails loudly instead of hanging the GPU).
-__device__ __forceinline__ int wait_progress(const int *progress, int target, int seen, int *info)
-{
-  if (seen >= target) return seen;
-  int v = 0;
-  for (int it = 0; it < (1 << 16); ++it) {
-    v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (v >= target) return v;
-    __builtin_amdgcn_s_sleep(8);
-  }
-  if ((threadIdx.x & 63) == 0) atomicCAS(&info[0], 0, -7); // internal error: no progress
-  return target;
-}
 // one strip, four waves (wave = 0..3 of the strip's group); sX = the group's three LDS tiles
 template <bool PUB, int SLOTS>
 __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const double *__restrict__ ws, const chol_trsm_desc d, double (*sX)[TS * TS],
@@ -1069,7 +1090,7 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                     \
       const int col_ = (J_) * TS + g + 4 * q;                                                           \
       sX[(J_) % 3][q * 64 + lp] = x_[q];                                                                \
-      if (vrow && col_ < n) B[r15 + (int64_t)col_ * ldb] = x_[q];                                       \
+      if (vrow && col_ < n) gstore<PUB>(&B[r15 + (int64_t)col_ * ldb], x_[q]);                          \
     }                                                                                                   \
   }
 #define APPLY_X(JX_, s_)                                                                                \
@@ -1167,21 +1188,41 @@ __global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base_, dou
 #define FUSED_SLOTS ((CHOL_FUSE_MAXN / TS + 3) / 4) /* column tiles per wave of a strip: the registers of a 768-thread workgroup hold three */
 __global__ __launch_bounds__(RR_THREADS) void k_potrf_trsm(double *__restrict__ base_, double *const *__restrict__ arena_slot, double *__restrict__ ws,
                                                            const chol_potrf_desc *__restrict__ pdescs, int n_potrf,
-                                                           const chol_trsm_desc *__restrict__ tdescs, int n_trsm, int *__restrict__ info,
-                                                           int *__restrict__ progress, int progress_base)
+                                                           const chol_trsm_desc *__restrict__ tdescs, int n_trsm,
+                                                           const chol_upd_task *__restrict__ tasks, const chol_upd_src *__restrict__ srcs, int n_task, int n_upd_wg,
+                                                           int *__restrict__ info, int *__restrict__ progress, int progress_base,
+                                                           int *__restrict__ done, int done_target)
 {
   double *const __restrict__ base = arena_slot ? *arena_slot : base_;
+  __shared__ double smem[RR_SMEM_DOUBLES]; // one image, carved by the role of the workgroup
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int grp = wave >> 2;
+  const int n_tg = (n_trsm + 2) / 3;
   if ((int)blockIdx.x < n_potrf) {
-    potrf_rr_body<true>(base, ws, pdescs[blockIdx.x], info, progress + blockIdx.x, progress_base);
-  } else {
-    __shared__ double sX[3][3][TS * TS];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int grp = wave >> 2;
+    potrf_rr_body<true>(base, ws, pdescs[blockIdx.x], info, progress + blockIdx.x, progress_base, smem);
+  } else if ((int)blockIdx.x < n_potrf + n_tg) {
+    double (*sX)[3][TS * TS] = (double (*)[3][TS * TS])smem;
     const int id = ((int)blockIdx.x - n_potrf) * 3 + grp;
     // every group runs the same number of barriers: the strips of a workgroup share one pivot block
     chol_trsm_desc d = tdescs[min(id, n_trsm - 1)];
     if (id >= n_trsm) d.m = 0;
-    trsm_rr_body<true, FUSED_SLOTS>(base, ws, d, sX[grp], wave & 3, threadIdx.x & 63, progress + d.flag, progress_base, info);
+    trsm_rr_body<true, FUSED_SLOTS>(base, ws, d, sX[grp], wave & 3, lane, progress + d.flag, progress_base, info);
+    // the update workgroups of this launch read the solved strips: count this workgroup out once its stores have completed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    // update role: three tasks at a time (one per group of four waves), tasks dealt round-robin to the update
+    // workgroups; the first one waits until every TRSM workgroup of the launch has counted itself out
+    double (*sAcc)[3][3][4][64] = (double (*)[3][3][4][64])smem; // [parity of the round][group]
+    const int u = (int)blockIdx.x - n_potrf - n_tg;
+    int round = 0;
+    for (int t0 = u * 3; t0 < n_task; t0 += n_upd_wg * 3, ++round) {
+      const int tid = t0 + grp;
+      const bool live = tid < n_task;
+      update_task_body<true>(base, tasks[live ? tid : t0], srcs, sAcc[round & 1][grp], wave & 3, lane, live, round == 0 ? done : nullptr, done_target, info);
+    }
   }
 }
 
@@ -1549,11 +1590,14 @@ int chol_launch_trsm(double *base, const double *ws, const chol_trsm_desc *descs
   return (int)hipGetLastError();
 }
 int chol_launch_potrf_trsm(double *base, double *ws, const chol_potrf_desc *pdescs, int n_potrf, const chol_trsm_desc *tdescs, int n_trsm,
-                           int *info, int *progress, int progress_base, hipStream_t st)
-{ // fused launch: POTRF workgroups first (lowest block indices), then groups of three strips
+                           const chol_upd_task *tasks, const chol_upd_src *srcs, int n_task,
+                           int *info, int *progress, int progress_base, int *done, int done_target, hipStream_t st)
+{ // fused launch: POTRF workgroups first (lowest block indices), then groups of three strips, then update workgroups
   if (n_potrf <= 0) return 0;
-  hipLaunchKernelGGL(k_potrf_trsm, dim3(n_potrf + (n_trsm + 2) / 3), dim3(RR_THREADS), 0, st, base, g_arena_slot, ws, pdescs, n_potrf, tdescs, n_trsm,
-                     info, progress, progress_base);
+  int n_upd_wg = (n_task + 2) / 3;
+  if (n_upd_wg > 1024) n_upd_wg = 1024;
+  hipLaunchKernelGGL(k_potrf_trsm, dim3(n_potrf + (n_trsm + 2) / 3 + n_upd_wg), dim3(RR_THREADS), 0, st, base, g_arena_slot, ws, pdescs, n_potrf, tdescs, n_trsm,
+                     tasks, srcs, n_task, n_upd_wg, info, progress, progress_base, done, done_target);
   return (int)hipGetLastError();
 }
 int chol_launch_trsm_w(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st)

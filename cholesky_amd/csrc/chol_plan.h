@@ -56,6 +56,7 @@ typedef struct {
 
 #define CHOL_TRSM_W_MAXN 64 /* widest pivot block the one-wave-per-strip TRSM kernel takes (4 tiles); measured against k_trsm_rr: 6.6 vs 8.0 us at 32, 8.4 vs 9.6 at 64, 12.6 vs 11.1 at 128 */
 #define CHOL_FUSE_MAXN 192 /* widest pivot block of a fused POTRF+TRSM launch (12 column tiles: three per wave of a strip) */
+#define CHOL_FUSE_UPDATE_MAX 0 /* most 16x16 update tasks a fused launch carries (chol_schedule.c); measured on lapl_3375: 0/64/256 within noise (227 us), 900 -> 239, all -> 248: the role exists, a launch of its own is as fast */
 #define CHOL_TRSM_ROWS 16
 
 typedef struct {
@@ -76,8 +77,8 @@ typedef struct {
 /* one batched launch: descriptors [first, first + n) of the level's array of that kind */
 typedef struct {
   int kind;  /* 0 potrf, 1 trsm, 2 update (16x16 tasks), 3 update (64x64 macro-tile tasks), 4 trsm (every strip's pivot block <= CHOL_TRSM_W_MAXN wide),
-              * 5 fused potrf (first, n) + trsm (first2, n2) */
-  int first, n, first2, n2;
+              * 5 fused potrf (first, n) + trsm (first2, n2) + 16x16 update tasks (first3, n3) */
+  int first, n, first2, n2, first3, n3;
   /* two-stream program only (chol_build_program): the stream the launch goes to, the events (ids from 1, 0 = none)
    * it waits for and the one recorded after it */
   int lane, wait[2], record;

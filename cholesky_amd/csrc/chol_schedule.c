@@ -77,6 +77,9 @@ typedef struct { chol_level_work *w; int cap_p, cap_t, cap_k, cap_km, cap_s, cap
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
 static int split_min(void) { static int v = -1; if (v < 0) v = env_int("CHOLAMD_SPLIT_MIN", CHOL_SPLIT_MIN); return v; }
 static int split_nb(void) { static int v = -1; if (v < 0) { v = env_int("CHOLAMD_SPLIT_NB", CHOL_SPLIT_NB); if (v > CHOL_RR_MAXN) v = CHOL_RR_MAXN; v = (v + 15) / 16 * 16; if (v < 16) v = 16; } return v; }
+/* a step's 16x16 update tasks ride in its fused launch up to this many (beyond, a launch of their own with eight
+ * 256-thread workgroups per CU beats the fused launch's one 768-thread workgroup per CU) */
+static int fuse_update_max(void) { static int v = -1; if (v < 0) v = env_int("CHOLAMD_FUSE_UPDATE_MAX", CHOL_FUSE_UPDATE_MAX); return v; }
 static int pivot_blocks(int n) { return n > split_min() || n > CHOL_RR_MAXN ? (n + split_nb() - 1) / split_nb() : 1; }
 static int pivot_block_width(int n) { const int nb = pivot_blocks(n); return nb == 1 ? n : ((n + nb - 1) / nb + 15) / 16 * 16; }
 
@@ -90,7 +93,7 @@ static void push_phase(builder *B, int kind, int first, int n)
   if (n <= 0) return;
   chol_level_work *w = B->w;
   if (w->n_phase == B->cap_ph) { B->cap_ph = B->cap_ph ? 2 * B->cap_ph : 16; w->phase = realloc(w->phase, B->cap_ph * sizeof(chol_phase)); }
-  chol_phase ph = { kind, first, n, 0, 0, 0, { 0, 0 }, 0 };
+  chol_phase ph = { kind, first, n, 0, 0, 0, 0, 0, { 0, 0 }, 0 };
   w->phase[w->n_phase++] = ph;
 }
 static void push_potrf(builder *B, chol_potrf_desc d)
@@ -236,6 +239,7 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
     if (pivot_blocks(p->sep_size[s]) > steps) steps = pivot_blocks(p->sep_size[s]);
   }
   if (steps == 0) steps = 1;
+  int fused_last = -1; /* the level's last fused launch, if nothing was launched after it */
   int fuse = !getenv("CHOLAMD_NO_FUSE"); /* POTRF + TRSM of a step in one launch, if every block fits its TRSM role */
   for (int q = 0; q < nh; q++) if (pivot_block_width(p->sep_size[p->tree[hs[q]]]) > CHOL_FUSE_MAXN) fuse = 0;
   /* pivots: small ones whole in step 0; big ones in pivot_block_width()-column blocks, each step =
@@ -274,19 +278,23 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
       }
       free(runs);
     }
-    if (fuse) { /* one launch: the strips follow their pivot's POTRF column by column */
+    flush_targets(B);
+    if (fuse) { /* one launch: the strips follow their pivot's POTRF column by column, the 16x16 update tasks of the
+                 * step (trailing columns of a split pivot) wait for the strips inside the same launch */
       if (w->n_phase == B->cap_ph) { B->cap_ph = B->cap_ph ? 2 * B->cap_ph : 16; w->phase = realloc(w->phase, B->cap_ph * sizeof(chol_phase)); }
-      chol_phase ph = { 5, p0, w->n_potrf - p0, t0, w->n_trsm - t0, 0, { 0, 0 }, 0 };
-      if (ph.n > 0) w->phase[w->n_phase++] = ph;
+      const int ride = w->n_task - k0 <= fuse_update_max();
+      chol_phase ph = { 5, p0, w->n_potrf - p0, t0, w->n_trsm - t0, k0, ride ? w->n_task - k0 : 0, 0, { 0, 0 }, 0 };
+      fused_last = -1;
+      if (ph.n > 0) { fused_last = w->n_phase; w->phase[w->n_phase++] = ph; }
+      if (ph.n <= 0 || !ride) { if (w->n_task > k0) fused_last = -1; push_phase(B, 2, k0, w->n_task - k0); }
     } else {
       push_phase(B, 0, p0, w->n_potrf - p0);
       /* strips whose pivot block is narrow enough take the one-wave-per-strip kernel */
       int wide = 0;
       for (int i = t0; i < w->n_trsm; i++) if (w->trsm[i].n > CHOL_TRSM_W_MAXN) wide = 1;
       push_phase(B, wide ? 1 : 4, t0, w->n_trsm - t0);
+      push_phase(B, 2, k0, w->n_task - k0);
     }
-    flush_targets(B);
-    push_phase(B, 2, k0, w->n_task - k0);
     push_phase(B, 3, km0, w->n_task_mt - km0);
   }
   /* extend-add of the level: tuples in program order (par bottom-up, gp from par to the root, tiles i, j),
@@ -340,7 +348,12 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
       i = e;
     }
     flush_targets(B);
-    push_phase(B, 2, k0, w->n_task - k0);
+    /* the 16x16 tasks of the extend-add ride in the level's last fused launch when that one carries no tasks of
+     * its own and nothing was launched after it */
+    if (fused_last >= 0 && fused_last == w->n_phase - 1 && w->phase[fused_last].n3 == 0 && w->n_task - k0 <= fuse_update_max()) {
+      w->phase[fused_last].first3 = k0;
+      w->phase[fused_last].n3 = w->n_task - k0;
+    } else push_phase(B, 2, k0, w->n_task - k0);
     push_phase(B, 3, km0, w->n_task_mt - km0);
   }
   free(tu); free(first); free(count); free(hs); free(B->pend); B->pend = NULL; B->cap_pend = 0;
@@ -378,7 +391,7 @@ static void push_step(builder *B, int kind, int first, int n, int lane, int wait
   chol_level_work *w = B->w;
   if (n <= 0) kind = -1; /* an empty launch still carries its waits and its event */
   if (w->n_phase == B->cap_ph) { B->cap_ph = B->cap_ph ? 2 * B->cap_ph : 16; w->phase = realloc(w->phase, B->cap_ph * sizeof(chol_phase)); }
-  chol_phase ph = { kind, first, n, 0, 0, lane, { wait0, wait1 }, record };
+  chol_phase ph = { kind, first, n, 0, 0, 0, 0, lane, { wait0, wait1 }, record };
   w->phase[w->n_phase++] = ph;
 }
 /* the update launches (16x16 and macro-tile) of the targets pushed since (k0, km0) */
