@@ -34,6 +34,8 @@ struct solve_dev {
   chol_trsv_desc *trsv = nullptr;
   chol_gemv_desc *fw = nullptr, *bw = nullptr;
   int *grp_start = nullptr, *grp_rows = nullptr, *bw_start = nullptr;
+  int n_ifw = 0, n_ibw = 0, max_n = 0;
+  int *ifw = nullptr, *ibw = nullptr;
 };
 struct timed_launch { hipEvent_t a, b; int kind; };
 
@@ -44,6 +46,7 @@ struct cholamd_device {
   std::vector<solve_dev> sv;
   bool solve_ready = false;
   double *ws = nullptr;
+  double *ws_solve = nullptr; // 16x16 inverses of the diagonal blocks of the arena being solved with
   int *info = nullptr;      // [0] first failing column, [1] separator
   int *progress = nullptr;  // fused launches: columns published per pivot block (epoch * 64 + columns); [nsep + 1] = TRSM workgroups finished
   int epoch = 0, done_total = 0;
@@ -184,8 +187,8 @@ extern "C" void cholamd_device_destroy(cholamd_device *d)
   if (!d) return;
   (void)hipSetDevice(d->dev);
   free_levels(d);
-  for (auto &s : d->sv) { (void)hipFree(s.trsv); (void)hipFree(s.fw); (void)hipFree(s.bw); (void)hipFree(s.grp_start); (void)hipFree(s.grp_rows); (void)hipFree(s.bw_start); }
-  (void)hipFree(d->ws); (void)hipFree(d->info); (void)hipFree(d->progress); (void)hipFree(d->a_dst); (void)hipFree(d->a_val); (void)hipFree(d->perm); (void)hipFree(d->ytmp);
+  for (auto &s : d->sv) { (void)hipFree(s.trsv); (void)hipFree(s.fw); (void)hipFree(s.bw); (void)hipFree(s.grp_start); (void)hipFree(s.grp_rows); (void)hipFree(s.bw_start); (void)hipFree(s.ifw); (void)hipFree(s.ibw); }
+  (void)hipFree(d->ws); (void)hipFree(d->ws_solve); (void)hipFree(d->info); (void)hipFree(d->progress); (void)hipFree(d->a_dst); (void)hipFree(d->a_val); (void)hipFree(d->perm); (void)hipFree(d->ytmp);
   for (auto &t : d->tl) { d->pool.push_back(t.a); d->pool.push_back(t.b); }
   for (auto e : d->pool) (void)hipEventDestroy(e);
   for (auto e : d->prog_ev) (void)hipEventDestroy(e);
@@ -405,10 +408,14 @@ static int build_solve(cholamd_device *d)
     if (!rc) rc = upload_vec(&s.grp_start, w.grp_start, (size_t)w.n_grp + 1);
     if (!rc) rc = upload_vec(&s.grp_rows, w.grp_rows, (size_t)2 * w.n_grp);
     if (!rc) rc = upload_vec(&s.bw_start, w.bw_start, (size_t)w.n_trsv + 1);
+    s.n_ifw = w.n_ifw; s.n_ibw = w.n_ibw; s.max_n = w.max_n;
+    if (!rc) rc = upload_vec(&s.ifw, w.ifw, (size_t)2 * w.n_ifw);
+    if (!rc) rc = upload_vec(&s.ibw, w.ibw, (size_t)2 * w.n_ibw);
     chol_solve_level_free(&w);
     if (rc) return rc;
   }
   HIPCHK(hipMalloc((void **)&d->ytmp, (size_t)d->plan->n * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&d->ws_solve, (size_t)(d->plan->ws_doubles > 0 ? d->plan->ws_doubles : 1) * sizeof(double)));
   d->solve_ready = true;
   return 0;
 }
@@ -422,14 +429,32 @@ extern "C" int cholamd_solve(cholamd_device *d, const double *d_arena, const dou
   const int L = d->plan->levels, n = d->plan->n;
   double *y = d->ytmp;
   HIPCHK((hipError_t)chol_launch_permute(d_b, d->perm, y, n, 0, st));
-  for (int lvl = L - 1; lvl >= 0; lvl--) { // forward, mmat.rg:1395-1435
-    const solve_dev &s = d->sv[lvl];
-    HIPCHK((hipError_t)chol_launch_trsv_fwd(d_arena, s.trsv, s.n_trsv, y, st));
-    HIPCHK((hipError_t)chol_launch_gemv_fwd(d_arena, s.fw, s.grp_start, s.grp_rows, s.n_grp, y, st));
-  }
-  for (int lvl = 0; lvl < L; lvl++) { // backward, mmat.rg:1438-1479
-    const solve_dev &s = d->sv[lvl];
-    HIPCHK((hipError_t)chol_launch_bwd(d_arena, s.trsv, s.bw, s.bw_start, s.n_trsv, y, st));
+  if (getenv("CHOLAMD_SOLVE_REFERENCE_SHAPE")) { // the per-call kernels the BLAS-level entry points use (deterministic, slow at scale)
+    for (int lvl = L - 1; lvl >= 0; lvl--) { // forward, mmat.rg:1395-1435
+      const solve_dev &s = d->sv[lvl];
+      HIPCHK((hipError_t)chol_launch_trsv_fwd(d_arena, s.trsv, s.n_trsv, y, st));
+      HIPCHK((hipError_t)chol_launch_gemv_fwd(d_arena, s.fw, s.grp_start, s.grp_rows, s.n_grp, y, st));
+    }
+    for (int lvl = 0; lvl < L; lvl++) { // backward, mmat.rg:1438-1479
+      const solve_dev &s = d->sv[lvl];
+      HIPCHK((hipError_t)chol_launch_bwd(d_arena, s.trsv, s.bw, s.bw_start, s.n_trsv, y, st));
+    }
+  } else {
+    // the 16x16 inverses of this arena's diagonal blocks (the factorisation's workspace belongs to the last arena factored)
+    for (int lvl = 0; lvl < L; lvl++) {
+      const solve_dev &s = d->sv[lvl];
+      HIPCHK((hipError_t)chol_launch_solve_dinv(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, st));
+    }
+    for (int lvl = L - 1; lvl >= 0; lvl--) { // forward, mmat.rg:1395-1435: TRSV per separator, then its panel into the ancestors
+      const solve_dev &s = d->sv[lvl];
+      HIPCHK((hipError_t)chol_launch_solve_trsv(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, y, 0, st));
+      HIPCHK((hipError_t)chol_launch_solve_offdiag(d_arena, s.bw, s.ifw, s.n_ifw, y, 0, st));
+    }
+    for (int lvl = 0; lvl < L; lvl++) { // backward, mmat.rg:1438-1479: gather from the ancestors, then TRSV^T
+      const solve_dev &s = d->sv[lvl];
+      HIPCHK((hipError_t)chol_launch_solve_offdiag(d_arena, s.bw, s.ibw, s.n_ibw, y, 1, st));
+      HIPCHK((hipError_t)chol_launch_solve_trsv(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, y, 1, st));
+    }
   }
   HIPCHK((hipError_t)chol_launch_permute(y, d->perm, d_x, n, 1, st));
   return 0;

@@ -22,6 +22,9 @@ int chol_launch_trsm(double *base, const double *ws, const chol_trsm_desc *descs
 int chol_launch_update(double *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st);
 int chol_launch_update_mt(double *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st);
 int chol_launch_permute(const double *in, const int *perm, double *out, int n, int inverse, hipStream_t st);
+int chol_launch_solve_dinv(const double *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st);
+int chol_launch_solve_trsv(const double *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, hipStream_t st);
+int chol_launch_solve_offdiag(const double *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st);
 int chol_launch_trsv_fwd(const double *base, const chol_trsv_desc *descs, int n, double *y, hipStream_t st);
 int chol_launch_gemv_fwd(const double *base, const chol_gemv_desc *descs, const int *grp_start, const int *grp_rows, int ngroups, double *y, hipStream_t st);
 int chol_launch_bwd(const double *base, const chol_trsv_desc *descs, const chol_gemv_desc *gd, const int *gstart, int n, double *y, hipStream_t st);

@@ -1543,6 +1543,250 @@ __global__ __launch_bounds__(256) void k_bwd(const double *__restrict__ base, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// Driver-level solve (cholamd_solve) at scale.  The kernels above keep the reference's per-call shape (one
+// workgroup per separator / per 256 target rows, dependent loads per column) and serve the BLAS-level entry
+// points; on a 10^6-unknown factor they take seconds.  These stream every panel once instead:
+//   * diagonal blocks: the 16x16 inverses of all diagonal blocks are recomputed into the solve workspace
+//     (k_solve_dinv: the factorisation's workspace belongs to the last arena factored, not to this one), and
+//     the triangular solves run in 64-column block steps with the in-block work done out of LDS
+//   * off-diagonal blocks: one workgroup per row chunk of an (ancestor, separator) block, source-centric,
+//     accumulating into y with hardware fp64 atomics (the only non-deterministic summation order in the library:
+//     the solution agrees from run to run to rounding, not bit for bit)
+// ------------------------------------------------------------------------------------------------
+#define SNB 64
+__global__ __launch_bounds__(64) void k_solve_dinv(const double *__restrict__ base, const chol_trsv_desc *__restrict__ descs, double *__restrict__ W)
+{ // grid (separators of the level, 16-column blocks of the widest one)
+  __shared__ double sYd[4][TS];
+  const chol_trsv_desc d = descs[blockIdx.x];
+  const int j0 = blockIdx.y * TS;
+  if (j0 >= d.n) return;
+  const double *Lp = base + d.a_off;
+  const int n = d.n, ldl = d.lda;
+  const int lane = threadIdx.x, r15 = lane & 15, g = lane >> 4;
+  const int row = j0 + r15, b4 = r15 & ~3, qi = r15 & 3;
+  double blk[4], x[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int col = j0 + b4 + k;
+    double v = (k == qi) ? 1.0 : 0.0; // identity padding past n
+    if (row < n && col < n) v = (k <= qi) ? Lp[row + (int64_t)col * ldl] : 0.0;
+    blk[k] = v;
+  }
+  double diag = blk[0];
+  diag = (qi == 1) ? blk[1] : diag;
+  diag = (qi == 2) ? blk[2] : diag;
+  diag = (qi == 3) ? blk[3] : diag;
+  linv4_quad(blk, 1.0 / diag, x, qi);
+  if (lane < TS) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) sYd[qi][b4 + m] = x[m];
+  }
+  __syncthreads();
+  double Lr[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const int c = g + 4 * b;
+    double v = (r15 == c) ? 1.0 : 0.0;
+    if (row < n && j0 + c < n) v = (c <= r15) ? Lp[row + (int64_t)(j0 + c) * ldl] : 0.0;
+    Lr[b] = v;
+  }
+  store_linv16(W + d.dinv_off + (int64_t)blockIdx.y * TS * TS, Lr, sYd[g][r15], r15, g);
+}
+
+// y_s <- L_ss^-1 y_s (forward) or L_ss^-T y_s (backward), one workgroup per separator, 64-column block steps:
+// the block's triangle and its four 16x16 inverses go to LDS, wave 0 solves the block there, then every thread
+// folds the solved block into the rows below (forward) / the block gathers the solved rows below first (backward)
+// Only the columns [col0, col0 + SSPAN) of every separator are handled per launch: the rows below that span are folded
+// in (forward) / gathered (backward) by k_solve_panel over all CUs, so a wide separator's triangle is not streamed by
+// one workgroup.
+#define SSPAN 256
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_solve_trsv(const double *__restrict__ base, const chol_trsv_desc *__restrict__ descs, const double *__restrict__ Wall,
+                                                    double *__restrict__ y, int col0)
+{
+  __shared__ double sL[SNB][SNB + 1]; // [r][c] of the diagonal block
+  __shared__ double sW[SNB / TS][TS * TS];
+  __shared__ double sx[SNB];
+  __shared__ double sred[4][SNB];
+  const chol_trsv_desc d = descs[blockIdx.x];
+  const double *Lm = base + d.a_off;
+  const double *W = Wall + d.dinv_off;
+  double *x = y + d.x_off;
+  const int lda = d.lda, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (d.n <= col0) return;
+  const int n = min(d.n, col0 + SSPAN); // rows and columns of this launch's span
+  const int nblk = (n - col0 + SNB - 1) / SNB;
+  for (int bi = 0; bi < nblk; ++bi) {
+    const int J0 = col0 + (BWD ? nblk - 1 - bi : bi) * SNB, jb = min(SNB, n - J0);
+    // stage the block: triangle, inverses, right-hand side
+    for (int e = tid; e < SNB * SNB; e += 256) {
+      const int r = e & (SNB - 1), c = e >> 6;
+      sL[r][c] = (r < jb && c <= r) ? Lm[(J0 + r) + (int64_t)(J0 + c) * lda] : 0.0;
+    }
+    for (int e = tid; e < (SNB / TS) * TS * TS; e += 256) {
+      const int t = e >> 8;
+      if (t * TS < jb) sW[t][e & 255] = W[(int64_t)(J0 / TS + t) * TS * TS + (e & 255)];
+    }
+    if (BWD) {
+      // x_J <- x_J - L(rows below, J)^T x(rows below): wave w takes the columns w, w+4, ..., lanes stride the rows
+      for (int c = wave; c < SNB; c += 4) {
+        double acc = 0.0;
+        if (c < jb)
+          for (int i = J0 + jb + lane; i < n; i += 64) acc += Lm[i + (int64_t)(J0 + c) * lda] * x[i];
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if (lane == 0) sx[c] = (c < jb) ? x[J0 + c] - acc : 0.0;
+      }
+    } else {
+      if (tid < SNB) sx[tid] = (tid < jb) ? x[J0 + tid] : 0.0;
+    }
+    __syncthreads();
+    if (wave == 0) { // in-block solve with the 16x16 inverses, lane = row of the block
+      double v = sx[lane];
+      const int nsub = (jb + TS - 1) / TS;
+      for (int su = 0; su < nsub; ++su) {
+        const int j = BWD ? nsub - 1 - su : su, r16 = lane & 15;
+        // x_j = Linv_j v_j (forward) / Linv_j^T v_j (backward); sW[j][k * 16 + c] = Linv(c, k)
+        double xj = 0.0;
+#pragma unroll
+        for (int k = 0; k < TS; ++k) {
+          const double vk = __shfl(v, j * TS + k, 64);
+          xj += (BWD ? sW[j][r16 * TS + k] : sW[j][k * TS + r16]) * vk;
+        }
+        if ((lane >> 4) == j) v = xj;
+        // fold x_j into the rest of the block
+#pragma unroll
+        for (int k = 0; k < TS; ++k) {
+          const double xk = __shfl(v, j * TS + k, 64);
+          if (BWD) { if ((lane >> 4) < j) v -= sL[j * TS + k][lane] * xk; }
+          else { if ((lane >> 4) > j) v -= sL[lane][j * TS + k] * xk; }
+        }
+      }
+      sx[lane] = v;
+      if (lane < jb) x[J0 + lane] = v;
+    }
+    __syncthreads();
+    if (!BWD) { // rows below the block: x[r] -= L(r, J) x_J
+      for (int r = J0 + jb + tid; r < n; r += 256) {
+        double acc = 0.0;
+        for (int k = 0; k < jb; ++k) acc += Lm[r + (int64_t)(J0 + k) * lda] * sx[k];
+        x[r] -= acc;
+      }
+    }
+    __syncthreads();
+  }
+  (void)sred;
+}
+
+// rows below the span of a wide separator: forward x[r] -= L(r, span) x_span (one thread per row, deterministic);
+// backward x_span[c] -= L(rows, c)^T x[rows] for a chunk of CHOL_SOLVE_BW_ROWS rows (atomics).  grid (separators, chunks)
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_solve_panel(const double *__restrict__ base, const chol_trsv_desc *__restrict__ descs, double *__restrict__ y, int col0)
+{
+  __shared__ double sx[SSPAN];
+  const chol_trsv_desc d = descs[blockIdx.x];
+  const int r0 = col0 + SSPAN;
+  const int rows = BWD ? CHOL_SOLVE_BW_ROWS : 256;
+  if (d.n <= r0 + (int)blockIdx.y * rows) return;
+  const double *Lm = base + d.a_off;
+  double *x = y + d.x_off;
+  const int n = d.n, lda = d.lda, tid = threadIdx.x;
+  if (!BWD) {
+    sx[tid] = x[col0 + tid];
+    __syncthreads();
+    const int r = r0 + blockIdx.y * 256 + tid;
+    const double *A = Lm + min(r, n - 1) + (int64_t)col0 * lda;
+    double acc = 0.0;
+    for (int k = 0; k < SSPAN; k += 8) {
+      double a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = A[(int64_t)(k + u) * lda];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += a[u] * sx[k + u];
+    }
+    if (r < n) x[r] -= acc;
+  } else {
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int PER = CHOL_SOLVE_BW_ROWS / 64;
+    const int row0 = r0 + blockIdx.y * CHOL_SOLVE_BW_ROWS;
+    double xa[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = row0 + lane + 64 * u;
+      xa[u] = i < n ? x[i] : 0.0;
+    }
+    for (int c = wave; c < SSPAN; c += 4) {
+      const double *Ac = Lm + (int64_t)(col0 + c) * lda;
+      double a[PER];
+#pragma unroll
+      for (int u = 0; u < PER; ++u) a[u] = Ac[min(row0 + lane + 64 * u, n - 1)];
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) acc += a[u] * xa[u];
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+      if (lane == 0) unsafeAtomicAdd(&x[col0 + c], -acc);
+    }
+  }
+}
+
+// forward: y_anc[rows] -= A(rows, :) y_s for one row chunk of the block A = (anc, s); y_s staged through LDS
+__global__ __launch_bounds__(256) void k_solve_gemv_fwd(const double *__restrict__ base, const chol_gemv_desc *__restrict__ blocks, const int *__restrict__ items,
+                                                        double *__restrict__ y)
+{
+  __shared__ double sx[256];
+  const chol_gemv_desc d = blocks[items[2 * blockIdx.x]];
+  const int r = items[2 * blockIdx.x + 1] + threadIdx.x;
+  const double *A = base + d.a_off + min(r, d.m - 1);
+  const double *xs = y + d.y_off; // the separator's (already solved) part
+  double acc = 0.0;
+  for (int k0 = 0; k0 < d.n; k0 += 256) {
+    const int kb = min(256, d.n - k0);
+    __syncthreads();
+    if ((int)threadIdx.x < kb) sx[threadIdx.x] = xs[k0 + threadIdx.x];
+    __syncthreads();
+    const double *Ak = A + (int64_t)k0 * d.lda;
+    int k = 0;
+    for (; k + 8 <= kb; k += 8) {
+      double a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = Ak[(int64_t)(k + u) * d.lda];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += a[u] * sx[k + u];
+    }
+    for (; k < kb; ++k) acc += Ak[(int64_t)k * d.lda] * sx[k];
+  }
+  if (r < d.m) unsafeAtomicAdd(&y[d.x_off + r], -acc);
+}
+
+// backward: y_s[c] -= A(rows, c)^T y_anc[rows] for one row chunk of the block; every lane keeps its rows' y_anc in
+// registers, wave w takes the columns w, w+4, ...
+__global__ __launch_bounds__(256) void k_solve_gather_bwd(const double *__restrict__ base, const chol_gemv_desc *__restrict__ blocks, const int *__restrict__ items,
+                                                          double *__restrict__ y)
+{
+  const chol_gemv_desc d = blocks[items[2 * blockIdx.x]];
+  const int row0 = items[2 * blockIdx.x + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int PER = CHOL_SOLVE_BW_ROWS / 64;
+  double ya[PER];
+  const double *A = base + d.a_off;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = row0 + lane + 64 * u;
+    ya[u] = i < d.m ? y[d.x_off + i] : 0.0;
+  }
+  for (int c = wave; c < d.n; c += 4) {
+    const double *Ac = A + (int64_t)c * d.lda;
+    double a[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) a[u] = Ac[min(row0 + lane + 64 * u, d.m - 1)];
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) acc += a[u] * ya[u];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) unsafeAtomicAdd(&y[d.y_off + c], -acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers (extern "C", called from chol_api.cpp)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
@@ -1631,6 +1875,36 @@ int chol_launch_permute(const double *in, const int *perm, double *out, int n, i
   if (n <= 0) return 0;
   if (inverse) hipLaunchKernelGGL(k_permute_out, dim3((n + 255) / 256), dim3(256), 0, st, in, perm, out, n);
   else hipLaunchKernelGGL(k_permute_in, dim3((n + 255) / 256), dim3(256), 0, st, in, perm, out, n);
+  return (int)hipGetLastError();
+}
+int chol_launch_solve_dinv(const double *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st)
+{
+  if (n <= 0 || max_n <= 0) return 0;
+  hipLaunchKernelGGL(k_solve_dinv, dim3(n, (max_n + TS - 1) / TS), dim3(64), 0, st, base, descs, W);
+  return (int)hipGetLastError();
+}
+int chol_launch_solve_trsv(const double *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, hipStream_t st)
+{ // all separators of a level; wide ones in spans of SSPAN columns: diagonal span by one workgroup each, the rows below by all CUs
+  if (n <= 0) return 0;
+  const int nspan = (max_n + SSPAN - 1) / SSPAN;
+  for (int i = 0; i < nspan; i++) {
+    const int sp = backward ? nspan - 1 - i : i, col0 = sp * SSPAN;
+    const int below = max_n - (col0 + SSPAN); // rows under the span in the widest separator
+    if (backward) {
+      if (below > 0) hipLaunchKernelGGL(k_solve_panel<true>, dim3(n, (below + CHOL_SOLVE_BW_ROWS - 1) / CHOL_SOLVE_BW_ROWS), dim3(256), 0, st, base, descs, y, col0);
+      hipLaunchKernelGGL(k_solve_trsv<true>, dim3(n), dim3(256), 0, st, base, descs, W, y, col0);
+    } else {
+      hipLaunchKernelGGL(k_solve_trsv<false>, dim3(n), dim3(256), 0, st, base, descs, W, y, col0);
+      if (below > 0) hipLaunchKernelGGL(k_solve_panel<false>, dim3(n, (below + 255) / 256), dim3(256), 0, st, base, descs, y, col0);
+    }
+  }
+  return (int)hipGetLastError();
+}
+int chol_launch_solve_offdiag(const double *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st)
+{
+  if (n_items <= 0) return 0;
+  if (backward) hipLaunchKernelGGL(k_solve_gather_bwd, dim3(n_items), dim3(256), 0, st, base, blocks, items, y);
+  else hipLaunchKernelGGL(k_solve_gemv_fwd, dim3(n_items), dim3(256), 0, st, base, blocks, items, y);
   return (int)hipGetLastError();
 }
 int chol_launch_trsv_fwd(const double *base, const chol_trsv_desc *descs, int n, double *y, hipStream_t st)

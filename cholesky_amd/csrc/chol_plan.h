@@ -100,6 +100,7 @@ typedef struct {
 /* solve-phase descriptors */
 typedef struct {
   int64_t a_off; int n, lda; int x_off; int sep;
+  int64_t dinv_off; /* the separator's 16x16 diagonal-block inverses in the solve workspace */
 } chol_trsv_desc;
 typedef struct {
   int64_t a_off; int m, n, lda; int x_off, y_off; /* y(m) -= A x(n)  or  y(n) -= A^T x(m) */
@@ -151,7 +152,14 @@ typedef struct {
   int n_fw; chol_gemv_desc *fw;                     /* forward sources, grouped by target row chunk */
   int n_grp; int *grp_start; int *grp_rows;         /* grp_start[n_grp+1]; grp_rows = (row0, y_off) pairs */
   int n_bw; chol_gemv_desc *bw; int *bw_start;      /* backward sources per separator: bw_start[n_trsv+1] */
+  /* driver-level solve (cholamd_solve): the (ancestor, separator) blocks `bw` cut into row chunks, one workgroup each:
+   * (block index, first row) pairs; forward chunks of CHOL_SOLVE_FW_ROWS rows, backward of CHOL_SOLVE_BW_ROWS */
+  int n_ifw; int *ifw;
+  int n_ibw; int *ibw;
+  int max_n;                                        /* widest separator of the level */
 } chol_solve_level;
+#define CHOL_SOLVE_FW_ROWS 256
+#define CHOL_SOLVE_BW_ROWS 512
 int chol_build_solve_level(const struct cholamd_plan *p, int level, chol_solve_level *out);
 void chol_solve_level_free(chol_solve_level *w);
 void chol_set_error(const char *fmt, ...);

@@ -721,7 +721,8 @@ int chol_build_solve_level(const plan_t *p, int level, chol_solve_level *w)
   w->bw = malloc((size_t)(cnt * (level > 0 ? level : 1)) * sizeof(chol_gemv_desc));
   for (int h = h0; h <= h1; h++) {
     int s = p->tree[h];
-    chol_trsv_desc t = { p->panel_off[s], p->sep_size[s], p->panel_ld[s], p->sep_off[s], s };
+    chol_trsv_desc t = { p->panel_off[s], p->sep_size[s], p->panel_ld[s], p->sep_off[s], s, p->dinv_off[s] };
+    if (p->sep_size[s] > w->max_n) w->max_n = p->sep_size[s];
     w->bw_start[w->n_trsv] = w->n_bw;
     w->trsv[w->n_trsv++] = t;
     for (int hp = h / 2; hp >= 1; hp /= 2) {
@@ -758,12 +759,22 @@ int chol_build_solve_level(const plan_t *p, int level, chol_solve_level *w)
       }
     }
   w->grp_start[w->n_grp] = w->n_fw;
+  /* row chunks of the blocks for the source-centric kernels of the driver-level solve */
+  for (int pass = 0; pass < 2; pass++) {
+    const int rows = pass ? CHOL_SOLVE_BW_ROWS : CHOL_SOLVE_FW_ROWS;
+    int n = 0;
+    for (int i = 0; i < w->n_bw; i++) n += (w->bw[i].m + rows - 1) / rows;
+    int *it = malloc((size_t)(n > 0 ? 2 * n : 2) * sizeof(int)), k = 0;
+    for (int i = 0; i < w->n_bw; i++)
+      for (int r0 = 0; r0 < w->bw[i].m; r0 += rows) { it[2 * k] = i; it[2 * k + 1] = r0; k++; }
+    if (pass) { w->ibw = it; w->n_ibw = n; } else { w->ifw = it; w->n_ifw = n; }
+  }
   return 0;
 }
 
 void chol_solve_level_free(chol_solve_level *w)
 {
-  free(w->trsv); free(w->fw); free(w->grp_start); free(w->grp_rows); free(w->bw); free(w->bw_start);
+  free(w->trsv); free(w->fw); free(w->grp_start); free(w->grp_rows); free(w->bw); free(w->bw_start); free(w->ifw); free(w->ibw);
   memset(w, 0, sizeof *w);
 }
 

@@ -43,6 +43,10 @@ for spec in sys.argv[1:]:
     d_x = torch.empty_like(d_b)
     dev.solve(a, d_b, d_x)
     dev.sync()
+    t0 = time.perf_counter()
+    dev.solve(a, d_b, d_x)
+    dev.sync()
+    t_solve = time.perf_counter() - t0
     x = d_x.cpu().numpy()
     # residual with the generated operator: 7-point Laplacian, diag 6, off-diag -1 (natural ordering)
     X = x.reshape(n, n, n)  # index x + n (y + n z): axes (z, y, x), the operator is symmetric in them
@@ -51,5 +55,5 @@ for spec in sys.argv[1:]:
     r[:, 1:, :] -= X[:, :-1, :]; r[:, :-1, :] -= X[:, 1:, :]
     r[:, :, 1:] -= X[:, :, :-1]; r[:, :, :-1] -= X[:, :, 1:]
     res = np.linalg.norm(r.ravel() - b) / np.linalg.norm(b)
-    print(f"   factor {dt*1e3:.2f} ms = {plan.flops/dt*1e-12:.2f} TF/s of F_ref, info={info}, |Ax-b|/|b| = {res:.2e}", flush=True)
+    print(f"   factor {dt*1e3:.2f} ms = {plan.flops/dt*1e-12:.2f} TF/s of F_ref, info={info}; solve {t_solve*1e3:.2f} ms ({plan.arena_doubles*8*2/t_solve*1e-12:.2f} TB/s over the arena, twice), |Ax-b|/|b| = {res:.2e}", flush=True)
     del dev, a
