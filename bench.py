@@ -76,7 +76,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--case", default="lapl_3375x3375")
+    ap.add_argument("--case", default="lapl_3375x3375",
+                    help="a reference fixture (default: the metric's configuration) or gen:N:levels[:tile] = a generated N^3 7-point "
+                         "Laplacian with geometric nested dissection (e.g. gen:100:10, BASELINE config 5's matrix; no cpu_baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -99,9 +101,16 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
-    g = os.path.join(ROOT, "tests", "golden", args.case)
-    files = [os.path.join(g, f) for f in CASES[args.case]]
-    plan = ca.Plan(*files)
+    generated = args.case.startswith("gen:")
+    if generated:
+        parts = args.case.split(":")
+        gn, glv, gtile = int(parts[1]), int(parts[2]), int(parts[3]) if len(parts) > 3 else 64
+        files = None
+        plan = ca.Problem(gn, gn, gn, glv, gtile).plan()
+    else:
+        g = os.path.join(ROOT, "tests", "golden", args.case)
+        files = [os.path.join(g, f) for f in CASES[args.case]]
+        plan = ca.Plan(*files)
     dev = ca.Device(plan, local_rank)
     split = parallel.split_level(world)
     tail_off = parallel.tail_offset(plan, world)  # first panel of the shared top of the tree
@@ -111,7 +120,7 @@ def main():
     K, W = args.steps, args.warmup
     stream = torch.cuda.current_stream()
     per_arena = plan.arena_doubles * 8
-    n_arenas = max(1, min(K + W, int(8e9 // per_arena)))
+    n_arenas = max(1, min(K + W, int((8e9 if not generated else 4e10) // per_arena)))
     arenas = [dev.new_arena() for _ in range(n_arenas)]
 
     def refill():
@@ -132,7 +141,9 @@ def main():
 
     refill()
     done = 0
-    for _ in range(W):
+    for i in range(W):
+        if i >= n_arenas:  # a factored arena is not an input: restore before re-using one
+            refill()
         step(arenas[done % n_arenas])
         done += 1
     fence()
@@ -140,11 +151,25 @@ def main():
         refill()
         done = 0
     fence()
-    t0 = time.perf_counter()
-    for i in range(K):
-        step(arenas[(done + i) % n_arenas])
-    fence()
-    dt = time.perf_counter() - t0
+    if K <= n_arenas:
+        t0 = time.perf_counter()
+        for i in range(K):
+            step(arenas[(done + i) % n_arenas])
+        fence()
+        dt = time.perf_counter() - t0
+    else:
+        # arenas too large to hold K of them (generated problems): K steps timed one by one, the re-fill of the
+        # arena between two steps outside the timed regions
+        dt = 0.0
+        for i in range(K):
+            a = arenas[i % n_arenas]
+            if i >= n_arenas:
+                dev.fill(a, stream)
+            fence()
+            t0 = time.perf_counter()
+            step(a)
+            fence()
+            dt += time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -190,14 +215,15 @@ def main():
             "value": round(value, 3), "unit": "GF/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"tests/{args.case} (reference fixture: 7-point Laplacian, nested-dissection ordering from the fixture files)",
+            "config": {"workload": (f"generated {gn}^3 7-point Laplacian, geometric nested dissection ({glv} levels, tile {gtile}), cholamd_generate_laplacian" if generated else
+                                    f"tests/{args.case} (reference fixture: 7-point Laplacian, nested-dissection ordering from the fixture files)"),
                        "n": plan.n, "levels": plan.levels, "separators": plan.nsep, "F_ref_flops": plan.flops,
                        "B_alg_bytes": plan.alg_bytes, "parallelism": f"subtree-sharded x{world}" if world > 1 else "single GPU",
                        "factor_info": list(info)},
-            "roofline": {"bound": "mfma", "kernel": {"potrf": "k_potrf_trsm" if fused else "k_potrf_rr", "trsm": "k_trsm_rr", "update": "k_update"}[dom], "achieved": None if achieved is None else round(achieved, 5),
+            "roofline": {"bound": "mfma", "kernel": {"potrf": "k_potrf_trsm" if fused else "k_potrf_rr", "trsm": "k_trsm_rr", "update": "k_update_mt + k_update" if generated else "k_update"}[dom], "achieved": None if achieved is None else round(achieved, 5),
                          "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": None if achieved is None else round(achieved / PEAK_FP64_TFLOPS, 6),
-                         "traffic": pmc_traffic({"potrf": "k_potrf_trsm" if fused else "k_potrf_rr", "trsm": "k_trsm_rr", "update": "k_update"}[dom]) if world == 1 else None,
+                         "traffic": pmc_traffic({"potrf": "k_potrf_trsm" if fused else "k_potrf_rr", "trsm": "k_trsm_rr", "update": "k_update"}[dom]) if world == 1 and not generated else None,
                          "traffic_note": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r1/pmc_summary.json (separate rocprofv3 --pmc passes of this command); algorithmic bytes of the same launch in alg_bytes_per_launch",
                          "alg_bytes_per_launch": (alg_bytes[dom] / max(launches_per_factor, 1)) if alg_bytes[dom] else None,
                          "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": launches_per_factor,
@@ -206,7 +232,7 @@ def main():
                          "whole_step_alg_GBs": round(plan.alg_bytes * K / dt * 1e-9, 3), "hbm_peak_GBs": PEAK_HBM_GBS,
                          "kernel_ms_per_step": {k: round(timing[k][0] / reps, 5) for k in ("potrf", "trsm", "update")}},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not generated:
             out["cpu_baseline"] = cpu_baseline(files, plan.flops)
         print(json.dumps(out))
     if world > 1:
