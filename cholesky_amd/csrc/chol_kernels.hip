@@ -569,6 +569,26 @@ __device__ __forceinline__ void lds_wait_ge(int *flag, int target)
     __builtin_amdgcn_s_sleep(1);
   asm volatile("" ::: "memory"); // later LDS reads stay behind the poll (LDS executes a wave's accesses in order)
 }
+// the same, returning the value read
+__device__ __forceinline__ int lds_wait_ge_v(int *flag, int target)
+{
+  int v;
+  while ((v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) < target)
+    __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+  return v;
+}
+// two adjacent flags (8-byte aligned pair) against the same target in one LDS read
+__device__ __forceinline__ void lds_wait_both_ge(int *pair, int target)
+{
+  for (;;) {
+    const long long v = __hip_atomic_load((long long *)pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int lo = __builtin_amdgcn_readfirstlane((int)v), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    if (lo >= target && hi >= target) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ void lds_set(int *flag, int value, int lane)
 {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's LDS writes have landed
@@ -613,8 +633,8 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
   int *const sFlag = (int *)(smem + RR_OFF_FLAG);                                      // [8] fL, fP, cSol, cUpd, cRaw, fA, fD
   int *const fL = &sFlag[0], *const fP = &sFlag[1], *const cSol = &sFlag[2], *const cUpd = &sFlag[3];
   int *const cRaw = &sFlag[4]; // raw tiles parked in sRaw so far (column j contributes T - 1 - j)
-  int *const fA = &sFlag[5];   // j: raw tile (j, j-1) is in sRaw[j]
-  int *const fD = &sFlag[6];   // j: diagonal tile (j, j), updated through step j-2, is in sDg[j & 1]
+  int *const fA = &sFlag[6];   // j: raw tile (j, j-1) is in sRaw[j]
+  int *const fD = &sFlag[7];   // j: diagonal tile (j, j), updated through step j-2, is in sDg[j & 1]; (fA, fD) = one aligned 64-bit word
 
   double *A = base + d.a_off;
   double *W = ws + d.dinv_off;
@@ -627,7 +647,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
   const int lp0 = g * TS + r15;
 
   for (int t = threadIdx.x; t < RR_SLOTS * RR_NW; t += RR_THREADS) sIJ[t] = (unsigned short)0xffff;
-  if (threadIdx.x < 8) sFlag[threadIdx.x] = (threadIdx.x == 5 || threadIdx.x == 6) ? 1 : 0; // (1,0) and (1,1) are parked by the prologue
+  if (threadIdx.x < 8) sFlag[threadIdx.x] = (threadIdx.x == 6 || threadIdx.x == 7) ? 1 : 0; // (1,0) and (1,1) are parked by the prologue
   if (threadIdx.x < TS * TS) sConv[TS + (threadIdx.x >> 4)][threadIdx.x & 15] = (threadIdx.x >> 4) == (threadIdx.x & 15) ? 1.0 : 0.0;
   __syncthreads();
   // Columns 0 and 1 never live in registers (column 0 receives no update, column 1 exactly one): the
@@ -648,6 +668,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
     // ================================================================== factor wave
     __builtin_amdgcn_s_setprio(3);
     lds_wait_ge(cUpd, RR_NW); // prologue of the tile waves done: (0,0), (1,1) are in sDg, column 0 in sRaw
+    int cupd_seen = RR_NW; // last value of cUpd read
     d4 dk; // diagonal tile of the current step, accumulator layout
 #pragma unroll
     for (int q = 0; q < 4; ++q) dk[q] = sDg[0][q * 64 + lp0];
@@ -669,8 +690,9 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
         if (atomicCAS(&info[0], 0, d.col0 + k * TS + bad) == 0) info[1] = d.sep;
       }
       const int par = k & 1;
-      // sLW / sSol of this parity were last read in step k-2: every tile wave has left it
-      lds_wait_ge(cUpd, RR_NW * k);
+      // sLW / sSol of this parity were last read in step k-2: every tile wave has left it (usually known from
+      // the value read a step ago: the counter is monotonic)
+      if (cupd_seen < RR_NW * k) cupd_seen = lds_wait_ge_v(cUpd, RR_NW * k);
       if (lane < 2 * TS) {
 #pragma unroll
         for (int c = 0; c < TS; ++c) sLW[par][lane][c] = a[c]; // L: entries above the diagonal are finite junk nobody uses
@@ -679,8 +701,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       STAMPK(3);
       if (k + 1 >= T) break;
       // ---- b. the two look-ahead tiles of step k-1's trailing update are in LDS (their owners do them first)
-      lds_wait_ge(fA, k + 1);
-      lds_wait_ge(fD, k + 1);
+      lds_wait_both_ge(fA, k + 1); // fA and fD in one 64-bit poll
       STAMPK(4);
       // ---- c. solve (k+1, k) and publish it
       double wv[4];
