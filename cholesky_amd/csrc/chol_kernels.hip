@@ -784,28 +784,33 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
           double wv[4];
 #pragma unroll
           for (int st = 0; st < 4; ++st) wv[st] = sLW[par][TS + 4 * st + g][r15];
-          const int i1c = i1 < T ? i1 : i0;
-          d4 raw0, raw1, x0 = { 0.0, 0.0, 0.0, 0.0 }, x1 = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { raw0[q] = sRaw[i0][q * 64 + lp]; raw1[q] = sRaw[i1c][q * 64 + lp]; }
-#pragma unroll
-          for (int st = 0; st < 4; ++st) {
-            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[st], raw0[st], x0, 0, 0, 0);
-            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[st], raw1[st], x1, 0, 0, 0);
-          }
           const int row0 = i0 * TS + r15, row1 = i1 * TS + r15;
           double *const col = A + (int64_t)(k * TS + g) * lda;
+          d4 raw0, x0 = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            sSol[par][i0][q * 64 + lp] = x0[q];
-            if (row0 < n) gstore<PUB>(&col[row0 + (int64_t)(4 * q) * lda], x0[q]);
-          }
-          if (i1 < T) {
+          for (int q = 0; q < 4; ++q) raw0[q] = sRaw[i0][q * 64 + lp];
+          if (i1 < T) { // two tiles (pivot blocks wider than 11 tiles only), interleaved
+            d4 raw1, x1 = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+            for (int q = 0; q < 4; ++q) raw1[q] = sRaw[i1][q * 64 + lp];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+              x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[st], raw0[st], x0, 0, 0, 0);
+              x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[st], raw1[st], x1, 0, 0, 0);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               sSol[par][i1][q * 64 + lp] = x1[q];
               if (row1 < n) gstore<PUB>(&col[row1 + (int64_t)(4 * q) * lda], x1[q]);
             }
+          } else {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[st], raw0[st], x0, 0, 0, 0);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            sSol[par][i0][q * 64 + lp] = x0[q];
+            if (row0 < n) gstore<PUB>(&col[row0 + (int64_t)(4 * q) * lda], x0[q]);
           }
         }
       }
