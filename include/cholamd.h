@@ -223,10 +223,13 @@ int cholamd_device_download(cholamd_device *d, double *h_dst, const double *d_sr
 int cholamd_device_sync(cholamd_device *d, void *stream);
 /* A scatter on the device (fill_block, mmat.rg:1216-1224): zero d_arena, scatter tril(A). */
 int cholamd_device_fill(cholamd_device *d, double *d_arena, void *stream);
-/* The hot path: the whole level loop of mmat.rg:1227-1355 on d_arena, asynchronously on stream
- * (at most three kernel launches per tree level).  level_lo/level_hi restrict the loop to tree
- * levels [level_lo, level_hi] (inclusive; pass 0, levels-1 for everything) -- used by the
- * multi-GPU driver to run subtree levels and top levels separately. */
+/* The hot path: the whole level loop of mmat.rg:1227-1355 on d_arena, asynchronously on stream.  Per tree level
+ * and column-block step of its pivots: one fused POTRF+TRSM launch and the update launch(es).  level_lo/level_hi
+ * restrict the loop to tree levels [level_lo, level_hi] (inclusive; pass 0, levels-1 for everything) -- used by
+ * the multi-GPU driver to run subtree levels and top levels separately.
+ * A device object carries one workspace (diagonal-block inverses, progress words of the fused launches, info):
+ * it serves one factorisation or solve at a time; use one object per concurrent stream of work.  The arena is
+ * the caller's: any number of arenas can be factored one after the other with the same object. */
 int cholamd_factor(cholamd_device *d, double *d_arena, void *stream);
 int cholamd_factor_levels(cholamd_device *d, double *d_arena, int level_hi, int level_lo, void *stream);
 /* Restrict the schedule to the subtrees owned by `rank` of `world` (a power of two <= 2^(levels-1)):
