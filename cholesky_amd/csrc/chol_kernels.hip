@@ -58,14 +58,14 @@ __device__ __forceinline__ int wait_progress(const int *progress, int target, in
   return target;
 }
 // ------------------------------------------------------------------------------------------------
-// acc(r, c) += sum_{k < K} X[r + k ldx] * Y[c + k ldy],  r < mv, c < nv (rows beyond are read as 0)
+// acc(r, c) += sum_{k < K} X[r + k ldx] * Y[c + k ldy],  r0 <= r < mv, c0 <= c < nv (rows outside are read as 0)
 // ------------------------------------------------------------------------------------------------
 template <bool PUB = false>
 __device__ __forceinline__ d4 rank_k_16x16(d4 acc, const double *__restrict__ X, int ldx, int mv,
-                                           const double *__restrict__ Y, int ldy, int nv, int K, int lane)
-{
+                                           const double *__restrict__ Y, int ldy, int nv, int K, int lane, int r0 = 0, int c0 = 0)
+{ // rows [r0, mv) of X and [c0, nv) of Y take part
   const int r = lane & 15, kq = lane >> 4;
-  const bool vx = r < mv, vy = r < nv;
+  const bool vx = r >= r0 && r < mv, vy = r >= c0 && r < nv;
   const double *px = X + r + (int64_t)kq * ldx;
   const double *py = Y + r + (int64_t)kq * ldy;
   int k0 = 0;
@@ -143,7 +143,8 @@ __device__ __forceinline__ void update_task_body(double *__restrict__ base, cons
     // round-robin, so four descriptor -> operand load chains are in flight instead of one
     for (int s = t.src_begin + wave; s < t.src_end; s += 4) {
       const chol_upd_src sd = srcs[s];
-      acc = rank_k_16x16<PUB>(acc, base + sd.a_off + t.ar, sd.lda, t.mv, base + sd.b_off + t.br, sd.ldb, t.nv, sd.k, lane);
+      const int r0 = sd.range & 255, r1 = sd.range ? (sd.range >> 8) & 255 : t.mv, c0 = (sd.range >> 16) & 255, c1 = sd.range ? (sd.range >> 24) & 255 : t.nv;
+      acc = rank_k_16x16<PUB>(acc, base + sd.a_off + t.ar, sd.lda, r1, base + sd.b_off + t.br, sd.ldb, c1, sd.k, lane, r0, c0);
     }
   } else {
     for (int s = t.src_begin; s < t.src_end; ++s) {
@@ -152,8 +153,9 @@ __device__ __forceinline__ void update_task_body(double *__restrict__ base, cons
       const int k_lo = wave * kc;
       if (k_lo < sd.k) {
         const int kn = min(kc, sd.k - k_lo);
-        acc = rank_k_16x16<PUB>(acc, base + sd.a_off + t.ar + (int64_t)k_lo * sd.lda, sd.lda, t.mv,
-                           base + sd.b_off + t.br + (int64_t)k_lo * sd.ldb, sd.ldb, t.nv, kn, lane);
+        const int r0 = sd.range & 255, r1 = sd.range ? (sd.range >> 8) & 255 : t.mv, c0 = (sd.range >> 16) & 255, c1 = sd.range ? (sd.range >> 24) & 255 : t.nv;
+        acc = rank_k_16x16<PUB>(acc, base + sd.a_off + t.ar + (int64_t)k_lo * sd.lda, sd.lda, r1,
+                           base + sd.b_off + t.br + (int64_t)k_lo * sd.ldb, sd.ldb, c1, kn, lane, r0, c0);
       }
     }
   }

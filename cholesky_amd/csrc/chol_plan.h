@@ -60,8 +60,11 @@ typedef struct {
 #define CHOL_TRSM_ROWS 16
 
 typedef struct {
-  int64_t a_off, b_off; /* first row of the A tile rows / B tile rows used by this task */
-  int lda, ldb, k, pad;
+  int64_t a_off, b_off; /* row 0 of the task's output sub-tile in the A rows / B rows of the source */
+  int lda, ldb, k;
+  int range;            /* 0: the source covers the whole sub-tile; else r0 | r1 << 8 | c0 << 16 | c1 << 24: it covers rows
+                         * [r0, r1) x columns [c0, c1) of it only (grid-cell tasks: a 16x16 cell of the target block cuts
+                         * through the cluster tiles of the reference) */
 } chol_upd_src;
 
 typedef struct {

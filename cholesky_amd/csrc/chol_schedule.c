@@ -45,6 +45,7 @@ typedef struct {
   int64_t seq;   /* reference program order */
   int64_t c_off, a_off, b_off;
   int ldc, lda, ldb, m, n, k, syrk;
+  int bc, crow, ccol; /* the target block and the tile's first row / column inside it */
 } upd_tuple;
 
 static int cmp_tuple(const void *x, const void *y)
@@ -182,6 +183,97 @@ static void flush_targets(builder *B)
     emit_tasks(B, big && (t->m > 16 || t->n > 16), t->c_off, t->ldc, t->m, t->n, t->syrk, t->src_begin, t->src_end);
   }
   B->n_pend = 0;
+}
+
+/* Extend-add targets of a level as 16x16 GRID CELLS of the target blocks instead of the reference's cluster tiles.
+ * The fixtures' clusters are a few rows high (most C tiles of lapl_3375 are 1-2 rows by 1-16 columns): one task per
+ * 16x16 piece of a cluster tile executes 5x the useful flops and, worse, is 6 000 latency-bound tasks.  A cell collects
+ * from every source the part of its contribution that falls inside the cell (rows [r0, r1) x columns [c0, c1) of it,
+ * chol_upd_src.range); sources stay in program order, every element keeps exactly one owner.  Diagonal blocks: cells
+ * above the diagonal are skipped, diagonal cells store row >= column only (the reference skips col > row cluster
+ * pairs and runs SYRK on col == row, blas.rg:396-431: the same elements).  Returns the number of tasks. */
+typedef struct { int64_t key, seq, c_off, a_off, b_off; int ldc, lda, ldb, k, mv, nv, lower, range; } cell_piece;
+static int cmp_piece(const void *x, const void *y)
+{
+  const cell_piece *a = x, *b = y;
+  if (a->key != b->key) return a->key < b->key ? -1 : 1;
+  return a->seq < b->seq ? -1 : (a->seq > b->seq);
+}
+static int emit_cell_tasks(builder *B, const plan_t *p, const upd_tuple *tu, int ntu)
+{
+  chol_level_work *w = B->w;
+  int cap = 4 * ntu + 16, np = 0;
+  cell_piece *pc = malloc((size_t)cap * sizeof(cell_piece));
+  for (int i = 0; i < ntu; i++) {
+    const upd_tuple *u = &tu[i];
+    const chol_block *Bc = &p->blk[u->bc];
+    const int diag = Bc->r == Bc->c;
+    for (int I = u->crow / 16; I <= (u->crow + u->m - 1) / 16; I++)
+      for (int J = u->ccol / 16; J <= (u->ccol + u->n - 1) / 16; J++) {
+        if (diag && J > I) continue;
+        if (np == cap) { cap *= 2; pc = realloc(pc, (size_t)cap * sizeof(cell_piece)); }
+        cell_piece *q = &pc[np++];
+        const int r0 = (u->crow > 16 * I ? u->crow : 16 * I) - 16 * I, r1 = (u->crow + u->m < 16 * I + 16 ? u->crow + u->m : 16 * I + 16) - 16 * I;
+        const int c0 = (u->ccol > 16 * J ? u->ccol : 16 * J) - 16 * J, c1 = (u->ccol + u->n < 16 * J + 16 ? u->ccol + u->n : 16 * J + 16) - 16 * J;
+        q->key = ((int64_t)u->bc << 40) | ((int64_t)I << 20) | (int64_t)J;
+        q->seq = u->seq;
+        q->c_off = Bc->off + 16 * I + (int64_t)(16 * J) * Bc->ld; q->ldc = Bc->ld;
+        q->mv = Bc->rows - 16 * I < 16 ? Bc->rows - 16 * I : 16;
+        q->nv = Bc->cols - 16 * J < 16 ? Bc->cols - 16 * J : 16;
+        q->lower = diag && I == J;
+        /* operand rows as seen from row 0 / column 0 of the cell (only [r0, r1) / [c0, c1) are read) */
+        q->a_off = u->a_off + (16 * I - u->crow); q->lda = u->lda;
+        q->b_off = u->b_off + (16 * J - u->ccol); q->ldb = u->ldb;
+        q->k = u->k;
+        q->range = r0 | (r1 << 8) | (c0 << 16) | (c1 << 24);
+      }
+  }
+  qsort(pc, np, sizeof(cell_piece), cmp_piece);
+  int ntask = 0;
+  for (int i = 0; i < np;) {
+    int e = i + 1;
+    while (e < np && pc[e].key == pc[i].key) e++;
+    const int sb = w->n_src;
+    for (int q = i; q < e;) {
+      /* the pieces one source panel sends into this cell (one per cluster-tile pair, consecutive in program order)
+       * share their operand rows: one source entry over the bounding rows x columns.  The rows in between belong to
+       * unfilled tiles of the panel: structural zeros of L, still zero in the arena */
+      int r0 = pc[q].range & 255, r1 = (pc[q].range >> 8) & 255, c0 = (pc[q].range >> 16) & 255, c1 = (pc[q].range >> 24) & 255, f = q + 1;
+      while (f < e && pc[f].a_off == pc[q].a_off && pc[f].b_off == pc[q].b_off && pc[f].k == pc[q].k) {
+        const int a0 = pc[f].range & 255, a1 = (pc[f].range >> 8) & 255, b0 = (pc[f].range >> 16) & 255, b1 = (pc[f].range >> 24) & 255;
+        if (a0 < r0) r0 = a0;
+        if (a1 > r1) r1 = a1;
+        if (b0 < c0) c0 = b0;
+        if (b1 > c1) c1 = b1;
+        f++;
+      }
+      chol_upd_src sd = { pc[q].a_off, pc[q].b_off, pc[q].lda, pc[q].ldb, pc[q].k, r0 | (r1 << 8) | (c0 << 16) | (c1 << 24) };
+      push_src(B, sd);
+      q = f;
+    }
+    if (w->n_task == B->cap_k) { B->cap_k = B->cap_k ? 2 * B->cap_k : 256; w->task = realloc(w->task, B->cap_k * sizeof(chol_upd_task)); }
+    chol_upd_task *t = &w->task[w->n_task++];
+    memset(t, 0, sizeof *t);
+    t->c_off = pc[i].c_off; t->ldc = pc[i].ldc;
+    t->mv = (short)pc[i].mv; t->nv = (short)pc[i].nv;
+    t->lower = pc[i].lower;
+    t->src_begin = sb; t->src_end = w->n_src;
+    ntask++;
+    i = e;
+  }
+  free(pc);
+  return ntask;
+}
+/* small update phases go cell by cell, large ones (macro tiles pay) tile by tile */
+static int tuples_are_small(const upd_tuple *tu, int ntu)
+{
+  static int mt_min = -1;
+  if (mt_min < 0) mt_min = env_int("CHOLAMD_MT_MIN_TILES", CHOL_MT_MIN_TILES);
+  if (getenv("CHOLAMD_NO_CELLS")) return 0;
+  int64_t fine = 0;
+  for (int i = 0; i < ntu; i++)
+    if (i == 0 || tu[i].key != tu[i - 1].key) fine += (int64_t)((tu[i].m + 15) / 16) * ((tu[i].n + 15) / 16);
+  return fine < mt_min;
 }
 
 /* filled row runs of the ancestor blocks of panel(s): (arena offset of the run's first row in column 0
@@ -328,6 +420,7 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
             u->b_off = Bb->off + (fb_->lo_x - Bb->lo_x); u->ldb = Bb->ld;
             u->m = fa->hi_x - fa->lo_x + 1; u->n = fb_->hi_x - fb_->lo_x + 1; u->k = n;
             u->syrk = (gp == par && fb_->cluster == fa->cluster);
+            u->bc = bc; u->crow = crow; u->ccol = ccol;
           }
         }
       }
@@ -336,6 +429,8 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
   qsort(tu, ntu, sizeof(upd_tuple), cmp_tuple);
   {
     const int k0 = w->n_task, km0 = w->n_task_mt;
+    if (tuples_are_small(tu, ntu)) emit_cell_tasks(B, p, tu, ntu);
+    else
     for (int i = 0; i < ntu;) {
       int e = i + 1;
       while (e < ntu && tu[e].key == tu[i].key) e++;
@@ -407,10 +502,11 @@ static void push_update_steps(builder *B, int k0, int km0, int lane, int wait0, 
   else push_step(B, 2, k0, nf, lane, wait0, wait1, record);
 }
 /* sort tuples by target, emit one target per group with its sources in (seq) order */
-static void emit_tuple_targets(builder *B, tuple_vec *t)
+static void emit_tuple_targets(builder *B, const plan_t *p, tuple_vec *t)
 {
   chol_level_work *w = B->w;
   qsort(t->v, t->n, sizeof(upd_tuple), cmp_tuple);
+  if (tuples_are_small(t->v, t->n)) { emit_cell_tasks(B, p, t->v, t->n); return; }
   for (int i = 0; i < t->n;) {
     int e = i + 1;
     while (e < t->n && t->v[e].key == t->v[i].key) e++;
@@ -467,6 +563,7 @@ int chol_build_program(const plan_t *p, chol_level_work *w, int *n_event)
               u.b_off = Bb->off + (fb_->lo_x - Bb->lo_x); u.ldb = Bb->ld;
               u.m = fa->hi_x - fa->lo_x + 1; u.n = fb_->hi_x - fb_->lo_x + 1; u.k = n;
               u.syrk = (gp == par && fb_->cluster == fa->cluster);
+              u.bc = bc; u.crow = crow; u.ccol = ccol;
               if (hp != h / 2) tv_push(&far[p->level_of[par] * L + level], &u);
               else if (hg == hp) tv_push(&crit[level], &u);
               else tv_push(&next[level], &u);
@@ -492,7 +589,7 @@ int chol_build_program(const plan_t *p, chol_level_work *w, int *n_event)
       tuple_vec *f = &far[(level - 1) * L + src];
       if (f->n == 0) continue;
       const int k0 = w->n_task, km0 = w->n_task_mt;
-      emit_tuple_targets(B, f);
+      emit_tuple_targets(B, p, f);
       ev_far = ++nev;
       push_update_steps(B, k0, km0, 1, 0, 0, ev_far);
       ev_last_bulk = ev_far;
@@ -604,13 +701,13 @@ int chol_build_program(const plan_t *p, chol_level_work *w, int *n_event)
       /* lane 0: the parents' diagonal blocks, after the far contributions to the same blocks */
       if (crit[level].n > 0) {
         const int k0 = w->n_task, km0 = w->n_task_mt;
-        emit_tuple_targets(B, &crit[level]);
+        emit_tuple_targets(B, p, &crit[level]);
         push_update_steps(B, k0, km0, 0, ev_far, 0, 0);
       } else if (ev_far) push_step(B, -1, 0, 0, 0, ev_far, 0, 0);
       /* lane 1: the other blocks of column level level-1 (rows of the far ancestors x rows of the parent) */
       if (next[level].n > 0) {
         const int k0 = w->n_task, km0 = w->n_task_mt;
-        emit_tuple_targets(B, &next[level]);
+        emit_tuple_targets(B, p, &next[level]);
         const int ev_n = ++nev;
         push_update_steps(B, k0, km0, 1, ev_tc_last, 0, ev_n);
         ev_last_bulk = ev_n;
