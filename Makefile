@@ -27,7 +27,7 @@ $(OUT)/chol_api.o: $(CSRC)/chol_api.cpp $(CSRC)/chol_plan.h $(CSRC)/chol_kernels
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
 $(OUT)/libcholamd.so: $(HOST_OBJS) $(HIP_OBJS)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 
 $(BIN)/cholamd_mmat: $(CSRC)/mmat_main.c $(OUT)/libcholamd.so include/cholamd.h
 	@mkdir -p $(BIN)

@@ -12,13 +12,18 @@ value = F_ref * K / t, F_ref = the reference's own BLAS-call flop count (SURVEY 
 N > 1: the SAME factorisation is sharded by subtrees of the separator tree (strong scaling): rank g
 factors the subtrees below tree level log2(N), the extend-add contributions to the shared top of
 the tree are summed with one RCCL all-reduce over the contiguous tail of the arena, then every
-rank factors the top levels.
+rank factors the top levels -- one C-ABI call per rank and step (cholamd_factor_sharded).
+`--gpus N` without a launcher (WORLD_SIZE unset) starts the N rank processes itself, as children,
+before anything touches the GPU; a world size that differs from --gpus is an error, never a silent
+single-GPU run.
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -71,6 +76,18 @@ def cpu_baseline(files, flops, budget_s=12.0):
     }
 
 
+def launch_ranks(n):
+    """--gpus n without a launcher: start n fresh rank processes (torch.distributed.run, one per GPU) as children of
+    this process, which has not touched the GPU, and return their exit code."""
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +98,11 @@ def main():
                          "Laplacian with geometric nested dissection (e.g. gen:100:10, BASELINE config 5's matrix; no cpu_baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1 or args.gpus & (args.gpus - 1):
+        sys.exit("bench.py: --gpus must be a power of two (the separator tree is cut at level log2(gpus))")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))  # nothing has touched the GPU in this process
 
     import torch
     import torch.distributed as dist
@@ -91,15 +113,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a mislabelled run")
+    if torch.cuda.device_count() < max(world, 1):  # counting devices does not initialise the GPU
+        sys.exit(f"bench.py: --gpus {args.gpus} needs {world} visible GPUs, found {torch.cuda.device_count()}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if dist.get_world_size() != args.gpus:
+            sys.exit(f"bench.py: process group of {dist.get_world_size()} ranks for --gpus {args.gpus}")
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     generated = args.case.startswith("gen:")
     if generated:
@@ -114,8 +139,10 @@ def main():
     dev = ca.Device(plan, local_rank)
     split = parallel.split_level(world)
     tail_off = parallel.tail_offset(plan, world)  # first panel of the shared top of the tree
+    comm = None
     if world > 1:
         dev.set_partition(rank, world)
+        comm = parallel.make_comm(dev, world, rank)  # libcholamd's own RCCL communicator (unique id broadcast by the process group)
 
     K, W = args.steps, args.warmup
     stream = torch.cuda.current_stream()
@@ -131,7 +158,7 @@ def main():
     def step(a):
         # world > 1: local subtree levels, ONE RCCL all-reduce of the arena tail (extend-add
         # contributions to the shared ancestors), then the top levels
-        parallel.factor_sharded(dev, a, world, tail_off, stream)
+        parallel.factor_sharded(dev, a, world, tail_off, stream, comm=comm)
 
     def fence():
         torch.cuda.synchronize()
@@ -174,7 +201,14 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    info = dev.info()
+    info = dev.info()  # raises on a negative (internal) code: no line is printed for a failed factorisation
+    if world > 1:
+        bad = torch.tensor([1.0 if info[0] != 0 else 0.0], device="cuda")
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if bad.item() != 0:
+            sys.exit(f"bench.py: factorisation failed on some rank (rank {rank}: info {info})")
+    elif info[0] != 0:
+        sys.exit(f"bench.py: factorisation failed: info {info}")
 
     # dominant-kernel roofline: HIP events recorded by the library around every launch, on the
     # stream the kernels run on, in a separate pass over pre-filled arenas
@@ -214,7 +248,8 @@ def main():
             "metric": "fp64 factorization GF/s (numeric level loop, F_ref flops) on 3-D Laplacian",
             "value": round(value, 3), "unit": "GF/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic (generated Laplacian, ordering and clusters)" if generated else "reference fixture (matrix, ordering and cluster files from the reference's tests/, copied as data); no random data anywhere",
             "config": {"workload": (f"generated {gn}^3 7-point Laplacian, geometric nested dissection ({glv} levels, tile {gtile}), cholamd_generate_laplacian" if generated else
                                     f"tests/{args.case} (reference fixture: 7-point Laplacian, nested-dissection ordering from the fixture files)"),
                        "n": plan.n, "levels": plan.levels, "separators": plan.nsep, "F_ref_flops": plan.flops,

@@ -8,7 +8,7 @@ torch.distributed (RCCL).  Nothing here computes on the CPU.
 """
 from ._lib import CholamdError, Filled, Op, Region, load  # noqa: F401
 from .plan import Plan, Problem  # noqa: F401
-from .device import Device  # noqa: F401
+from .device import Comm, Device  # noqa: F401
 from . import blas  # noqa: F401
 
-__all__ = ["Plan", "Problem", "Device", "blas", "CholamdError", "Filled", "Op", "Region", "load"]
+__all__ = ["Plan", "Problem", "Device", "Comm", "blas", "CholamdError", "Filled", "Op", "Region", "load"]

@@ -91,12 +91,22 @@ def load():
     L.cholamd_plan_arena_to_dense.argtypes = [vp, vp, vp]
     L.cholamd_plan_fill_host_part.argtypes = [vp, vp, ci, ci, C.POINTER(i64)]
     L.cholamd_plan_level_work_counts.argtypes = [vp, ci, ci, ci, vp]
-    L.cholamd_plan_program_check.argtypes = [vp]
     L.cholamd_plan_write_matrix.argtypes = [vp, vp, C.c_char_p, ci]
     L.cholamd_plan_write_debug_log.argtypes = [vp, vp]
     L.cholamd_device_create.argtypes = [vp, ci, C.POINTER(vp)]
     L.cholamd_device_destroy.argtypes = [vp]
     L.cholamd_device_set_partition.argtypes = [vp, ci, ci]
+    L.cholamd_device_set_option.argtypes = [vp, C.c_char_p, ci]
+    L.cholamd_comm_unique_id.argtypes = [vp]
+    L.cholamd_comm_create.argtypes = [vp, ci, ci, vp, C.POINTER(vp)]
+    L.cholamd_comm_adopt.argtypes = [vp, ci, ci, C.POINTER(vp)]
+    L.cholamd_comm_destroy.argtypes = [vp]
+    L.cholamd_comm_destroy.restype = None
+    L.cholamd_comm_allreduce.argtypes = [vp, vp, i64, vp]
+    L.cholamd_device_tail_offset.argtypes = [vp]
+    L.cholamd_device_tail_offset.restype = i64
+    L.cholamd_exchange_tail.argtypes = [vp, vp, vp, vp]
+    L.cholamd_factor_sharded.argtypes = [vp, vp, vp, vp]
     L.cholamd_device_alloc.argtypes = [vp, i64, C.POINTER(vp)]
     L.cholamd_device_free.argtypes = [vp, vp]
     L.cholamd_device_upload.argtypes = [vp, vp, vp, i64, vp]
@@ -109,6 +119,7 @@ def load():
     L.cholamd_solve.argtypes = [vp, vp, vp, vp, vp]
     L.cholamd_device_set_timing.argtypes = [vp, ci]
     L.cholamd_device_get_timing.argtypes = [vp, vp, vp]
+    L.cholamd_device_event_overhead.argtypes = [vp, vp, C.POINTER(C.c_float)]
     RP, FP = C.POINTER(Region), C.POINTER(Filled)
     L.cholamd_fused_dpotrf.argtypes = [RP, FP, ci, ci, ci, ci, vp]
     L.cholamd_fused_dtrsm.argtypes = [RP, RP, FP, ci, FP, ci, ci, ci, ci, vp]

@@ -2,10 +2,12 @@
 // BLAS-level entry points.  Compiled with hipcc; everything exported is extern "C" (include/cholamd.h).
 // There is no CPU fallback: every compute entry point needs a HIP device and fails loudly otherwise.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "chol_kernels.h"
@@ -54,18 +56,9 @@ struct cholamd_device {
   bool timing = false;
   std::vector<timed_launch> tl;
   std::vector<hipEvent_t> pool;
-  // the two-stream program of the whole factorisation (single GPU; chol_build_program)
-  level_dev prog;
-  std::vector<hipEvent_t> prog_ev; // [id], id 0 unused
-  hipStream_t bulk = nullptr;      // lane 1
-  bool prog_ready = false;
-  // ... captured once into a HIP graph: one hipGraphLaunch per factorisation instead of ~45 launches and as many
-  // event calls (which take longer on the host than the factorisation on the GPU).  The kernels of the graph read
-  // the arena pointer from a device cell, written by a one-thread kernel ahead of the graph launch.
-  hipStream_t cap = nullptr;       // capture origin (lane 0 while capturing)
-  double **arena_slot = nullptr;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
+  // switches, read from the environment once at cholamd_device_create (cholamd_device_set_option changes them later)
+  chol_sched_opts opt;
+  bool solve_reference_shape = false; // cholamd_solve with the per-call (deterministic) kernels of the BLAS-level entry points
 };
 
 static int no_device_error()
@@ -99,10 +92,6 @@ static void free_levels(cholamd_device *d)
 {
   for (auto &l : d->lv) free_level(l);
   d->lv.clear();
-  free_level(d->prog);
-  d->prog_ready = false;
-  if (d->graph_exec) { (void)hipGraphExecDestroy(d->graph_exec); d->graph_exec = nullptr; }
-  if (d->graph) { (void)hipGraphDestroy(d->graph); d->graph = nullptr; }
 }
 static int upload_level(level_dev &l, const chol_level_work &w)
 {
@@ -123,34 +112,11 @@ static int build_levels(cholamd_device *d)
   d->lv.resize(L);
   for (int lvl = 0; lvl < L; lvl++) {
     chol_level_work w;
-    int rc = chol_build_level_work(d->plan, lvl, d->rank, d->world, &w);
+    int rc = chol_build_level_work(d->plan, &d->opt, lvl, d->rank, d->world, &w);
     if (rc) return rc;
     rc = upload_level(d->lv[lvl], w);
     chol_level_work_free(&w);
     if (rc) return rc;
-  }
-  // single GPU: the same factorisation as one list of launches on two streams (the per-level lists above stay for
-  // level ranges, the partitioned run and the timed run).
-  // Opt-in (CHOLAMD_OVERLAP=1).  Measured on MI355X: lapl_3375 291 us against 241 us level by level -- its TRSM /
-  // update launches are latency-bound (5-10 us each whatever their size), so taking work off them shortens nothing
-  // and the graph's cross-queue edges cost more than in-stream launches; generated 24^3 / 32^3 / 40^3 Laplacians
-  // +15 % / +5 % / -6 %.
-  if (d->world == 1 && getenv("CHOLAMD_OVERLAP")) {
-    chol_level_work w;
-    int nev = 0;
-    int rc = chol_build_program(d->plan, &w, &nev);
-    if (!rc) rc = upload_level(d->prog, w);
-    chol_level_work_free(&w);
-    if (rc) return rc;
-    while ((int)d->prog_ev.size() < nev + 1) {
-      hipEvent_t e;
-      HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      d->prog_ev.push_back(e);
-    }
-    if (!d->bulk) HIPCHK(hipStreamCreateWithFlags(&d->bulk, hipStreamNonBlocking));
-    if (!d->cap) HIPCHK(hipStreamCreateWithFlags(&d->cap, hipStreamNonBlocking));
-    if (!d->arena_slot) HIPCHK(hipMalloc((void **)&d->arena_slot, sizeof(double *)));
-    d->prog_ready = true;
   }
   return 0;
 }
@@ -165,6 +131,8 @@ extern "C" int cholamd_device_create(const cholamd_plan *plan, int device_id, ch
   HIPCHK(hipSetDevice(device_id));
   cholamd_device *d = new cholamd_device();
   d->plan = plan; d->dev = device_id;
+  chol_sched_opts_from_env(&d->opt);
+  { const char *e = getenv("CHOLAMD_SOLVE_REFERENCE_SHAPE"); d->solve_reference_shape = e && *e && atoi(e) != 0; }
   int rc = build_levels(d);
   if (!rc) {
     hipError_t e = hipMalloc((void **)&d->ws, (size_t)(plan->ws_doubles > 0 ? plan->ws_doubles : 1) * sizeof(double));
@@ -191,10 +159,6 @@ extern "C" void cholamd_device_destroy(cholamd_device *d)
   (void)hipFree(d->ws); (void)hipFree(d->ws_solve); (void)hipFree(d->info); (void)hipFree(d->progress); (void)hipFree(d->a_dst); (void)hipFree(d->a_val); (void)hipFree(d->perm); (void)hipFree(d->ytmp);
   for (auto &t : d->tl) { d->pool.push_back(t.a); d->pool.push_back(t.b); }
   for (auto e : d->pool) (void)hipEventDestroy(e);
-  for (auto e : d->prog_ev) (void)hipEventDestroy(e);
-  if (d->bulk) (void)hipStreamDestroy(d->bulk);
-  if (d->cap) (void)hipStreamDestroy(d->cap);
-  (void)hipFree(d->arena_slot);
   delete d;
 }
 
@@ -207,6 +171,22 @@ extern "C" int cholamd_device_set_partition(cholamd_device *d, int rank, int wor
   }
   d->rank = rank; d->world = world;
   return build_levels(d);
+}
+
+extern "C" int cholamd_device_set_option(cholamd_device *d, const char *name, int value)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  const std::string n(name ? name : "");
+  bool rebuild = true;
+  if (n == "split_min") d->opt.split_min = value;
+  else if (n == "split_nb") d->opt.split_nb = value;
+  else if (n == "fuse") d->opt.fuse = value != 0;
+  else if (n == "fuse_update_max") d->opt.fuse_update_max = value;
+  else if (n == "mt_min_tiles") d->opt.mt_min_tiles = value;
+  else if (n == "cells") d->opt.cells = value != 0;
+  else if (n == "solve_reference_shape") { d->solve_reference_shape = value != 0; rebuild = false; }
+  else { chol_set_error("unknown option '%s'", n.c_str()); return CHOLAMD_ERR_ARG; }
+  return rebuild ? build_levels(d) : 0;
 }
 
 extern "C" int cholamd_device_alloc(cholamd_device *d, int64_t doubles, double **dptr)
@@ -303,13 +283,32 @@ extern "C" int cholamd_device_get_timing(cholamd_device *d, float ms_by_kind[4],
   return 0;
 }
 
+extern "C" int cholamd_device_event_overhead(cholamd_device *d, void *stream, float *ms_out)
+{ // what a (record, record) pair with NOTHING between reads on this stream: the share of every timed launch above that is
+  // the event commands themselves, not the kernel (bench.py subtracts it)
+  HIPCHK(hipSetDevice(d->dev));
+  hipStream_t st = (hipStream_t)stream;
+  const int reps = 64;
+  std::vector<hipEvent_t> ev(2 * reps);
+  for (auto &e : ev) e = get_event(d);
+  for (int i = 0; i < reps; i++) { HIPCHK(hipEventRecord(ev[2 * i], st)); HIPCHK(hipEventRecord(ev[2 * i + 1], st)); }
+  HIPCHK(hipStreamSynchronize(st));
+  double acc = 0.0;
+  for (int i = 0; i < reps; i++) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); acc += ms; }
+  for (auto e : ev) d->pool.push_back(e);
+  *ms_out = (float)(acc / reps);
+  return 0;
+}
+
 // ---- the hot path ---------------------------------------------------------------------------
 static int launch_phase(cholamd_device *d, const level_dev &l, const chol_phase &ph, double *d_arena, hipStream_t st)
 {
   if (ph.kind == 5) {
-    if (d->epoch >= (1 << 24)) { HIPCHK(hipMemsetAsync(d->progress, 0, (size_t)(d->plan->nsep + 2) * sizeof(int), st)); d->epoch = 0; d->done_total = 0; }
+    // the progress words (epoch * 64 + columns) and the count of finished TRSM workgroups are monotonic across launches:
+    // both start over, in stream order, long before either can wrap
+    if (d->epoch >= (1 << 24) || d->done_total >= (1 << 30)) { HIPCHK(hipMemsetAsync(d->progress, 0, (size_t)(d->plan->nsep + 2) * sizeof(int), st)); d->epoch = 0; d->done_total = 0; }
     d->epoch++;
-    d->done_total += (ph.n2 + 2) / 3; // TRSM workgroups of this launch
+    if (ph.n3 > 0) d->done_total += (ph.n2 + 2) / 3; // TRSM workgroups of this launch count themselves out only when update tasks ride along
     HIPCHK((hipError_t)chol_launch_potrf_trsm(d_arena, d->ws, l.potrf + ph.first, ph.n, l.trsm + ph.first2, ph.n2, l.task + ph.first3, l.src, ph.n3,
                                               d->info, d->progress, d->epoch * 64, d->progress + d->plan->nsep + 1, d->done_total, st));
   } else if (ph.kind == 0) HIPCHK((hipError_t)chol_launch_potrf(d_arena, d->ws, l.potrf + ph.first, ph.n, d->info, st));
@@ -337,50 +336,9 @@ extern "C" int cholamd_factor_levels(cholamd_device *d, double *d_arena, int lev
   }
   return 0;
 }
-// the two-stream program on (lane0, lane1); the kernels take the arena from `d_arena`, or from the device cell when
-// chol_launch_set_arena_slot() is in force
-static int run_program(cholamd_device *d, double *d_arena, hipStream_t lane0, hipStream_t lane1)
-{
-  hipStream_t lane[2] = { lane0, lane1 };
-  HIPCHK(hipMemsetAsync(d->info, 0, 2 * sizeof(int), lane[0]));
-  for (const chol_phase &ph : d->prog.phase) {
-    hipStream_t st = lane[ph.lane];
-    for (int i = 0; i < 2; i++)
-      if (ph.wait[i] > 0) HIPCHK(hipStreamWaitEvent(st, d->prog_ev[ph.wait[i]], 0));
-    int rc = launch_phase(d, d->prog, ph, d_arena, st);
-    if (rc) return rc;
-    if (ph.record > 0) HIPCHK(hipEventRecord(d->prog_ev[ph.record], st));
-  }
-  return 0;
-}
-static int capture_program(cholamd_device *d)
-{
-  HIPCHK(hipStreamBeginCapture(d->cap, hipStreamCaptureModeThreadLocal));
-  chol_launch_set_arena_slot(d->arena_slot);
-  int rc = run_program(d, nullptr, d->cap, d->bulk);
-  chol_launch_set_arena_slot(nullptr);
-  hipGraph_t g = nullptr;
-  hipError_t e = hipStreamEndCapture(d->cap, &g);
-  if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
-  HIPCHK(e);
-  d->graph = g;
-  HIPCHK(hipGraphInstantiate(&d->graph_exec, d->graph, nullptr, nullptr, 0));
-  return 0;
-}
 extern "C" int cholamd_factor(cholamd_device *d, double *d_arena, void *stream)
 {
-  if (!d->prog_ready || d->timing) return cholamd_factor_levels(d, d_arena, d->plan->levels - 1, 0, stream);
-  HIPCHK(hipSetDevice(d->dev));
-  static const int mode = getenv("CHOLAMD_ONE_LANE") ? 1 : getenv("CHOLAMD_NO_GRAPH") ? 2 : 0;
-  if (mode == 1) return run_program(d, d_arena, (hipStream_t)stream, (hipStream_t)stream); // debugging aid: program order on one stream
-  if (mode == 2) return run_program(d, d_arena, (hipStream_t)stream, d->bulk);             // the two streams, launch by launch
-  if (!d->graph_exec) {
-    int rc = capture_program(d);
-    if (rc) return rc;
-  }
-  HIPCHK((hipError_t)chol_launch_set_slot(d->arena_slot, d_arena, (hipStream_t)stream));
-  HIPCHK(hipGraphLaunch(d->graph_exec, (hipStream_t)stream));
-  return 0;
+  return cholamd_factor_levels(d, d_arena, d->plan->levels - 1, 0, stream);
 }
 extern "C" int cholamd_factor_info(cholamd_device *d, int *sep_out)
 {
@@ -388,6 +346,9 @@ extern "C" int cholamd_factor_info(cholamd_device *d, int *sep_out)
   int h[2] = { 0, 0 };
   HIPCHK(hipMemcpy(h, d->info, sizeof h, hipMemcpyDeviceToHost));
   if (sep_out) *sep_out = h[1];
+  if (h[0] == CHOLAMD_ERR_STALL)
+    chol_set_error("factorisation stalled: a workgroup of a fused launch waited ~50 ms for a progress word of the same launch and gave up; the factor is not valid");
+  else if (h[0] < 0) chol_set_error("factorisation failed with internal code %d", h[0]);
   return h[0];
 }
 
@@ -423,13 +384,12 @@ static int build_solve(cholamd_device *d)
 extern "C" int cholamd_solve(cholamd_device *d, const double *d_arena, const double *d_b, double *d_x, void *stream)
 {
   HIPCHK(hipSetDevice(d->dev));
-  if (d->world != 1) { chol_set_error("cholamd_solve needs the complete factor on one device (partition world must be 1)"); return CHOLAMD_ERR_ARG; }
   if (!d->solve_ready) { int rc = build_solve(d); if (rc) return rc; }
   hipStream_t st = (hipStream_t)stream;
   const int L = d->plan->levels, n = d->plan->n;
   double *y = d->ytmp;
   HIPCHK((hipError_t)chol_launch_permute(d_b, d->perm, y, n, 0, st));
-  if (getenv("CHOLAMD_SOLVE_REFERENCE_SHAPE")) { // the per-call kernels the BLAS-level entry points use (deterministic, slow at scale)
+  if (d->solve_reference_shape) { // the per-call kernels the BLAS-level entry points use (deterministic, slow at scale)
     for (int lvl = L - 1; lvl >= 0; lvl--) { // forward, mmat.rg:1395-1435
       const solve_dev &s = d->sv[lvl];
       HIPCHK((hipError_t)chol_launch_trsv_fwd(d_arena, s.trsv, s.n_trsv, y, st));
@@ -937,4 +897,149 @@ extern "C" void cholamd_cblas_dgemv(int layout, int trans, int m, int n, double 
   if (!rc && hipMemcpy(y, xy + lx, (size_t)ly * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = CHOLAMD_ERR_HIP;
   (void)hipFree(xy);
   g_blas_status = rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU: subtree sharding + ONE extend-add exchange over RCCL.
+// The separator tree is cut at level d = log2(world): rank g owns the subtrees under its level-d separator and
+// factors them locally; contributions to the shared top of the tree accumulate in the rank's own copy of the
+// arena tail (the top panels are the contiguous tail of the arena: chol_plan.h); one ncclAllReduce(sum) over
+// that tail is the exchange; the top levels follow on every rank.
+// ---------------------------------------------------------------------------------------------
+struct cholamd_comm {
+  ncclComm_t comm = nullptr;
+  int world = 1, rank = 0;
+  bool owned = true;
+};
+#define NCCLCHK(call)                                                                                 \
+  do {                                                                                                \
+    ncclResult_t r_ = (call);                                                                         \
+    if (r_ != ncclSuccess) {                                                                          \
+      chol_set_error("%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__);     \
+      return CHOLAMD_ERR_COMM;                                                                        \
+    }                                                                                                 \
+  } while (0)
+
+extern "C" int cholamd_comm_unique_id(char id[CHOLAMD_UNIQUE_ID_BYTES])
+{
+  static_assert(sizeof(ncclUniqueId) <= CHOLAMD_UNIQUE_ID_BYTES, "unique id size");
+  ncclUniqueId u;
+  NCCLCHK(ncclGetUniqueId(&u));
+  std::memset(id, 0, CHOLAMD_UNIQUE_ID_BYTES);
+  std::memcpy(id, &u, sizeof u);
+  return 0;
+}
+extern "C" int cholamd_comm_create(cholamd_device *d, int world, int rank, const char id[CHOLAMD_UNIQUE_ID_BYTES], cholamd_comm **out)
+{
+  *out = nullptr;
+  if (world < 1 || rank < 0 || rank >= world) { chol_set_error("bad communicator rank %d of %d", rank, world); return CHOLAMD_ERR_ARG; }
+  HIPCHK(hipSetDevice(d->dev));
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof u);
+  cholamd_comm *c = new cholamd_comm();
+  c->world = world; c->rank = rank;
+  ncclResult_t r = ncclCommInitRank(&c->comm, world, u, rank);
+  if (r != ncclSuccess) { chol_set_error("ncclCommInitRank failed: %s", ncclGetErrorString(r)); delete c; return CHOLAMD_ERR_COMM; }
+  *out = c;
+  return 0;
+}
+extern "C" int cholamd_comm_create_all(cholamd_device *const *devs, int n, cholamd_comm **out)
+{ // one process driving n devices (cholamd_mmat --gpus n)
+  if (n < 1) { chol_set_error("no devices"); return CHOLAMD_ERR_ARG; }
+  std::vector<int> ids(n);
+  std::vector<ncclComm_t> comms(n);
+  for (int i = 0; i < n; i++) ids[i] = devs[i]->dev;
+  NCCLCHK(ncclCommInitAll(comms.data(), n, ids.data()));
+  for (int i = 0; i < n; i++) { out[i] = new cholamd_comm(); out[i]->comm = comms[i]; out[i]->world = n; out[i]->rank = i; }
+  return 0;
+}
+extern "C" int cholamd_comm_adopt(void *nccl_comm, int world, int rank, cholamd_comm **out)
+{ // an ncclComm_t the caller made (and keeps): e.g. the one a Legion mapper or torch's process group holds
+  if (!nccl_comm) { chol_set_error("null ncclComm_t"); return CHOLAMD_ERR_ARG; }
+  cholamd_comm *c = new cholamd_comm();
+  c->comm = (ncclComm_t)nccl_comm; c->world = world; c->rank = rank; c->owned = false;
+  *out = c;
+  return 0;
+}
+extern "C" void cholamd_comm_destroy(cholamd_comm *c)
+{
+  if (!c) return;
+  if (c->owned && c->comm) (void)ncclCommDestroy(c->comm);
+  delete c;
+}
+static int tail_of(const cholamd_device *d, int64_t *tail, int64_t *count)
+{
+  const cholamd_plan *p = d->plan;
+  *tail = d->world > 1 ? p->panel_off[p->nsep - (d->world - 1) + 1] : p->arena;
+  *count = p->arena - *tail;
+  return 0;
+}
+extern "C" int64_t cholamd_device_tail_offset(const cholamd_device *d)
+{
+  int64_t t, c;
+  tail_of(d, &t, &c);
+  return t;
+}
+extern "C" int cholamd_comm_allreduce(cholamd_comm *c, double *d_buf, int64_t count, void *stream)
+{ // in-place fp64 sum over the communicator's ranks, asynchronous on `stream` (of the current device)
+  if (!c || !c->comm) { chol_set_error("null communicator"); return CHOLAMD_ERR_ARG; }
+  if (count <= 0) return 0;
+  NCCLCHK(ncclAllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, c->comm, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int cholamd_exchange_tail(cholamd_device *d, double *d_arena, cholamd_comm *c, void *stream)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  if (!c || c->world != d->world || c->rank != d->rank) { chol_set_error("communicator (rank %d of %d) does not match the device partition (rank %d of %d)", c ? c->rank : -1, c ? c->world : -1, d->rank, d->world); return CHOLAMD_ERR_ARG; }
+  int64_t tail, count;
+  tail_of(d, &tail, &count);
+  return cholamd_comm_allreduce(c, d_arena + tail, count, stream);
+}
+extern "C" int cholamd_factor_sharded(cholamd_device *d, double *d_arena, cholamd_comm *c, void *stream)
+{
+  const int L = d->plan->levels, split = chol_split_level(d->world);
+  if (d->world == 1) return cholamd_factor_levels(d, d_arena, L - 1, 0, stream);
+  int rc = cholamd_factor_levels(d, d_arena, L - 1, split, stream);
+  if (!rc) rc = cholamd_exchange_tail(d, d_arena, c, stream);
+  if (!rc) rc = cholamd_factor_levels(d, d_arena, split - 1, 0, stream);
+  return rc;
+}
+extern "C" int cholamd_factor_multi(cholamd_device *const *devs, double *const *arenas, cholamd_comm *const *comms, int n, void *const *streams)
+{ // one process, n devices: everything is asynchronous on each device's stream
+  if (n < 1) { chol_set_error("no devices"); return CHOLAMD_ERR_ARG; }
+  if (n == 1) return cholamd_factor_levels(devs[0], arenas[0], devs[0]->plan->levels - 1, 0, streams ? streams[0] : nullptr);
+  const int L = devs[0]->plan->levels, split = chol_split_level(n);
+  for (int g = 0; g < n; g++) {
+    if (devs[g]->world != n || devs[g]->rank != g) { chol_set_error("device %d is not partitioned as rank %d of %d", g, g, n); return CHOLAMD_ERR_ARG; }
+    int rc = cholamd_factor_levels(devs[g], arenas[g], L - 1, split, streams ? streams[g] : nullptr);
+    if (rc) return rc;
+  }
+  NCCLCHK(ncclGroupStart());
+  for (int g = 0; g < n; g++) {
+    int rc = cholamd_exchange_tail(devs[g], arenas[g], comms[g], streams ? streams[g] : nullptr);
+    if (rc) { (void)ncclGroupEnd(); return rc; }
+  }
+  NCCLCHK(ncclGroupEnd());
+  for (int g = 0; g < n; g++) {
+    int rc = cholamd_factor_levels(devs[g], arenas[g], split - 1, 0, streams ? streams[g] : nullptr);
+    if (rc) return rc;
+  }
+  return 0;
+}
+extern "C" int cholamd_gather_factor(cholamd_device *const *devs, double *const *arenas, int n, void *const *streams)
+{ // the panels of the subtrees ranks 1..n-1 own -> device 0's arena (peer copies), so that it holds the complete factor
+  const cholamd_plan *p = devs[0]->plan;
+  for (int g = 1; g < n; g++) {
+    HIPCHK(hipSetDevice(devs[g]->dev));
+    HIPCHK(hipStreamSynchronize(streams ? (hipStream_t)streams[g] : nullptr));
+  }
+  HIPCHK(hipSetDevice(devs[0]->dev));
+  for (int s = 1; s <= p->nsep; s++) {
+    const int g = chol_owner_of(p, s, n);
+    if (g <= 0) continue;
+    const int64_t off = p->panel_off[s];
+    const int64_t len = (s < p->nsep ? p->panel_off[s + 1] : p->arena) - off;
+    HIPCHK(hipMemcpyPeerAsync(arenas[0] + off, devs[0]->dev, arenas[g] + off, devs[g]->dev, (size_t)len * sizeof(double), streams ? (hipStream_t)streams[0] : nullptr));
+  }
+  return 0;
 }

@@ -7,8 +7,6 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-void chol_launch_set_arena_slot(double *const *slot);
-int chol_launch_set_slot(double **slot, double *arena, hipStream_t st);
 int chol_launch_scatter(double *arena, const int64_t *dst, const double *val, int64_t nnz, hipStream_t st);
 int chol_launch_potrf(double *base, double *ws, const chol_potrf_desc *descs, int n, int *info, hipStream_t st);
 int chol_launch_potrf_big(double *base, double *ws, const chol_potrf_desc *descs, int n, int *info, hipStream_t st);

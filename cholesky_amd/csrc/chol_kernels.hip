@@ -54,7 +54,7 @@ __device__ __forceinline__ int wait_progress(const int *progress, int target, in
     if (v >= target) return v;
     __builtin_amdgcn_s_sleep(8);
   }
-  if ((threadIdx.x & 63) == 0) atomicCAS(&info[0], 0, -7); // internal error: no progress
+  if ((threadIdx.x & 63) == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); // no progress: the factorisation is reported as failed
   return target;
 }
 // ------------------------------------------------------------------------------------------------
@@ -173,10 +173,9 @@ __device__ __forceinline__ void update_task_body(double *__restrict__ base, cons
     }
   }
 }
-__global__ __launch_bounds__(256) void k_update(double *__restrict__ base_, double *const *__restrict__ arena_slot, const chol_upd_task *__restrict__ tasks,
+__global__ __launch_bounds__(256) void k_update(double *__restrict__ base, const chol_upd_task *__restrict__ tasks,
                                                 const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd)
 {
-  double *const __restrict__ base = arena_slot ? *arena_slot : base_; // graph launches read the arena from a device cell
   __shared__ double sAcc[3][4][64];
   const int tid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= per_xcd || tid >= ntask) return;
@@ -193,10 +192,9 @@ __global__ __launch_bounds__(256) void k_update(double *__restrict__ base_, doub
 // ------------------------------------------------------------------------------------------------
 #define MT 64
 #define MKB 16
-__global__ __launch_bounds__(256) void k_update_mt(double *__restrict__ base_, double *const *__restrict__ arena_slot, const chol_upd_task *__restrict__ tasks,
+__global__ __launch_bounds__(256) void k_update_mt(double *__restrict__ base, const chol_upd_task *__restrict__ tasks,
                                                    const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd)
 {
-  double *const __restrict__ base = arena_slot ? *arena_slot : base_; // graph launches read the arena from a device cell
   __shared__ double sA[2][MKB][MT];
   __shared__ double sB[2][MKB][MT];
   const int tt = threadIdx.x, lane = tt & 63;
@@ -920,10 +918,9 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
   }
 }
 
-__global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ base_, double *const *__restrict__ arena_slot, double *__restrict__ ws,
+__global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ base, double *__restrict__ ws,
                                                          const chol_potrf_desc *__restrict__ descs, int *__restrict__ info)
 {
-  double *const __restrict__ base = arena_slot ? *arena_slot : base_; // graph launches read the arena from a device cell
   __shared__ double smem[RR_SMEM_DOUBLES];
   potrf_rr_body<false>(base, ws, descs[blockIdx.x], info, nullptr, 0, smem);
 }
@@ -1195,10 +1192,9 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
 #undef APPLY_X
 }
 
-__global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base_, double *const *__restrict__ arena_slot, const double *__restrict__ ws,
+__global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base, const double *__restrict__ ws,
                                                  const chol_trsm_desc *__restrict__ descs)
 {
-  double *const __restrict__ base = arena_slot ? *arena_slot : base_; // graph launches read the arena from a device cell
   __shared__ double sX[3][TS * TS]; // [J mod 3][c * 16 + r]: solved column tiles, accumulator-register order
   trsm_rr_body<false, TRSM_SLOTS>(base, ws, descs[blockIdx.x], sX, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, nullptr, 0, nullptr);
 }
@@ -1214,14 +1210,13 @@ __global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base_, dou
 // after the workgroup's stores of that column have completed (s_waitcnt vmcnt(0)).
 // ------------------------------------------------------------------------------------------------
 #define FUSED_SLOTS ((CHOL_FUSE_MAXN / TS + 3) / 4) /* column tiles per wave of a strip: the registers of a 768-thread workgroup hold three */
-__global__ __launch_bounds__(RR_THREADS) void k_potrf_trsm(double *__restrict__ base_, double *const *__restrict__ arena_slot, double *__restrict__ ws,
+__global__ __launch_bounds__(RR_THREADS) void k_potrf_trsm(double *__restrict__ base, double *__restrict__ ws,
                                                            const chol_potrf_desc *__restrict__ pdescs, int n_potrf,
                                                            const chol_trsm_desc *__restrict__ tdescs, int n_trsm,
                                                            const chol_upd_task *__restrict__ tasks, const chol_upd_src *__restrict__ srcs, int n_task, int n_upd_wg,
                                                            int *__restrict__ info, int *__restrict__ progress, int progress_base,
                                                            int *__restrict__ done, int done_target)
 {
-  double *const __restrict__ base = arena_slot ? *arena_slot : base_;
   __shared__ double smem[RR_SMEM_DOUBLES]; // one image, carved by the role of the workgroup
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -1236,10 +1231,12 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_trsm(double *__restrict__ 
     chol_trsm_desc d = tdescs[min(id, n_trsm - 1)];
     if (id >= n_trsm) d.m = 0;
     trsm_rr_body<true, FUSED_SLOTS>(base, ws, d, sX[grp], wave & 3, lane, progress + d.flag, progress_base, info);
-    // the update workgroups of this launch read the solved strips: count this workgroup out once its stores have completed
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the update workgroups of this launch (if any) read the solved strips: count this workgroup out once its stores have completed
+    if (n_task > 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_barrier();
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   } else {
     // update role: three tasks at a time (one per group of four waves), tasks dealt round-robin to the update
     // workgroups; the first one waits until every TRSM workgroup of the launch has counted itself out
@@ -1302,10 +1299,9 @@ template <int T> __device__ __forceinline__ void trsm_w_solve(d4 (&tile)[TW_MAXT
     }
   }
 }
-__global__ __launch_bounds__(256) void k_trsm_w(double *__restrict__ base_, double *const *__restrict__ arena_slot, const double *__restrict__ ws,
+__global__ __launch_bounds__(256) void k_trsm_w(double *__restrict__ base, const double *__restrict__ ws,
                                                 const chol_trsm_desc *__restrict__ descs, int ndesc)
 {
-  double *const __restrict__ base = arena_slot ? *arena_slot : base_; // graph launches read the arena from a device cell
   // slot(J2, J) = J T - J (J - 1) / 2 + (J2 - J), J2 >= J: tile L(J2, J) as the MFMA Y operand (element (c, k) at
   // (k / 4) * 64 + (k % 4) * 16 + c, i.e. accumulator-register order); the diagonal slots hold Linv(J,J) in the
   // layout solve16() reads (the workspace layout, copied verbatim)
@@ -1819,12 +1815,6 @@ __global__ __launch_bounds__(256) void k_solve_gather_bwd(const double *__restri
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__global__ void k_set_slot(double **slot, double *arena) { *slot = arena; }
-int chol_launch_set_slot(double **slot, double *arena, hipStream_t st)
-{
-  hipLaunchKernelGGL(k_set_slot, dim3(1), dim3(1), 0, st, slot, arena);
-  return (int)hipGetLastError();
-}
 int chol_launch_scatter(double *arena, const int64_t *dst, const double *val, int64_t nnz, hipStream_t st)
 {
   if (nnz <= 0) return 0;
@@ -1833,14 +1823,10 @@ int chol_launch_scatter(double *arena, const int64_t *dst, const double *val, in
   hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(256), 0, st, arena, dst, val, nnz);
   return (int)hipGetLastError();
 }
-// the cell the next launches read their arena pointer from (nullptr = the pointer argument); set only while
-// cholamd_factor's launch graph is being captured
-static thread_local double *const *g_arena_slot = nullptr;
-void chol_launch_set_arena_slot(double *const *slot) { g_arena_slot = slot; }
 int chol_launch_potrf(double *base, double *ws, const chol_potrf_desc *descs, int n, int *info, hipStream_t st)
 { // pivots up to CHOL_RR_MAXN: register-resident kernel, one 1024-thread workgroup each
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(k_potrf_rr, dim3(n), dim3(RR_THREADS), 0, st, base, g_arena_slot, ws, descs, info);
+  hipLaunchKernelGGL(k_potrf_rr, dim3(n), dim3(RR_THREADS), 0, st, base, ws, descs, info);
   return (int)hipGetLastError();
 }
 int chol_launch_potrf_big(double *base, double *ws, const chol_potrf_desc *descs, int n, int *info, hipStream_t st)
@@ -1858,7 +1844,7 @@ int chol_launch_dinv(const double *L, int n, int ldl, double *W, hipStream_t st)
 int chol_launch_trsm(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st)
 { // strips of pivots up to CHOL_RR_MAXN
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(k_trsm_rr, dim3(n), dim3(256), 0, st, base, g_arena_slot, ws, descs);
+  hipLaunchKernelGGL(k_trsm_rr, dim3(n), dim3(256), 0, st, base, ws, descs);
   return (int)hipGetLastError();
 }
 int chol_launch_potrf_trsm(double *base, double *ws, const chol_potrf_desc *pdescs, int n_potrf, const chol_trsm_desc *tdescs, int n_trsm,
@@ -1868,14 +1854,14 @@ int chol_launch_potrf_trsm(double *base, double *ws, const chol_potrf_desc *pdes
   if (n_potrf <= 0) return 0;
   int n_upd_wg = (n_task + 2) / 3;
   if (n_upd_wg > 1024) n_upd_wg = 1024;
-  hipLaunchKernelGGL(k_potrf_trsm, dim3(n_potrf + (n_trsm + 2) / 3 + n_upd_wg), dim3(RR_THREADS), 0, st, base, g_arena_slot, ws, pdescs, n_potrf, tdescs, n_trsm,
+  hipLaunchKernelGGL(k_potrf_trsm, dim3(n_potrf + (n_trsm + 2) / 3 + n_upd_wg), dim3(RR_THREADS), 0, st, base, ws, pdescs, n_potrf, tdescs, n_trsm,
                      tasks, srcs, n_task, n_upd_wg, info, progress, progress_base, done, done_target);
   return (int)hipGetLastError();
 }
 int chol_launch_trsm_w(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st)
 { // strips of pivot blocks up to CHOL_TRSM_W_MAXN columns, one wave each; every aligned group of four descriptors shares one block
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(k_trsm_w, dim3((n + 3) / 4), dim3(256), 0, st, base, g_arena_slot, ws, descs, n);
+  hipLaunchKernelGGL(k_trsm_w, dim3((n + 3) / 4), dim3(256), 0, st, base, ws, descs, n);
   return (int)hipGetLastError();
 }
 int chol_launch_trsm_big(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st)
@@ -1888,14 +1874,14 @@ int chol_launch_update(double *base, const chol_upd_task *tasks, const chol_upd_
 {
   if (ntask <= 0) return 0;
   const int per_xcd = (ntask + 7) / 8;
-  hipLaunchKernelGGL(k_update, dim3(per_xcd * 8), dim3(256), 0, st, base, g_arena_slot, tasks, srcs, ntask, per_xcd);
+  hipLaunchKernelGGL(k_update, dim3(per_xcd * 8), dim3(256), 0, st, base, tasks, srcs, ntask, per_xcd);
   return (int)hipGetLastError();
 }
 int chol_launch_update_mt(double *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st)
 {
   if (ntask <= 0) return 0;
   const int per_xcd = (ntask + 7) / 8;
-  hipLaunchKernelGGL(k_update_mt, dim3(per_xcd * 8), dim3(256), 0, st, base, g_arena_slot, tasks, srcs, ntask, per_xcd);
+  hipLaunchKernelGGL(k_update_mt, dim3(per_xcd * 8), dim3(256), 0, st, base, tasks, srcs, ntask, per_xcd);
   return (int)hipGetLastError();
 }
 int chol_launch_permute(const double *in, const int *perm, double *out, int n, int inverse, hipStream_t st)

@@ -82,10 +82,19 @@ typedef struct {
   int kind;  /* 0 potrf, 1 trsm, 2 update (16x16 tasks), 3 update (64x64 macro-tile tasks), 4 trsm (every strip's pivot block <= CHOL_TRSM_W_MAXN wide),
               * 5 fused potrf (first, n) + trsm (first2, n2) + 16x16 update tasks (first3, n3) */
   int first, n, first2, n2, first3, n3;
-  /* two-stream program only (chol_build_program): the stream the launch goes to, the events (ids from 1, 0 = none)
-   * it waits for and the one recorded after it */
-  int lane, wait[2], record;
 } chol_phase;
+
+/* schedule switches of one device object (chol_schedule.c): read from the environment once, at cholamd_device_create */
+#define CHOL_MT_MIN_TILES 8192 /* a phase whose 16x16 sub-tile count reaches this goes to 64x64 macro tiles for its larger targets */
+typedef struct {
+  int split_min, split_nb;  /* pivots wider than split_min are factored in column blocks of at most split_nb columns */
+  int fuse;                 /* POTRF + TRSM of a column-block step in one launch */
+  int fuse_update_max;      /* most 16x16 update tasks such a launch carries */
+  int mt_min_tiles;
+  int cells;                /* extend-add of small phases by 16x16 grid cells of the target blocks */
+} chol_sched_opts;
+void chol_sched_opts_default(chol_sched_opts *o);
+void chol_sched_opts_from_env(chol_sched_opts *o);
 
 #define CHOL_SPLIT_MIN 144 /* pivots wider than this are factored in column blocks (chol_schedule.c); measured on lapl_3375: 258 us unsplit, 240 us at 144/144 */
 #define CHOL_SPLIT_NB 144  /* ... of at most this many columns */
@@ -143,9 +152,7 @@ int chol_plan_finish(struct cholamd_plan *p, int nz, const int *a_row, const int
 const chol_block *chol_plan_block(const struct cholamd_plan *p, int r, int c);
 int chol_ntiles(const struct cholamd_plan *p, int sep, int interval);
 /* Build the device work lists of one tree level for (rank, world); caller frees with chol_level_work_free */
-/* the whole factorisation as one list of launches on two streams (single GPU, all levels): see chol_schedule.c */
-int chol_build_program(const struct cholamd_plan *p, chol_level_work *w, int *n_event);
-int chol_build_level_work(const struct cholamd_plan *p, int level, int rank, int world, chol_level_work *out);
+int chol_build_level_work(const struct cholamd_plan *p, const chol_sched_opts *opts /* NULL: defaults */, int level, int rank, int world, chol_level_work *out);
 void chol_level_work_free(chol_level_work *w);
 int chol_owner_of(const struct cholamd_plan *p, int label, int world); /* -1: shared top of the tree */
 int chol_split_level(int world);

@@ -69,32 +69,44 @@ static void index_snapshot(const plan_t *p, int lbl, int64_t *first, int *count)
 
 /* growable arrays of the level work */
 typedef struct { int64_t c_off; int ldc, m, n, syrk, src_begin, src_end; } upd_target;
-typedef struct { chol_level_work *w; int cap_p, cap_t, cap_k, cap_km, cap_s, cap_ph; upd_target *pend; int n_pend, cap_pend; } builder;
+typedef struct { chol_level_work *w; const chol_sched_opts *o; int cap_p, cap_t, cap_k, cap_km, cap_s, cap_ph; upd_target *pend; int n_pend, cap_pend; } builder;
 /* Blocking of a pivot at the schedule level.  The POTRF kernel takes pivots up to CHOL_RR_MAXN whole, but one
  * workgroup's MFMA throughput bounds the early steps of a large one (the trailing update of step 0 of a
  * 17 x 17 tile grid is 120 tile updates on one CU); a pivot wider than CHOL_SPLIT_MIN is therefore factored
  * in equal column blocks of at most CHOL_SPLIT_NB columns (a multiple of 16), with the TRSM of the rows below
  * and the rank-nb update of the trailing columns spread over the whole chip between the blocks. */
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
-static int split_min(void) { static int v = -1; if (v < 0) v = env_int("CHOLAMD_SPLIT_MIN", CHOL_SPLIT_MIN); return v; }
-static int split_nb(void) { static int v = -1; if (v < 0) { v = env_int("CHOLAMD_SPLIT_NB", CHOL_SPLIT_NB); if (v > CHOL_RR_MAXN) v = CHOL_RR_MAXN; v = (v + 15) / 16 * 16; if (v < 16) v = 16; } return v; }
-/* a step's 16x16 update tasks ride in its fused launch up to this many (beyond, a launch of their own with eight
- * 256-thread workgroups per CU beats the fused launch's one 768-thread workgroup per CU) */
-static int fuse_update_max(void) { static int v = -1; if (v < 0) v = env_int("CHOLAMD_FUSE_UPDATE_MAX", CHOL_FUSE_UPDATE_MAX); return v; }
-static int pivot_blocks(int n) { return n > split_min() || n > CHOL_RR_MAXN ? (n + split_nb() - 1) / split_nb() : 1; }
-static int pivot_block_width(int n) { const int nb = pivot_blocks(n); return nb == 1 ? n : ((n + nb - 1) / nb + 15) / 16 * 16; }
+/* schedule switches: defaults, overridden once per device object from the environment (chol_sched_opts_from_env,
+ * called by cholamd_device_create) or by cholamd_device_set_option */
+void chol_sched_opts_default(chol_sched_opts *o)
+{
+  o->split_min = CHOL_SPLIT_MIN; o->split_nb = CHOL_SPLIT_NB; o->fuse = 1; o->fuse_update_max = CHOL_FUSE_UPDATE_MAX;
+  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1;
+}
+void chol_sched_opts_from_env(chol_sched_opts *o)
+{
+  chol_sched_opts_default(o);
+  o->split_min = env_int("CHOLAMD_SPLIT_MIN", o->split_min);
+  o->split_nb = env_int("CHOLAMD_SPLIT_NB", o->split_nb);
+  o->fuse = !env_int("CHOLAMD_NO_FUSE", 0);
+  o->fuse_update_max = env_int("CHOLAMD_FUSE_UPDATE_MAX", o->fuse_update_max);
+  o->mt_min_tiles = env_int("CHOLAMD_MT_MIN_TILES", o->mt_min_tiles);
+  o->cells = !env_int("CHOLAMD_NO_CELLS", 0);
+}
+static int split_nb(const chol_sched_opts *o) { int v = o->split_nb; if (v > CHOL_RR_MAXN) v = CHOL_RR_MAXN; v = (v + 15) / 16 * 16; if (v < 16) v = 16; return v; }
+static int pivot_blocks(const chol_sched_opts *o, int n) { return n > o->split_min || n > CHOL_RR_MAXN ? (n + split_nb(o) - 1) / split_nb(o) : 1; }
+static int pivot_block_width(const chol_sched_opts *o, int n) { const int nb = pivot_blocks(o, n); return nb == 1 ? n : ((n + nb - 1) / nb + 15) / 16 * 16; }
 
 /* a phase whose 16x16 sub-tile count reaches this goes to 64x64 macro tiles for its larger targets:
  * below it the 16x16 split-K workgroups are what fills the 256 CUs, above it their 4x operand
  * re-reads are what costs */
-#define CHOL_MT_MIN_TILES 8192
 
 static void push_phase(builder *B, int kind, int first, int n)
 {
   if (n <= 0) return;
   chol_level_work *w = B->w;
   if (w->n_phase == B->cap_ph) { B->cap_ph = B->cap_ph ? 2 * B->cap_ph : 16; w->phase = realloc(w->phase, B->cap_ph * sizeof(chol_phase)); }
-  chol_phase ph = { kind, first, n, 0, 0, 0, 0, 0, { 0, 0 }, 0 };
+  chol_phase ph = { kind, first, n, 0, 0, 0, 0 };
   w->phase[w->n_phase++] = ph;
 }
 static void push_potrf(builder *B, chol_potrf_desc d)
@@ -175,9 +187,7 @@ static void flush_targets(builder *B)
     const int64_t tr = (B->pend[i].m + 15) / 16, tc = (B->pend[i].n + 15) / 16;
     fine += B->pend[i].syrk ? tr * (tr + 1) / 2 : tr * tc;
   }
-  static int mt_min = -1;
-  if (mt_min < 0) mt_min = env_int("CHOLAMD_MT_MIN_TILES", CHOL_MT_MIN_TILES);
-  const int big = fine >= mt_min;
+  const int big = fine >= B->o->mt_min_tiles;
   for (int i = 0; i < B->n_pend; i++) {
     const upd_target *t = &B->pend[i];
     emit_tasks(B, big && (t->m > 16 || t->n > 16), t->c_off, t->ldc, t->m, t->n, t->syrk, t->src_begin, t->src_end);
@@ -265,11 +275,10 @@ static int emit_cell_tasks(builder *B, const plan_t *p, const upd_tuple *tu, int
   return ntask;
 }
 /* small update phases go cell by cell, large ones (macro tiles pay) tile by tile */
-static int tuples_are_small(const upd_tuple *tu, int ntu)
+static int tuples_are_small(const chol_sched_opts *o, const upd_tuple *tu, int ntu)
 {
-  static int mt_min = -1;
-  if (mt_min < 0) mt_min = env_int("CHOLAMD_MT_MIN_TILES", CHOL_MT_MIN_TILES);
-  if (getenv("CHOLAMD_NO_CELLS")) return 0;
+  const int mt_min = o->mt_min_tiles;
+  if (!o->cells) return 0;
   int64_t fine = 0;
   for (int i = 0; i < ntu; i++)
     if (i == 0 || tu[i].key != tu[i - 1].key) fine += (int64_t)((tu[i].m + 15) / 16) * ((tu[i].n + 15) / 16);
@@ -306,11 +315,13 @@ static int ancestor_runs(const plan_t *p, int h, const cholamd_filled *snap, con
   return ancestor_runs_of(p, h, 0, snap, first, count, out);
 }
 
-int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_level_work *w)
+int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int level, int rank, int world, chol_level_work *w)
 {
+  chol_sched_opts dflt;
+  if (!opts) { chol_sched_opts_default(&dflt); opts = &dflt; }
   memset(w, 0, sizeof *w);
   w->level = level;
-  builder Bd; memset(&Bd, 0, sizeof Bd); Bd.w = w;
+  builder Bd; memset(&Bd, 0, sizeof Bd); Bd.w = w; Bd.o = opts;
   builder *B = &Bd;
   const int L = p->levels, lbl = L - 1 - level;
   const int d = chol_split_level(world);
@@ -328,12 +339,12 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
     if (level >= d && chol_owner_of(p, s, world) != rank) continue;
     if (count[BIDX(p, s, s)] == 0 || p->sep_size[s] == 0) continue;
     hs[nh++] = h;
-    if (pivot_blocks(p->sep_size[s]) > steps) steps = pivot_blocks(p->sep_size[s]);
+    if (pivot_blocks(opts, p->sep_size[s]) > steps) steps = pivot_blocks(opts, p->sep_size[s]);
   }
   if (steps == 0) steps = 1;
   int fused_last = -1; /* the level's last fused launch, if nothing was launched after it */
-  int fuse = !getenv("CHOLAMD_NO_FUSE"); /* POTRF + TRSM of a step in one launch, if every block fits its TRSM role */
-  for (int q = 0; q < nh; q++) if (pivot_block_width(p->sep_size[p->tree[hs[q]]]) > CHOL_FUSE_MAXN) fuse = 0;
+  int fuse = opts->fuse; /* POTRF + TRSM of a step in one launch, if every block fits its TRSM role */
+  for (int q = 0; q < nh; q++) if (pivot_block_width(opts, p->sep_size[p->tree[hs[q]]]) > CHOL_FUSE_MAXN) fuse = 0;
   /* pivots: small ones whole in step 0; big ones in pivot_block_width()-column blocks, each step =
    * POTRF of the diagonal block, TRSM of every row below it (rows of the pivot and filled ancestor rows
    * alike), rank-nb update of the remaining columns of those rows */
@@ -341,7 +352,7 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
     const int p0 = w->n_potrf, t0 = w->n_trsm, k0 = w->n_task, km0 = w->n_task_mt;
     for (int q = 0; q < nh; q++) {
       const int h = hs[q], s = p->tree[h], n = p->sep_size[s], ld = p->panel_ld[s];
-      const int bw = pivot_block_width(n);
+      const int bw = pivot_block_width(opts, n);
       const int c0 = st * bw;
       if (c0 >= n) continue;
       const int nb = n - c0 < bw ? n - c0 : bw;
@@ -374,8 +385,8 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
     if (fuse) { /* one launch: the strips follow their pivot's POTRF column by column, the 16x16 update tasks of the
                  * step (trailing columns of a split pivot) wait for the strips inside the same launch */
       if (w->n_phase == B->cap_ph) { B->cap_ph = B->cap_ph ? 2 * B->cap_ph : 16; w->phase = realloc(w->phase, B->cap_ph * sizeof(chol_phase)); }
-      const int ride = w->n_task - k0 <= fuse_update_max();
-      chol_phase ph = { 5, p0, w->n_potrf - p0, t0, w->n_trsm - t0, k0, ride ? w->n_task - k0 : 0, 0, { 0, 0 }, 0 };
+      const int ride = w->n_task - k0 <= opts->fuse_update_max;
+      chol_phase ph = { 5, p0, w->n_potrf - p0, t0, w->n_trsm - t0, k0, ride ? w->n_task - k0 : 0 };
       fused_last = -1;
       if (ph.n > 0) { fused_last = w->n_phase; w->phase[w->n_phase++] = ph; }
       if (ph.n <= 0 || !ride) { if (w->n_task > k0) fused_last = -1; push_phase(B, 2, k0, w->n_task - k0); }
@@ -429,7 +440,7 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
   qsort(tu, ntu, sizeof(upd_tuple), cmp_tuple);
   {
     const int k0 = w->n_task, km0 = w->n_task_mt;
-    if (tuples_are_small(tu, ntu)) emit_cell_tasks(B, p, tu, ntu);
+    if (tuples_are_small(opts, tu, ntu)) emit_cell_tasks(B, p, tu, ntu);
     else
     for (int i = 0; i < ntu;) {
       int e = i + 1;
@@ -445,7 +456,7 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
     flush_targets(B);
     /* the 16x16 tasks of the extend-add ride in the level's last fused launch when that one carries no tasks of
      * its own and nothing was launched after it */
-    if (fused_last >= 0 && fused_last == w->n_phase - 1 && w->phase[fused_last].n3 == 0 && w->n_task - k0 <= fuse_update_max()) {
+    if (fused_last >= 0 && fused_last == w->n_phase - 1 && w->phase[fused_last].n3 == 0 && w->n_task - k0 <= opts->fuse_update_max) {
       w->phase[fused_last].first3 = k0;
       w->phase[fused_last].n3 = w->n_task - k0;
     } else push_phase(B, 2, k0, w->n_task - k0);
@@ -453,349 +464,6 @@ int chol_build_level_work(const plan_t *p, int level, int rank, int world, chol_
   }
   free(tu); free(first); free(count); free(hs); free(B->pend); B->pend = NULL; B->cap_pend = 0;
   return 0;
-}
-
-/* ---------------------------------------------------------------------------------------- */
-/* The whole factorisation as ONE list of launches on two streams (single GPU, every level).  */
-/*                                                                                            */
-/* Only a small part of a level's TRSM / extend-add work feeds the next POTRF: the rows of    */
-/* the PARENT separator in each panel and the contributions to the parent's diagonal block.   */
-/* Everything else is needed later -- a target block (a', a) not before the level of its      */
-/* column separator a is factored -- and the POTRF launches occupy at most one CU per pivot.  */
-/* So the launches are split over two streams:                                                */
-/*   lane 0 (critical):  POTRF(l) -> TRSM of the pivot's own rows below a column block and of */
-/*                       the parent rows -> their trailing update -> ... -> the extend-add    */
-/*                       into the parents' diagonal blocks -> POTRF(l-1)                      */
-/*   lane 1 (bulk):      TRSM of the far-ancestor rows, their trailing updates, the extend-   */
-/*                       add into the off-diagonal blocks of column level l-1, and -- at the  */
-/*                       START of level l, ahead of that level's own bulk work -- the merged  */
-/*                       contributions of all levels >= l+1 to the blocks of column level l-1 */
-/*                       ("far" targets, queued by deadline)                                  */
-/* Every target block has all its writers on one stream or ordered by an event, so the result */
-/* does not depend on timing; the accumulation order over descendants of a far target is by   */
-/* source level (deepest first), within a level the reference's program order.                */
-/* ---------------------------------------------------------------------------------------- */
-typedef struct { upd_tuple *v; int n, cap; } tuple_vec;
-static void tv_push(tuple_vec *t, const upd_tuple *u)
-{
-  if (t->n == t->cap) { t->cap = t->cap ? 2 * t->cap : 256; t->v = realloc(t->v, t->cap * sizeof(upd_tuple)); }
-  t->v[t->n++] = *u;
-}
-static void push_step(builder *B, int kind, int first, int n, int lane, int wait0, int wait1, int record)
-{
-  chol_level_work *w = B->w;
-  if (n <= 0) kind = -1; /* an empty launch still carries its waits and its event */
-  if (w->n_phase == B->cap_ph) { B->cap_ph = B->cap_ph ? 2 * B->cap_ph : 16; w->phase = realloc(w->phase, B->cap_ph * sizeof(chol_phase)); }
-  chol_phase ph = { kind, first, n, 0, 0, 0, 0, lane, { wait0, wait1 }, record };
-  w->phase[w->n_phase++] = ph;
-}
-/* the update launches (16x16 and macro-tile) of the targets pushed since (k0, km0) */
-static void push_update_steps(builder *B, int k0, int km0, int lane, int wait0, int wait1, int record)
-{
-  chol_level_work *w = B->w;
-  flush_targets(B);
-  const int nf = w->n_task - k0, nm = w->n_task_mt - km0;
-  if (nf > 0 && nm > 0) {
-    push_step(B, 2, k0, nf, lane, wait0, wait1, 0);
-    push_step(B, 3, km0, nm, lane, 0, 0, record);
-  } else if (nm > 0) push_step(B, 3, km0, nm, lane, wait0, wait1, record);
-  else push_step(B, 2, k0, nf, lane, wait0, wait1, record);
-}
-/* sort tuples by target, emit one target per group with its sources in (seq) order */
-static void emit_tuple_targets(builder *B, const plan_t *p, tuple_vec *t)
-{
-  chol_level_work *w = B->w;
-  qsort(t->v, t->n, sizeof(upd_tuple), cmp_tuple);
-  if (tuples_are_small(t->v, t->n)) { emit_cell_tasks(B, p, t->v, t->n); return; }
-  for (int i = 0; i < t->n;) {
-    int e = i + 1;
-    while (e < t->n && t->v[e].key == t->v[i].key) e++;
-    const int sb = w->n_src;
-    for (int q = i; q < e; q++) {
-      chol_upd_src sd = { t->v[q].a_off, t->v[q].b_off, t->v[q].lda, t->v[q].ldb, t->v[q].k, 0 };
-      push_src(B, sd);
-    }
-    push_tasks(B, t->v[i].c_off, t->v[i].ldc, t->v[i].m, t->v[i].n, t->v[i].syrk, sb, w->n_src);
-    i = e;
-  }
-}
-
-int chol_build_program(const plan_t *p, chol_level_work *w, int *n_event)
-{
-  memset(w, 0, sizeof *w);
-  w->level = -1;
-  builder Bd; memset(&Bd, 0, sizeof Bd); Bd.w = w;
-  builder *B = &Bd;
-  const int L = p->levels;
-  int64_t *first = malloc(p->nblk * sizeof(int64_t));
-  int *count = malloc(p->nblk * sizeof(int));
-  int nev = 0;
-  /* extend-add tuples of every level, by destination: crit[l] = diagonal blocks of the parents, next[l] = the
-   * other blocks of column level l-1, far[c] = blocks of column level c from levels >= c+2 */
-  /* far[c * L + l]: from source level l; the tile partition of a target block differs from level to level, so
-   * the contributions of different levels are separate launches (deepest level first), never one merged task */
-  tuple_vec *crit = calloc(L, sizeof(tuple_vec)), *next = calloc(L, sizeof(tuple_vec)), *far = calloc((size_t)L * L, sizeof(tuple_vec));
-  int64_t seq = 0;
-  for (int level = L - 1; level >= 1; level--) { /* deepest first: the order far targets accumulate in */
-    const int lbl = L - 1 - level;
-    index_snapshot(p, lbl, first, count);
-    const cholamd_filled *snap = p->snap[lbl];
-    for (int h = 1 << level; h < (1 << (level + 1)); h++) {
-      const int s = p->tree[h], n = p->sep_size[s];
-      if (count[BIDX(p, s, s)] == 0 || n == 0) continue;
-      for (int hp = h / 2; hp >= 1; hp /= 2) {
-        const int par = p->tree[hp], bb = BIDX(p, par, s);
-        const chol_block *Bb = &p->blk[bb];
-        for (int hg = hp; hg >= 1; hg /= 2) {
-          const int gp = p->tree[hg], ba = BIDX(p, gp, s), bc = BIDX(p, gp, par);
-          const chol_block *Ba = &p->blk[ba], *Bc = &p->blk[bc];
-          for (int i = 0; i < count[ba]; i++) {
-            const cholamd_filled *fa = &snap[first[ba] + i];
-            for (int j = 0; j < count[bb]; j++) {
-              const cholamd_filled *fb_ = &snap[first[bb] + j];
-              if (gp == par && fb_->cluster > fa->cluster) continue; /* col > row skipped, blas.rg:396-431 */
-              upd_tuple u;
-              const int crow = fa->lo_x - Bc->lo_x, ccol = fb_->lo_x - Bc->lo_y;
-              u.key = ((int64_t)bc << 40) | ((int64_t)crow << 20) | (int64_t)ccol;
-              u.seq = seq++;
-              u.c_off = Bc->off + crow + (int64_t)ccol * Bc->ld; u.ldc = Bc->ld;
-              u.a_off = Ba->off + (fa->lo_x - Ba->lo_x); u.lda = Ba->ld;
-              u.b_off = Bb->off + (fb_->lo_x - Bb->lo_x); u.ldb = Bb->ld;
-              u.m = fa->hi_x - fa->lo_x + 1; u.n = fb_->hi_x - fb_->lo_x + 1; u.k = n;
-              u.syrk = (gp == par && fb_->cluster == fa->cluster);
-              u.bc = bc; u.crow = crow; u.ccol = ccol;
-              if (hp != h / 2) tv_push(&far[p->level_of[par] * L + level], &u);
-              else if (hg == hp) tv_push(&crit[level], &u);
-              else tv_push(&next[level], &u);
-            }
-          }
-        }
-      }
-    }
-  }
-
-  int ev_far_prev = 0;  /* far contributions to the diagonal blocks of the level being factored are complete */
-  int ev_grp_prev = 0;  /* every contribution to the off-diagonal blocks of that column level is complete */
-  int ev_last_bulk = 0;
-  for (int level = L - 1; level >= 0; level--) {
-    const int lbl = L - 1 - level;
-    index_snapshot(p, lbl, first, count);
-    const cholamd_filled *snap = p->snap[lbl];
-    const int h0 = 1 << level, h1 = (1 << (level + 1)) - 1;
-    /* lane 1, first in line: far targets of column level level-1 (sources: far-ancestor rows of levels >= level+1,
-     * solved by earlier lane-1 launches) */
-    int ev_far = 0;
-    for (int src = L - 1; level >= 1 && src > level; src--) {
-      tuple_vec *f = &far[(level - 1) * L + src];
-      if (f->n == 0) continue;
-      const int k0 = w->n_task, km0 = w->n_task_mt;
-      emit_tuple_targets(B, p, f);
-      ev_far = ++nev;
-      push_update_steps(B, k0, km0, 1, 0, 0, ev_far);
-      ev_last_bulk = ev_far;
-    }
-    int *hs = malloc((h1 - h0 + 1) * sizeof(int)), nh = 0, steps = 1;
-    for (int h = h0; h <= h1; h++) {
-      const int s = p->tree[h];
-      if (count[BIDX(p, s, s)] == 0 || p->sep_size[s] == 0) continue;
-      hs[nh++] = h;
-      if (pivot_blocks(p->sep_size[s]) > steps) steps = pivot_blocks(p->sep_size[s]);
-    }
-    int ev_tc_last = 0;
-    for (int st = 0; st < steps; st++) {
-      /* ---- lane 0: POTRF of the column block, TRSM of the pivot rows below it and of the parent rows, their
-       *      trailing update */
-      const int p0 = w->n_potrf, t0 = w->n_trsm;
-      for (int q = 0; q < nh; q++) {
-        const int h = hs[q], s = p->tree[h], n = p->sep_size[s], ld = p->panel_ld[s];
-        const int bw = pivot_block_width(n), c0 = st * bw;
-        if (c0 >= n) continue;
-        const int nb = n - c0 < bw ? n - c0 : bw;
-        const int64_t diag = p->panel_off[s] + c0 + (int64_t)c0 * ld;
-        const int64_t dinv = p->dinv_off[s] + (int64_t)(c0 / CHOL_NB) * CHOL_NB * CHOL_NB;
-        chol_potrf_desc pd = { diag, dinv, nb, ld, s, c0 };
-        push_potrf(B, pd);
-      }
-      const int ev_p = ++nev;
-      /* the first POTRF of a level needs the far contributions to its diagonal blocks (lane 1); the parents'
-       * own contribution came on lane 0 */
-      push_step(B, 0, p0, w->n_potrf - p0, 0, st == 0 ? ev_far_prev : 0, 0, ev_p);
-      int k0 = w->n_task, km0 = w->n_task_mt;
-      for (int q = 0; q < nh; q++) {
-        const int h = hs[q], s = p->tree[h], n = p->sep_size[s], ld = p->panel_ld[s];
-        const int bw = pivot_block_width(n), c0 = st * bw;
-        if (c0 >= n) continue;
-        const int nb = n - c0 < bw ? n - c0 : bw;
-        const int64_t diag = p->panel_off[s] + c0 + (int64_t)c0 * ld;
-        const int64_t dinv = p->dinv_off[s] + (int64_t)(c0 / CHOL_NB) * CHOL_NB * CHOL_NB;
-        const int64_t colbase = (int64_t)c0 * ld;
-        const int below = n - c0 - nb;
-        const int ts = w->n_trsm;
-        if (below > 0) push_trsm_run(B, diag, dinv, p->panel_off[s] + (c0 + nb) + colbase, nb, ld, below, -1);
-        row_run *runs; const int nr = ancestor_runs_of(p, h, 1, snap, first, count, &runs);
-        for (int r = 0; r < nr; r++) push_trsm_run(B, diag, dinv, runs[r].off + colbase, nb, ld, runs[r].m, -1);
-        if (nb <= CHOL_TRSM_W_MAXN && w->n_trsm > ts) pad_trsm_group(B, t0, 4, diag, dinv, diag, nb, ld, -1);
-        if (below > 0) {
-          const int64_t x_piv = p->panel_off[s] + (c0 + nb) + colbase;
-          chol_upd_src sp = { x_piv, x_piv, ld, ld, nb, 0 };
-          const int sidx = push_src(B, sp);
-          push_tasks(B, p->panel_off[s] + (c0 + nb) + (int64_t)(c0 + nb) * ld, ld, below, below, 1, sidx, sidx + 1);
-          for (int r = 0; r < nr; r++) {
-            chol_upd_src sa = { runs[r].off + colbase, x_piv, ld, ld, nb, 0 };
-            const int si = push_src(B, sa);
-            push_tasks(B, runs[r].off + (int64_t)(c0 + nb) * ld, ld, runs[r].m, below, 0, si, si + 1);
-          }
-        }
-        free(runs);
-      }
-      int wide = 0;
-      for (int i = t0; i < w->n_trsm; i++) if (w->trsm[i].n > CHOL_TRSM_W_MAXN) wide = 1;
-      const int ev_tc = ++nev;
-      /* the parent rows received contributions from deeper levels on lane 1 */
-      push_step(B, wide ? 1 : 4, t0, w->n_trsm - t0, 0, st == 0 ? ev_grp_prev : 0, 0, ev_tc);
-      ev_tc_last = ev_tc;
-      if (B->n_pend > 0) push_update_steps(B, k0, km0, 0, 0, 0, 0);
-      /* ---- lane 1: the far-ancestor rows of the same column block */
-      const int tb0 = w->n_trsm;
-      k0 = w->n_task; km0 = w->n_task_mt;
-      for (int q = 0; q < nh; q++) {
-        const int h = hs[q], s = p->tree[h], n = p->sep_size[s], ld = p->panel_ld[s];
-        const int bw = pivot_block_width(n), c0 = st * bw;
-        if (c0 >= n) continue;
-        const int nb = n - c0 < bw ? n - c0 : bw;
-        const int64_t diag = p->panel_off[s] + c0 + (int64_t)c0 * ld;
-        const int64_t dinv = p->dinv_off[s] + (int64_t)(c0 / CHOL_NB) * CHOL_NB * CHOL_NB;
-        const int64_t colbase = (int64_t)c0 * ld;
-        const int below = n - c0 - nb;
-        const int ts = w->n_trsm;
-        row_run *runs; const int nr = ancestor_runs_of(p, h, 2, snap, first, count, &runs);
-        for (int r = 0; r < nr; r++) push_trsm_run(B, diag, dinv, runs[r].off + colbase, nb, ld, runs[r].m, -1);
-        if (nb <= CHOL_TRSM_W_MAXN && w->n_trsm > ts) pad_trsm_group(B, tb0, 4, diag, dinv, diag, nb, ld, -1);
-        if (below > 0) {
-          const int64_t x_piv = p->panel_off[s] + (c0 + nb) + colbase;
-          for (int r = 0; r < nr; r++) {
-            chol_upd_src sa = { runs[r].off + colbase, x_piv, ld, ld, nb, 0 };
-            const int si = push_src(B, sa);
-            push_tasks(B, runs[r].off + (int64_t)(c0 + nb) * ld, ld, runs[r].m, below, 0, si, si + 1);
-          }
-        }
-        free(runs);
-      }
-      if (w->n_trsm > tb0) {
-        wide = 0;
-        for (int i = tb0; i < w->n_trsm; i++) if (w->trsm[i].n > CHOL_TRSM_W_MAXN) wide = 1;
-        const int ev_tb = ++nev;
-        push_step(B, wide ? 1 : 4, tb0, w->n_trsm - tb0, 1, ev_p, 0, ev_tb);
-        ev_last_bulk = ev_tb;
-      }
-      if (B->n_pend > 0) { /* uses the pivot rows solved on lane 0 */
-        const int ev_ub = ++nev;
-        push_update_steps(B, k0, km0, 1, ev_tc, 0, ev_ub);
-        ev_last_bulk = ev_ub;
-      }
-    }
-    free(hs);
-    /* ---- extend-add of the level */
-    ev_far_prev = 0; ev_grp_prev = 0;
-    if (level >= 1) {
-      /* lane 0: the parents' diagonal blocks, after the far contributions to the same blocks */
-      if (crit[level].n > 0) {
-        const int k0 = w->n_task, km0 = w->n_task_mt;
-        emit_tuple_targets(B, p, &crit[level]);
-        push_update_steps(B, k0, km0, 0, ev_far, 0, 0);
-      } else if (ev_far) push_step(B, -1, 0, 0, 0, ev_far, 0, 0);
-      /* lane 1: the other blocks of column level level-1 (rows of the far ancestors x rows of the parent) */
-      if (next[level].n > 0) {
-        const int k0 = w->n_task, km0 = w->n_task_mt;
-        emit_tuple_targets(B, p, &next[level]);
-        const int ev_n = ++nev;
-        push_update_steps(B, k0, km0, 1, ev_tc_last, 0, ev_n);
-        ev_last_bulk = ev_n;
-      }
-      /* what the next level waits for: its POTRF for the far contributions to its diagonal blocks (already
-       * awaited on lane 0 just above, so nothing more), its first TRSM for everything lane 1 wrote so far */
-      ev_grp_prev = ev_last_bulk;
-    }
-  }
-  /* join: the factorisation is complete when lane 0 is */
-  if (ev_last_bulk) push_step(B, -1, 0, 0, 0, ev_last_bulk, 0, 0);
-  for (int l = 0; l < L; l++) { free(crit[l].v); free(next[l].v); }
-  for (int l = 0; l < L * L; l++) free(far[l].v);
-  free(crit); free(next); free(far); free(first); free(count); free(B->pend);
-  *n_event = nev;
-  return 0;
-}
-
-/* Self-check of the two-stream program (host only, used by the CPU tests): it must contain exactly the work of
- * the per-level lists -- the same POTRF blocks, the same TRSM strips and, per 16x16 output tile, the same
- * (target, source) pairs -- and every event must be recorded before the launch that waits for it. */
-typedef struct { int64_t a, b, c, d; } quad;
-static int cmp_quad(const void *x, const void *y) { return memcmp(x, y, sizeof(quad)); }
-static int64_t collect_work(const chol_level_work *w, quad **out, int64_t n, int64_t *cap)
-{
-  quad *v = *out;
-#define PUSHQ(A_, B_, C_, D_) do { if (n == *cap) { *cap = *cap ? 2 * *cap : 4096; v = realloc(v, *cap * sizeof(quad)); } quad q_ = { A_, B_, C_, D_ }; v[n++] = q_; } while (0)
-  for (int i = 0; i < w->n_potrf; i++) PUSHQ(-1, w->potrf[i].a_off, w->potrf[i].n, w->potrf[i].col0);
-  for (int i = 0; i < w->n_trsm; i++) /* row by row: the program cuts the row runs at the parent / far-ancestor boundary */
-    for (int r = 0; r < w->trsm[i].m; r++) PUSHQ(-2, w->trsm[i].b_off + r, w->trsm[i].n, w->trsm[i].l_off);
-  for (int pass = 0; pass < 2; pass++) {
-    const chol_upd_task *t = pass ? w->task_mt : w->task;
-    const int nt = pass ? w->n_task_mt : w->n_task, ts = pass ? 64 : 16;
-    (void)ts;
-    for (int i = 0; i < nt; i++)
-      for (int r = 0; r < t[i].mv; r++) /* per target row and 16-column tile */
-        for (int c = 0; c < t[i].nv; c += 16) {
-          if (t[i].lower && c > r / 16 * 16) continue;
-          for (int q = t[i].src_begin; q < t[i].src_end; q++)
-            PUSHQ(t[i].c_off + r + (int64_t)c * t[i].ldc, w->src[q].a_off + t[i].ar + r, w->src[q].b_off + t[i].br + c, w->src[q].k);
-        }
-  }
-#undef PUSHQ
-  *out = v;
-  return n;
-}
-int chol_program_check(const plan_t *p)
-{
-  quad *a = NULL, *b = NULL;
-  int64_t na = 0, nb = 0, ca = 0, cb = 0;
-  for (int l = 0; l < p->levels; l++) {
-    chol_level_work w;
-    int rc = chol_build_level_work(p, l, 0, 1, &w);
-    if (rc) return rc;
-    na = collect_work(&w, &a, na, &ca);
-    chol_level_work_free(&w);
-  }
-  chol_level_work w;
-  int nev = 0;
-  int rc = chol_build_program(p, &w, &nev);
-  if (rc) return rc;
-  nb = collect_work(&w, &b, nb, &cb);
-  /* events */
-  char *seen = calloc(nev + 2, 1);
-  for (int i = 0; i < w.n_phase && !rc; i++) {
-    const chol_phase *ph = &w.phase[i];
-    if (ph->lane < 0 || ph->lane > 1) { chol_set_error("program step %d: lane %d", i, ph->lane); rc = CHOLAMD_ERR_ARG; }
-    for (int k = 0; k < 2 && !rc; k++)
-      if (ph->wait[k] && (ph->wait[k] > nev || !seen[ph->wait[k]])) { chol_set_error("program step %d waits for event %d before it is recorded", i, ph->wait[k]); rc = CHOLAMD_ERR_ARG; }
-    if (ph->record) { if (ph->record > nev) rc = CHOLAMD_ERR_ARG; else seen[ph->record] = 1; }
-  }
-  free(seen);
-  chol_level_work_free(&w);
-  if (!rc) {
-    qsort(a, na, sizeof(quad), cmp_quad);
-    qsort(b, nb, sizeof(quad), cmp_quad);
-    int64_t i = 0;
-    while (i < na && i < nb && !memcmp(&a[i], &b[i], sizeof(quad))) i++;
-    if (na != nb || i < na) {
-      const quad *x = i < na ? &a[i] : NULL, *y = i < nb ? &b[i] : NULL;
-      chol_set_error("program work differs from the level lists: %lld vs %lld items; first difference at %lld: levels (%lld, %lld, %lld, %lld) program (%lld, %lld, %lld, %lld)",
-                     (long long)na, (long long)nb, (long long)i, x ? (long long)x->a : 0, x ? (long long)x->b : 0, x ? (long long)x->c : 0, x ? (long long)x->d : 0,
-                     y ? (long long)y->a : 0, y ? (long long)y->b : 0, y ? (long long)y->c : 0, y ? (long long)y->d : 0);
-      rc = CHOLAMD_ERR_ARG;
-    }
-  }
-  free(a); free(b);
-  return rc;
 }
 
 void chol_level_work_free(chol_level_work *w)
@@ -890,12 +558,10 @@ int cholamd_plan_fill_host_part(const cholamd_plan *p, double *arena, int rank, 
   return 0;
 }
 
-int cholamd_plan_program_check(const cholamd_plan *p) { return chol_program_check(p); }
-
 int cholamd_plan_level_work_counts(const cholamd_plan *p, int level, int rank, int world, int out[4])
 {
   chol_level_work w;
-  int rc = chol_build_level_work(p, level, rank, world, &w);
+  int rc = chol_build_level_work(p, NULL, level, rank, world, &w);
   if (rc) return rc;
   int strips = 0; /* without the placeholders that fill the groups of four */
   for (int i = 0; i < w.n_trsm; i++) strips += w.trsm[i].m > 0;

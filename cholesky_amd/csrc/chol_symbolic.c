@@ -226,7 +226,12 @@ int chol_plan_finish(plan_t *p, int nz, const int *a_row, const int *a_col, cons
   int *px = malloc((size_t)(nz > 0 ? nz : 1) * sizeof(int)), *py = malloc((size_t)(nz > 0 ? nz : 1) * sizeof(int));
   for (int e = 0; e < nz; e++) {
     int i = a_row[e], j = a_col[e];
-    if (i < 0 || j < 0 || i >= n || j >= n) { chol_set_error("matrix entry %d out of range", e); return CHOLAMD_ERR_FORMAT; }
+    if (i < 0 || j < 0 || i >= n || j >= n) {
+      chol_set_error("matrix entry %d out of range", e);
+      for (int b = 0; b < p->nblk; b++) free(F[b].f);
+      free(F); free(px); free(py); /* a_dst / a_val belong to the plan: cholamd_plan_destroy frees them */
+      return CHOLAMD_ERR_FORMAT;
+    }
     if (a_val[e] == 0.0) continue; /* explicit zeros are invisible to the reference (mnd.c:168-195) */
     int pi = p->iperm[i], pj = p->iperm[j];
     int x = pi > pj ? pi : pj, y = pi > pj ? pj : pi;

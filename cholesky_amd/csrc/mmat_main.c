@@ -2,7 +2,9 @@
  *
  *   -i matrix.mtx  -s separators.txt  -c clusters.txt  [-b rhs.mtx] [-o solution] [-m factor.mtx]
  *   [-p permuted.mtx] [-d debug_dir] [--iterations n]
- * plus:  --gpu id (default 0), --full-precision (write %.17g instead of the reference's %0.8g).
+ * plus:  --gpu id (first device, default 0), --gpus n (subtree-sharded over n devices of this node, one RCCL all-reduce;
+ *        n a power of two), --repeat n (= --iterations), --full-precision (write %.17g instead of the reference's
+ *        %0.8g), --precision fp64|mixed (mixed: fp32 factor + fp64 iterative refinement of the solve).
  * Unknown flags (the reference passes -fflow/-ll:cpu/-fcuda/-ll:csize through to Legion) are ignored.
  *
  * Flow = main() of mmat.rg:1056-1496 with the numeric phase on the GPU.  Progress lines keep the
@@ -28,7 +30,8 @@ int main(int argc, char **argv)
 {
   const char *matrix_file = "", *separator_file = "", *clusters_file = "", *b_file = "", *solution_file = "", *factor_file = "",
              *permuted_file = "", *debug_path = "";
-  int debug = 0, iterations = 1, gpu = 0, full = 0;
+  int debug = 0, iterations = 1, gpu = 0, full = 0, gpus = 1;
+  const char *precision = "fp64";
   for (int i = 0; i < argc; i++) {
     const char *next = i + 1 < argc ? argv[i + 1] : "";
     if (!strcmp(argv[i], "-i")) matrix_file = next;
@@ -40,7 +43,10 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[i], "-b")) b_file = next;
     else if (!strcmp(argv[i], "-d")) { debug_path = next; debug = 1; }
     else if (!strcmp(argv[i], "--iterations")) iterations = atoi(next);
+    else if (!strcmp(argv[i], "--repeat")) iterations = atoi(next);
     else if (!strcmp(argv[i], "--gpu")) gpu = atoi(next);
+    else if (!strcmp(argv[i], "--gpus")) gpus = atoi(next);
+    else if (!strcmp(argv[i], "--precision")) precision = next;
     else if (!strcmp(argv[i], "--full-precision")) full = 1;
   }
   printf("Iterations: %d\n", iterations);
@@ -74,28 +80,47 @@ int main(int argc, char **argv)
     fclose(f);
   }
 
-  cholamd_device *dev = NULL;
-  if (cholamd_device_create(plan, gpu, &dev)) DIE("device: %s", cholamd_last_error());
-  double *d_arena = NULL;
-  if (cholamd_device_alloc(dev, na, &d_arena)) DIE("alloc: %s", cholamd_last_error());
+  if (strcmp(precision, "fp64")) DIE("--precision %s is not supported (fp64)", precision);
+  if (gpus < 1 || gpus > 64 || (gpus & (gpus - 1))) DIE("--gpus must be a power of two");
+  if (cholamd_device_count() < gpu + gpus) DIE("--gpus %d from device %d: only %d HIP devices are visible", gpus, gpu, cholamd_device_count());
+  /* one device object + arena per GPU; devs[0] ends up with the complete factor */
+  cholamd_device *devs[64] = { NULL };
+  double *arenas[64] = { NULL };
+  cholamd_comm *comms[64] = { NULL };
+  for (int g = 0; g < gpus; g++) {
+    if (cholamd_device_create(plan, gpu + g, &devs[g])) DIE("device %d: %s", gpu + g, cholamd_last_error());
+    if (gpus > 1 && cholamd_device_set_partition(devs[g], g, gpus)) DIE("partition: %s", cholamd_last_error());
+    if (cholamd_device_alloc(devs[g], na, &arenas[g])) DIE("alloc: %s", cholamd_last_error());
+  }
+  if (gpus > 1 && cholamd_comm_create_all(devs, gpus, comms)) DIE("rccl: %s", cholamd_last_error());
+  cholamd_device *dev = devs[0];
+  double *d_arena = arenas[0];
   printf("Done fill.\n");
   double t_factor = 0;
   for (int it = 0; it < iterations; it++) { /* mmat.rg:1212-1358 */
-    if (cholamd_device_fill(dev, d_arena, NULL) || cholamd_device_sync(dev, NULL)) DIE("fill: %s", cholamd_last_error());
+    for (int g = 0; g < gpus; g++)
+      if (cholamd_device_fill(devs[g], arenas[g], NULL) || cholamd_device_sync(devs[g], NULL)) DIE("fill: %s", cholamd_last_error());
     for (int lvl = levels - 1, interval = 0; lvl >= 0; lvl--) {
       printf("Factoring Level: %d Interval: %d Iteration: %d\n", lvl, interval, it);
       if (lvl <= levels - 2) interval++;
     }
     double t1 = now_s();
-    if (cholamd_factor(dev, d_arena, NULL) || cholamd_device_sync(dev, NULL)) DIE("factor: %s", cholamd_last_error());
+    if (cholamd_factor_multi(devs, arenas, comms, gpus, NULL)) DIE("factor: %s", cholamd_last_error());
+    for (int g = 0; g < gpus; g++) if (cholamd_device_sync(devs[g], NULL)) DIE("factor: %s", cholamd_last_error());
     t_factor = now_s() - t1;
-    int sep = 0, info = cholamd_factor_info(dev, &sep);
-    if (info > 0) fprintf(stderr, "warning: leading minor %d of separator %d is not positive definite\n", info, sep);
+    for (int g = 0; g < gpus; g++) {
+      int sep = 0, info = cholamd_factor_info(devs[g], &sep);
+      if (info < 0) DIE("factor: %s", cholamd_last_error()); /* internal failure (stall watchdog / HIP error): no output file is written */
+      if (info > 0) fprintf(stderr, "warning: leading minor %d of separator %d is not positive definite\n", info, sep);
+    }
     printf("Done factoring Iteration: %d.\n", it);
   }
+  if (gpus > 1) { /* the subtrees' panels -> device 0 */
+    if (cholamd_gather_factor(devs, arenas, gpus, NULL) || cholamd_device_sync(dev, NULL)) DIE("gather: %s", cholamd_last_error());
+  }
   const double flops = cholamd_plan_flops(plan);
-  fprintf(stderr, "[cholamd] symbolic %.3f ms, numeric factorisation %.3f ms, F_ref %.6g flop, %.3f GF/s, B_alg %ld bytes\n",
-          1e3 * t_sym, 1e3 * t_factor, flops, flops / t_factor * 1e-9, (long)cholamd_plan_alg_bytes(plan));
+  fprintf(stderr, "[cholamd] %d GPU(s), symbolic %.3f ms, numeric factorisation %.3f ms, F_ref %.6g flop, %.3f GF/s, B_alg %ld bytes\n",
+          gpus, 1e3 * t_sym, 1e3 * t_factor, flops, flops / t_factor * 1e-9, (long)cholamd_plan_alg_bytes(plan));
 
   if (*factor_file) { /* mmat.rg:1360-1362 */
     if (cholamd_device_download(dev, h_arena, d_arena, na, NULL)) DIE("download: %s", cholamd_last_error());
@@ -116,8 +141,11 @@ int main(int argc, char **argv)
     cholamd_device_free(dev, d_b); cholamd_device_free(dev, d_x);
     free(b); free(x);
   }
-  cholamd_device_free(dev, d_arena);
-  cholamd_device_destroy(dev);
+  for (int g = 0; g < gpus; g++) {
+    cholamd_comm_destroy(comms[g]);
+    cholamd_device_free(devs[g], arenas[g]);
+    cholamd_device_destroy(devs[g]);
+  }
   cholamd_plan_destroy(plan);
   free(h_arena);
   return 0;

@@ -83,6 +83,22 @@ class Device:
     def set_partition(self, rank, world):
         check(self.L.cholamd_device_set_partition(self.h, rank, world), "cholamd_device_set_partition")
 
+    def set_option(self, name, value):
+        """Schedule / kernel-selection switch of this device object (cholamd_device_set_option)."""
+        check(self.L.cholamd_device_set_option(self.h, name.encode(), int(value)), "cholamd_device_set_option")
+
+    def tail_offset(self):
+        """First double of the shared top of the tree in the arena under the current partition."""
+        return int(self.L.cholamd_device_tail_offset(self.h))
+
+    def exchange_tail(self, arena, comm, stream=None):
+        """The extend-add exchange alone: in-place RCCL all-reduce (sum) of the arena tail (cholamd_exchange_tail)."""
+        check(self.L.cholamd_exchange_tail(self.h, self.ptr(arena), comm.h, _stream_ptr(stream)), "cholamd_exchange_tail")
+
+    def factor_sharded(self, arena, comm, stream=None):
+        """This rank's part of a sharded factorisation (cholamd_factor_sharded): local levels, RCCL exchange, top levels."""
+        check(self.L.cholamd_factor_sharded(self.h, self.ptr(arena), comm.h if comm is not None else None, _stream_ptr(stream)), "cholamd_factor_sharded")
+
     def info(self):
         sep = C.c_int(0)
         rc = self.L.cholamd_factor_info(self.h, C.byref(sep))
@@ -96,8 +112,42 @@ class Device:
     def set_timing(self, on):
         check(self.L.cholamd_device_set_timing(self.h, int(on)), "set_timing")
 
+    def event_overhead_ms(self, stream=None):
+        v = C.c_float(0)
+        check(self.L.cholamd_device_event_overhead(self.h, _stream_ptr(stream), C.byref(v)), "event_overhead")
+        return float(v.value)
+
     def get_timing(self):
         ms = np.zeros(4, dtype=np.float32)
         cnt = np.zeros(4, dtype=np.int32)
         check(self.L.cholamd_device_get_timing(self.h, ms.ctypes.data, cnt.ctypes.data), "get_timing")
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KINDS)}
+
+
+class Comm:
+    """An RCCL communicator owned by libcholamd (cholamd_comm_create: ncclCommInitRank on the device's GPU)."""
+
+    def __init__(self, dev, world, rank, unique_id):
+        self.L = load()
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        check(self.L.cholamd_comm_create(dev.h, world, rank, buf, C.byref(h)), "cholamd_comm_create")
+        self.h, self.world, self.rank = h, world, rank
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(load().cholamd_comm_unique_id(buf), "cholamd_comm_unique_id")
+        return bytes(buf.raw)
+
+    def allreduce(self, t, stream=None):
+        """In-place fp64 sum of a CUDA tensor over the ranks (cholamd_comm_allreduce)."""
+        check(self.L.cholamd_comm_allreduce(self.h, C.c_void_p(t.data_ptr()), t.numel(), _stream_ptr(stream)), "cholamd_comm_allreduce")
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.cholamd_comm_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass

@@ -132,10 +132,6 @@ class Plan:
         check(self.L.cholamd_plan_level_work_counts(self.h, level, rank, world, out.ctypes.data), "cholamd_plan_level_work_counts")
         return tuple(int(v) for v in out)
 
-    def program_check(self):
-        """Host-side self-check of the two-stream launch program (raises CholamdError on a mismatch)."""
-        check(self.L.cholamd_plan_program_check(self.h), "cholamd_plan_program_check")
-
     def arena_to_dense(self, arena):
         arena = np.ascontiguousarray(arena, dtype=np.float64)
         assert arena.size == self.arena_doubles

@@ -43,6 +43,9 @@ extern "C" {
 #define CHOLAMD_ERR_NO_DEVICE (-5)   /* no usable HIP device: there is NO CPU fallback */
 #define CHOLAMD_ERR_HIP (-6)         /* a HIP runtime call failed (see cholamd_last_error) */
 #define CHOLAMD_ERR_NOMEM (-7)
+#define CHOLAMD_ERR_COMM (-9)        /* an RCCL call failed (see cholamd_last_error) */
+#define CHOLAMD_ERR_STALL (-8)       /* cholamd_factor_info only: a workgroup of a fused launch gave up waiting (~50 ms) for a progress
+                                      * word of the same launch; the factor in the arena is NOT valid */
 /* > 0: LAPACK-style info of the first failing pivot (see cholamd_factor_info) */
 
 const char *cholamd_last_error(void);
@@ -56,7 +59,10 @@ const char *cholamd_version(void);
 /*   mm_write_mtx_crd_size mmio.c:181-187  (called mmat.rg:129)                                 */
 /* Same names, same argument meaning, same return codes (mmio.h:73-79), so libmmio.so's users    */
 /* can link this library instead.  Like the reference, mm_read_banner does NOT run mm_is_valid,  */
-/* so the fixtures' "real hermitian" banner is accepted.                                         */
+/* so the fixtures' "real hermitian" banner is accepted.  One deliberate difference:             */
+/* mm_write_mtx_crd_size returns 0 when the size line was written; the reference compares        */
+/* fprintf's character count with 3 (mmio.c:181-187) and so reports MM_COULD_NOT_WRITE_FILE for   */
+/* every successful write -- a return value its only caller ignores (mmat.rg:129).                */
 /* ----------------------------------------------------------------------------------------- */
 typedef char MM_typecode[4];
 #define MM_COULD_NOT_READ_FILE 11
@@ -169,10 +175,6 @@ int cholamd_plan_fill_host_part(const cholamd_plan *p, double *arena, int rank, 
 /* sizes of the device work lists of one tree level for (rank, world): potrf descriptors, trsm
  * strips, update tasks, update sources */
 int cholamd_plan_level_work_counts(const cholamd_plan *p, int level, int rank, int world, int out[4]);
-/* host-side self-check of the two-stream launch program cholamd_factor() runs on one GPU: same POTRF blocks,
- * TRSM strips and (target tile, source) pairs as the per-level lists, every event recorded before it is awaited;
- * 0 = consistent, otherwise cholamd_last_error() names the first difference */
-int cholamd_plan_program_check(const cholamd_plan *p);
 /* dense N x N col-major image of an arena (zeros outside allocated blocks) and back */
 int cholamd_plan_arena_to_dense(const cholamd_plan *p, const double *arena, double *dense);
 /* write_matrix (mmat.rg:102-147): banner, "M N nnz", "row col %0.8g" per non-zero, block by
@@ -237,14 +239,56 @@ int cholamd_factor_levels(cholamd_device *d, double *d_arena, int level_hi, int 
  * restores the full schedule. */
 int cholamd_device_set_partition(cholamd_device *d, int rank, int world);
 /* LAPACK-style info after the stream has been synchronised: 0 ok; k > 0 = leading minor k of the
- * pivot of separator *sep_out is not positive definite (the reference ignores this, blas.rg:71) */
+ * pivot of separator *sep_out is not positive definite (the reference ignores this, blas.rg:71);
+ * < 0 = the factorisation itself failed (CHOLAMD_ERR_STALL, or a HIP error code of this call) and
+ * cholamd_last_error() says why -- callers must not use the factor in either non-zero case. */
 int cholamd_factor_info(cholamd_device *d, int *sep_out);
-/* Solve phase, mmat.rg:1364-1495: b and x in ORIGINAL dof order (device pointers, n doubles) */
+/* Schedule / kernel-selection switches of this device object.  They default to the values the environment gave when
+ * the object was created (CHOLAMD_SPLIT_MIN, CHOLAMD_SPLIT_NB, CHOLAMD_NO_FUSE, CHOLAMD_FUSE_UPDATE_MAX,
+ * CHOLAMD_MT_MIN_TILES, CHOLAMD_NO_CELLS, CHOLAMD_SOLVE_REFERENCE_SHAPE: read once, there); names: "split_min",
+ * "split_nb", "fuse", "fuse_update_max", "mt_min_tiles", "cells", "solve_reference_shape".  Rebuilds the work lists. */
+int cholamd_device_set_option(cholamd_device *d, const char *name, int value);
+/* Solve phase, mmat.rg:1364-1495: b and x in ORIGINAL dof order (device pointers, n doubles).
+ * The off-diagonal blocks accumulate into the vector with hardware fp64 atomics, so x agrees from run to run to
+ * rounding (~1e-16 relative), NOT bit for bit; option "solve_reference_shape" selects the deterministic per-call
+ * kernels of the BLAS-level entry points instead (slow beyond ~10^5 unknowns). */
 int cholamd_solve(cholamd_device *d, const double *d_arena, const double *d_b, double *d_x, void *stream);
 /* average device time (ms) of the three kernel families of the last cholamd_factor call measured
  * with HIP events on its stream; valid after cholamd_device_sync.  Enable with set_timing(1). */
 int cholamd_device_set_timing(cholamd_device *d, int on);
 int cholamd_device_get_timing(cholamd_device *d, float ms_by_kind[4], int launches_by_kind[4]);
+/* mean elapsed time (ms) of an event pair with nothing between them on `stream`: the part of every timed launch
+ * above that is the event commands, not the kernel */
+int cholamd_device_event_overhead(cholamd_device *d, void *stream, float *ms_out);
+
+/* ----------------------------------------------------------------------------------------- */
+/* Multi-GPU (not in the reference, whose Legion runtime would move instances          */
+/* implicitly): one rank per GPU, the separator tree cut at level log2(world).  Rank g factors    */
+/* the subtrees under its level-d separator (cholamd_device_set_partition), its contributions to  */
+/* the shared top of the tree accumulate in its own copy of the arena TAIL (the top panels are    */
+/* contiguous: offset cholamd_device_tail_offset), ONE RCCL all-reduce (sum, fp64) over that tail  */
+/* is the extend-add exchange, then every rank factors the top levels.  libcholamd links RCCL;     */
+/* the communicator is an ncclComm_t made here or adopted from the caller.                         */
+/* ----------------------------------------------------------------------------------------- */
+typedef struct cholamd_comm cholamd_comm;
+#define CHOLAMD_UNIQUE_ID_BYTES 128
+int cholamd_comm_unique_id(char id[CHOLAMD_UNIQUE_ID_BYTES]);   /* ncclGetUniqueId: rank 0 calls it and hands the bytes to every rank */
+int cholamd_comm_create(cholamd_device *d, int world, int rank, const char id[CHOLAMD_UNIQUE_ID_BYTES], cholamd_comm **out); /* ncclCommInitRank on d's GPU (collective) */
+int cholamd_comm_create_all(cholamd_device *const *devs, int n, cholamd_comm **out /* n handles */); /* one process, n GPUs: ncclCommInitAll */
+int cholamd_comm_adopt(void *nccl_comm /* ncclComm_t */, int world, int rank, cholamd_comm **out);  /* the caller keeps ownership of the ncclComm_t */
+void cholamd_comm_destroy(cholamd_comm *c);
+int cholamd_comm_allreduce(cholamd_comm *c, double *d_buf, int64_t count, void *stream); /* in-place fp64 sum (ncclAllReduce), asynchronous on `stream` */
+int64_t cholamd_device_tail_offset(const cholamd_device *d);    /* first double of the shared top of the tree in the arena (arena size if world == 1) */
+/* the exchange alone: in-place ncclAllReduce(sum) of d_arena[tail .. arena), asynchronous on `stream` */
+int cholamd_exchange_tail(cholamd_device *d, double *d_arena, cholamd_comm *c, void *stream);
+/* one rank's part of a sharded factorisation: local levels, exchange, top levels; asynchronous on `stream`.
+ * The arena must have been filled by cholamd_device_fill AFTER cholamd_device_set_partition (rank-aware fill). */
+int cholamd_factor_sharded(cholamd_device *d, double *d_arena, cholamd_comm *c, void *stream);
+/* the same for one process driving n GPUs (devs[g] partitioned as rank g of n): the n all-reduces form one RCCL group */
+int cholamd_factor_multi(cholamd_device *const *devs, double *const *arenas, cholamd_comm *const *comms, int n, void *const *streams /* or NULL */);
+/* after cholamd_factor_multi: peer-copies the panels of the subtrees owned by ranks 1..n-1 into arenas[0], which then
+ * holds the complete factor (for cholamd_solve and the writers) */
+int cholamd_gather_factor(cholamd_device *const *devs, double *const *arenas, int n, void *const *streams /* or NULL */);
 
 /* ----------------------------------------------------------------------------------------- */
 /* L-B: task level -- the four fused leaf tasks of blas.rg.  A region is a block instance:     */

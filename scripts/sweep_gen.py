@@ -15,7 +15,7 @@ for (nx,ny,nz,lv,tile) in cases:
         except Exception as e:
             print((nx,ny,nz,lv,tile), "generator refused:", str(e)[:80]); continue
         m,o,c,b = prob.write(os.path.join(td,"g"))
-        plan = prob.plan(); plan.program_check()
+        plan = prob.plan()
         O = orc.Oracle(m,o,c); O.factor()
         dev = ca.Device(plan,0); a = dev.new_arena(); dev.fill(a); dev.factor(a); dev.sync()
         L = np.tril(plan.arena_to_dense(a.cpu().numpy())); Lo = np.tril(O.dense())

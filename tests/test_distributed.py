@@ -1,9 +1,13 @@
 """Multi-rank tests of the subtree sharding.
 
-* CPU (gloo, world_size 2): the host-side partition logic -- per-rank fills whose tails sum to the
+* CPU (gloo, world_size 2 and 8): the host-side partition logic -- per-rank fills whose tails sum to the
   full fill, and per-rank work lists that tile the full schedule -- with a real all-reduce.
 * GPU (marker gpu; gloo, 2 and 4 ranks sharing the one GPU of the test box): the sharded
-  factorisation equals the single-GPU one to 1e-12."""
+  factorisation equals the single-GPU one to 1e-12.  World 8 (BASELINE config 4's rank count) runs its
+  eight partitions in ONE process (the box admits at most 6 processes on the card), the exchange being a
+  device-side sum of the eight tails.
+* RCCL: the C-ABI communicator is exercised for real -- a one-rank ncclAllReduce on the one GPU, and the
+  complete cholamd_factor_sharded path on two GPUs when the box has them (skipped otherwise)."""
 import os
 import socket
 
@@ -48,12 +52,12 @@ def _cpu_worker(rank, world, port, case, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["lapl_400x400", "lapl_3375x3375"])
-def test_partition_logic_gloo_world2(case):
+@pytest.mark.parametrize("case,world", [("lapl_400x400", 2), ("lapl_3375x3375", 2), ("lapl_3375x3375", 8)])
+def test_partition_logic_gloo(case, world):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_cpu_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    procs = [ctx.Process(target=_cpu_worker, args=(r, world, port, case, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -129,3 +133,134 @@ def test_sharded_factorisation_matches_single_gpu(world):
     # every rank holds the same top factor
     for r in range(1, world):
         assert np.abs(parts[r][tail:] - parts[0][tail:]).max() <= 1e-12
+
+
+def _assemble(plan, parts, world, ref_like):
+    """Panel of separator s from its owner's arena, the top from rank 0."""
+    d = world.bit_length() - 1
+    tree = plan.tree
+    owner = {}
+    for h in range(1, plan.nsep + 1):
+        lvl = h.bit_length() - 1
+        owner[int(tree[h - 1])] = 0 if lvl < d else (h >> (lvl - d)) - (1 << d)
+    diag = {int(b[1]): int(b[7]) for b in plan.blocks if b[0] == b[1]}
+    order = sorted(diag)
+    out = np.zeros_like(ref_like)
+    for i, s in enumerate(order):
+        lo = diag[s]
+        hi = diag[order[i + 1]] if i + 1 < len(order) else plan.arena_doubles
+        out[lo:hi] = parts[owner[s]][lo:hi]
+    return out
+
+
+@pytest.mark.gpu
+def test_sharded_world8_in_one_process():
+    """BASELINE config 4's partition (8 ranks, tree cut at level 3): the eight rank programs run one after the
+    other on the one GPU, the exchange is the device-side sum of the eight tails; result == single-GPU factor."""
+    import cholesky_amd as ca
+    from cholesky_amd import parallel
+    case, world = "lapl_3375x3375", 8
+    plan = ca.Plan(*case_paths(case)[:3])
+    one = ca.Device(plan, 0)
+    ref_t = one.new_arena()
+    one.fill(ref_t)
+    one.factor(ref_t)
+    one.sync()
+    ref = ref_t.cpu().numpy()
+    d = parallel.split_level(world)
+    tail = parallel.tail_offset(plan, world)
+    devs, arenas = [], []
+    for r in range(world):
+        dev = ca.Device(plan, 0)
+        dev.set_partition(r, world)
+        assert dev.tail_offset() == tail
+        a = dev.new_arena()
+        dev.fill(a)
+        dev.factor_levels(a, plan.levels - 1, d)
+        devs.append(dev)
+        arenas.append(a)
+    torch.cuda.synchronize()
+    total = torch.stack([a[tail:] for a in arenas]).sum(dim=0)
+    for dev, a in zip(devs, arenas):
+        a[tail:] = total
+        dev.factor_levels(a, d - 1, 0)
+        dev.sync()
+        assert dev.info() == (0, 0)
+    parts = [a.cpu().numpy() for a in arenas]
+    assert np.abs(_assemble(plan, parts, world, ref) - ref).max() <= 1e-12
+    for r in range(1, world):
+        assert np.array_equal(parts[r][tail:], parts[0][tail:])
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_allreduce_and_sharded_entry():
+    """libcholamd's RCCL binding runs: unique id, ncclCommInitRank, an in-place ncclAllReduce on the stream, and
+    cholamd_factor_sharded (world 1 = the plain level loop) through the communicator-taking entry point."""
+    import cholesky_amd as ca
+    plan = ca.Plan(*case_paths("lapl_400x400")[:3])
+    dev = ca.Device(plan, 0)
+    comm = ca.Comm(dev, 1, 0, ca.Comm.unique_id())
+    t = torch.arange(1000, dtype=torch.float64, device="cuda")
+    comm.allreduce(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64))
+    a, b = dev.new_arena(), dev.new_arena()
+    dev.fill(a)
+    dev.fill(b)
+    dev.factor(a)
+    dev.factor_sharded(b, comm)
+    dev.sync()
+    assert torch.equal(a, b)
+
+
+def _rccl_worker(rank, world, port, case, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # carries the unique id only
+    import cholesky_amd as ca
+    from cholesky_amd import parallel
+    plan = ca.Plan(*case_paths(case)[:3])
+    dev = ca.Device(plan, rank)  # one GPU per rank
+    dev.set_partition(rank, world)
+    comm = parallel.make_comm(dev, world, rank)
+    torch.cuda.set_device(rank)
+    arena = dev.new_arena()
+    dev.fill(arena)
+    parallel.factor_sharded(dev, arena, world, dev.tail_offset(), comm=comm)
+    dev.sync()
+    info = dev.info()
+    mine = arena.cpu()
+    gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, gathered, dst=0)
+    if rank == 0:
+        q.put((info, [g.numpy() for g in gathered]))
+    del comm
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_factorisation_over_rccl_two_gpus():
+    """The product path of BASELINE config 4 at world 2: one process per GPU, cholamd_factor_sharded with a real
+    RCCL all-reduce between the devices.  Needs two GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (the round's test box has one)")
+    import cholesky_amd as ca
+    case, world = "lapl_3375x3375", 2
+    plan = ca.Plan(*case_paths(case)[:3])
+    dev = ca.Device(plan, 0)
+    arena = dev.new_arena()
+    dev.fill(arena)
+    dev.factor(arena)
+    dev.sync()
+    ref = arena.cpu().numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    info, parts = q.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert info == (0, 0)
+    assert np.abs(_assemble(plan, parts, world, ref) - ref).max() <= 1e-12

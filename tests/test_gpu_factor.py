@@ -209,54 +209,39 @@ def _ntiles_table(case):
     return table
 
 
-_ALT_SCRIPT = r"""
-import sys
-import numpy as np
-import torch
-sys.path.insert(0, sys.argv[1])
-sys.path.insert(0, sys.argv[1] + "/tests")
-import cholesky_amd as ca
-from conftest import case_paths
-m, o, c, b = case_paths(sys.argv[2])
-plan = ca.Plan(m, o, c)
-dev = ca.Device(plan, 0)
-arena = dev.new_arena()
-dev.fill(arena)
-dev.factor(arena)
-dev.sync()
-assert dev.info() == (0, 0)
-g = np.load(sys.argv[1] + "/tests/golden/" + sys.argv[2] + "/golden.npz")
-L = np.tril(plan.arena_to_dense(arena.cpu().numpy()))
-ref = np.zeros_like(L)
-ref[g["L_row"], g["L_col"]] = g["L_val"]
-bvec = ca.plan.read_vector(b, plan.n)
-d_b = torch.from_numpy(bvec).cuda()
-d_x = torch.empty_like(d_b)
-dev.solve(arena, d_b, d_x)
-dev.sync()
-print("RESULT", float(np.abs(L - ref).max()), float(np.abs(d_x.cpu().numpy() - g["x"]).max()))
-"""
+@pytest.mark.parametrize("opts", [
+    {"fuse": 0},                                       # separate POTRF / TRSM launches (k_potrf_rr, k_trsm_rr, k_trsm_w)
+    {"fuse_update_max": 100000},                       # update tasks inside the fused launch
+    {"split_min": 272, "split_nb": 256},               # pivots factored whole (k_potrf_rr up to 17 tiles)
+    {"split_min": 64, "split_nb": 64},                 # many column-block steps per pivot
+    {"cells": 0},                                      # extend-add by the reference's cluster tiles instead of grid cells
+    {"solve_reference_shape": 1},                      # the per-call (deterministic) solve kernels
+], ids=lambda o: "+".join(f"{k}={v}" for k, v in o.items()))
+def test_alternative_launch_paths_keep_parity(opts, ca, golden):
+    """Every schedule / launch variant selectable through cholamd_device_set_option factors lapl_3375 to the same L
+    (reference golden, 1e-12) and solves to the same x."""
+    import torch
+    case = "lapl_3375x3375"
+    m, o, c, b = case_paths(case)
+    plan = ca.Plan(m, o, c)
+    dev = ca.Device(plan, 0)
+    for k, v in opts.items():
+        dev.set_option(k, v)
+    arena = dev.new_arena()
+    dev.fill(arena)
+    dev.factor(arena)
+    dev.sync()
+    assert dev.info() == (0, 0)
+    g = golden(case)
+    L = np.tril(plan.arena_to_dense(arena.cpu().numpy()))
+    assert np.abs(L - g["L"]).max() <= TOL_L
+    d_b = torch.from_numpy(ca.plan.read_vector(b, plan.n)).cuda()
+    d_x = torch.empty_like(d_b)
+    dev.solve(arena, d_b, d_x)
+    dev.sync()
+    assert np.abs(d_x.cpu().numpy() - g["x"]).max() <= 1e-9
 
 
-@pytest.mark.parametrize("env", [
-    {"CHOLAMD_NO_FUSE": "1"},                                      # separate POTRF / TRSM launches (k_potrf_rr, k_trsm_rr, k_trsm_w)
-    {"CHOLAMD_OVERLAP": "1"},                                      # the two-stream HIP-graph program
-    {"CHOLAMD_FUSE_UPDATE_MAX": "100000"},                         # update tasks inside the fused launch
-    {"CHOLAMD_SPLIT_MIN": "272", "CHOLAMD_SPLIT_NB": "256"},       # pivots factored whole (k_potrf_rr up to 17 tiles)
-    {"CHOLAMD_SPLIT_MIN": "64", "CHOLAMD_SPLIT_NB": "64"},         # many column-block steps per pivot
-    {"CHOLAMD_SOLVE_REFERENCE_SHAPE": "1"},                        # the per-call solve kernels
-], ids=lambda e: "+".join(f"{k[8:]}={v}" for k, v in e.items()))
-def test_alternative_launch_paths_keep_parity(env):
-    """Every schedule / launch variant selectable by environment factors lapl_3375 to the same L (golden, 1e-12)
-    and solves to the same x; each runs in its own process (the switches are read once per process)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    e = dict(os.environ)
-    e.update(env)
-    out = subprocess.run([sys.executable, "-c", _ALT_SCRIPT, root, "lapl_3375x3375"], env=e, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
-    assert float(line[1]) <= TOL_L, line
-    assert float(line[2]) <= 1e-9, line
+def test_unknown_option_is_refused(ca, runs):
+    with pytest.raises(ca.CholamdError):
+        runs["lapl_9x9"]["dev"].set_option("no_such_switch", 1)

@@ -216,13 +216,3 @@ def test_partition_work_lists(ca, plans):
             assert len(mine) == (P.nsep - (world - 1)) // world
         top = sorted(s for s, o in owners.items() if o == -1)
         assert top == list(range(P.nsep - (world - 1) + 1, P.nsep + 1))
-
-
-@pytest.mark.parametrize("case", list(CASES))
-def test_two_stream_program_covers_the_level_lists(case):
-    """cholamd_factor() on one GPU runs one launch list on two streams (critical path / bulk work): host-side
-    check that it holds exactly the POTRF blocks, TRSM rows and (target tile, source) pairs of the per-level
-    lists and that every event is recorded before the launch waiting for it."""
-    import cholesky_amd as ca
-    m, o, c, _ = case_paths(case)
-    ca.Plan(m, o, c).program_check()
