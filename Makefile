@@ -10,7 +10,7 @@ CFLAGS  := -O2 -fPIC -Wall -Wextra -std=gnu11 -Iinclude -I$(CSRC)
 HIPFLAGS:= -O3 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall
 
 HOST_OBJS := $(OUT)/chol_ingest.o $(OUT)/chol_symbolic.o $(OUT)/chol_schedule.o $(OUT)/chol_generate.o
-HIP_OBJS  := $(OUT)/chol_kernels.o $(OUT)/chol_api.o
+HIP_OBJS  := $(OUT)/chol_kernels.o $(OUT)/chol_kernels_f32.o $(OUT)/chol_api.o
 
 all: $(OUT)/libcholamd.so $(BIN)/cholamd_mmat oracle
 
@@ -19,6 +19,10 @@ $(OUT)/%.o: $(CSRC)/%.c $(CSRC)/chol_plan.h include/cholamd.h
 	$(CC) $(CFLAGS) -c $< -o $@
 
 $(OUT)/chol_kernels.o: $(CSRC)/chol_kernels.hip $(CSRC)/chol_plan.h $(CSRC)/chol_kernels.h
+	@mkdir -p $(OUT)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OUT)/chol_kernels_f32.o: $(CSRC)/chol_kernels_f32.hip $(CSRC)/chol_plan.h $(CSRC)/chol_kernels.h
 	@mkdir -p $(OUT)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

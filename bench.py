@@ -38,18 +38,22 @@ CASES = {
 }
 PEAK_FP64_TFLOPS = 78.6   # MI355X dense fp64 (vector = matrix) peak, public spec; the microarch guide lists no fp64 row
 PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")  # rocprofv3 --pmc passes of this very command
+PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = the fp32 vector rate
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r2", "summary.json")  # scripts/profile_summary.py over the rocprofv3 passes of this command
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (counters cannot be read live
-    from inside the process); None if that profile is not there."""
+def profile_numbers(kernel, case, mixed):
+    """Counter-derived numbers of `kernel` for this workload from the committed rocprofv3 passes (counters cannot be
+    read live from inside the process): HBM bytes per launch, average launch duration, MFMA busy fraction."""
     try:
-        with open(PMC_SUMMARY) as f:
-            k = json.load(f)["kernels"][kernel]
-        return k["hbm_bytes_per_launch_corrected"]
+        with open(PROFILE_SUMMARY) as f:
+            runs = json.load(f)["runs"]
+        key = case + (":mixed" if mixed else "")
+        k = runs[key]["kernels"][kernel]
+        return {"hbm_bytes_per_launch": k.get("hbm_bytes_per_launch_corrected"), "avg_launch_us": k.get("avg_launch_us"),
+                "mfma_busy_frac": k.get("mfma_busy_frac"), "source": "profiles/r2/summary.json: " + runs[key].get("source", "")}
     except Exception:
-        return None
+        return {}
 
 
 def cpu_baseline(files, flops, budget_s=12.0):
@@ -96,6 +100,8 @@ def main():
     ap.add_argument("--case", default="lapl_3375x3375",
                     help="a reference fixture (default: the metric's configuration) or gen:N:levels[:tile] = a generated N^3 7-point "
                          "Laplacian with geometric nested dissection (e.g. gen:100:10, BASELINE config 5's matrix; no cpu_baseline)")
+    ap.add_argument("--precision", default="fp64", choices=["fp64", "mixed"],
+                    help="mixed = fp32 factor (the timed step) + fp64 iterative refinement of one solve (reported in config), BASELINE config 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.gpus < 1 or args.gpus & (args.gpus - 1):
@@ -144,21 +150,28 @@ def main():
         dev.set_partition(rank, world)
         comm = parallel.make_comm(dev, world, rank)  # libcholamd's own RCCL communicator (unique id broadcast by the process group)
 
+    mixed = args.precision == "mixed"
+    if mixed and world > 1:
+        sys.exit("bench.py: --precision mixed is a single-GPU path")
     K, W = args.steps, args.warmup
     stream = torch.cuda.current_stream()
-    per_arena = plan.arena_doubles * 8
+    per_arena = plan.arena_doubles * (4 if mixed else 8)
     n_arenas = max(1, min(K + W, int((8e9 if not generated else 4e10) // per_arena)))
-    arenas = [dev.new_arena() for _ in range(n_arenas)]
+    arenas = [dev.new_arena_f32() if mixed else dev.new_arena() for _ in range(n_arenas)]
+    fill = dev.fill_f32 if mixed else dev.fill
 
     def refill():
         for a in arenas:
-            dev.fill(a, stream)
+            fill(a, stream)
         dev.sync(stream)
 
     def step(a):
         # world > 1: local subtree levels, ONE RCCL all-reduce of the arena tail (extend-add
         # contributions to the shared ancestors), then the top levels
-        parallel.factor_sharded(dev, a, world, tail_off, stream, comm=comm)
+        if mixed:
+            dev.factor_f32(a, stream)
+        else:
+            parallel.factor_sharded(dev, a, world, tail_off, stream, comm=comm)
 
     def fence():
         torch.cuda.synchronize()
@@ -191,7 +204,7 @@ def main():
         for i in range(K):
             a = arenas[i % n_arenas]
             if i >= n_arenas:
-                dev.fill(a, stream)
+                fill(a, stream)
             fence()
             t0 = time.perf_counter()
             step(a)
@@ -212,61 +225,95 @@ def main():
 
     # dominant-kernel roofline: HIP events recorded by the library around every launch, on the
     # stream the kernels run on, in a separate pass over pre-filled arenas
+    refine = None
+    if mixed:  # the other half of the configuration: one right-hand side solved to fp64 accuracy with the fp32 factor
+        if generated:
+            bvec = torch.from_numpy(ca.Problem(gn, gn, gn, glv, gtile).rhs()).cuda()
+        else:
+            bvec = torch.from_numpy(ca.plan.read_vector(os.path.join(os.path.dirname(files[0]), f"B_{plan.n}x1.mtx"), plan.n)).cuda()
+        xvec = torch.empty_like(bvec)
+        dev.solve_refine(arenas[(done + K - 1) % n_arenas] if K <= n_arenas else arenas[(K - 1) % n_arenas], bvec, xvec, 30, 1e-11, stream)  # warm-up (work lists, CSR upload)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        it, rel = dev.solve_refine(arenas[(done + K - 1) % n_arenas] if K <= n_arenas else arenas[(K - 1) % n_arenas], bvec, xvec, 30, 1e-11, stream)
+        torch.cuda.synchronize()
+        refine = {"corrections": it, "relres": rel, "ms": round((time.perf_counter() - t0) * 1e3, 3), "tol": 1e-11}
     refill()
     dev.set_timing(1)
     reps = min(n_arenas, 20)
     for a in arenas[:reps]:
-        dev.factor(a, stream) if world == 1 else dev.factor_levels(a, plan.levels - 1, split, stream)
+        if mixed:
+            dev.factor_f32(a, stream)
+        else:
+            dev.factor(a, stream) if world == 1 else dev.factor_levels(a, plan.levels - 1, split, stream)
     dev.sync(stream)
     timing = dev.get_timing()
     dev.set_timing(0)
+    ev_ms = dev.event_overhead_ms(stream)  # what an empty (record, record) pair reads on this stream
 
     if rank == 0:
         calls, flops = plan.counts()
         kinds = {"potrf": float(flops[0]), "trsm": float(flops[1]), "update": float(flops[2] + flops[3])}
-        # the library fuses the POTRF and TRSM of a column-block step into one launch (k_potrf_trsm), timed as
-        # "potrf"; separate TRSM launches only exist with CHOLAMD_NO_FUSE
+        # the fp64 library fuses the POTRF and TRSM of a column-block step into one launch (k_potrf_trsm), timed as
+        # "potrf"; separate TRSM launches exist in the fp32 schedule (and with option fuse = 0)
         fused = timing["trsm"][1] == 0
         if fused:
             kinds["potrf"] += kinds["trsm"]
-        # algorithmic bytes of those launches: every pivot block and every filled ancestor row of its panel is read
-        # and written once (16 B per entry), the pivot once more by the strips solving against it (8 B)
+        # dense-panel bytes of those launches: every pivot block and every filled ancestor row of its panel read and
+        # written once, the pivot once more by the strips solving against it
+        eb = 4.0 if mixed else 8.0
         blocks = plan.blocks
         sizes = {int(b[1]): int(b[4] - b[2] + 1) for b in blocks if b[0] == b[1]}
         piv_entries = sum(n * (n + 1) // 2 for n in sizes.values())
         anc_entries = sum(int(b[4] - b[2] + 1) * sizes[int(b[1])] for b in blocks if b[0] != b[1])
-        alg_bytes = {"potrf": 16.0 * piv_entries + (16.0 * anc_entries + 8.0 * piv_entries if fused else 0.0),
-                     "trsm": 16.0 * anc_entries + 8.0 * piv_entries, "update": None}
+        panel_bytes = {"potrf": 2 * eb * piv_entries + (2 * eb * anc_entries + eb * piv_entries if fused else 0.0),
+                       "trsm": 2 * eb * anc_entries + eb * piv_entries, "update": None}
         dom = max(("potrf", "trsm", "update"), key=lambda k: timing[k][0])
         ms, n_launch = timing[dom]
-        avg_s = ms / max(n_launch, 1) * 1e-3
         launches_per_factor = n_launch / reps
+        # launch duration: HIP events around every launch on the launch stream, minus the empty-pair reading (the event
+        # commands themselves); the committed rocprofv3 --kernel-trace --stats of this command is the cross-check
+        avg_s_raw = ms / max(n_launch, 1) * 1e-3
+        avg_s = max(avg_s_raw - ev_ms * 1e-3, 1e-9)
         flops_per_launch = kinds[dom] / max(launches_per_factor, 1) if world == 1 else None
         achieved = (flops_per_launch / avg_s * 1e-12) if flops_per_launch else None
+        peak = PEAK_FP32_TFLOPS if mixed else PEAK_FP64_TFLOPS
         value = plan.flops * K / dt * 1e-9
+        if mixed:
+            names = {"potrf": "k32_potrf", "trsm": "k32_trsm", "update": "k32_update_mt + k32_update"}
+        else:
+            names = {"potrf": "k_potrf_trsm" if fused else "k_potrf_rr", "trsm": "k_trsm_rr", "update": "k_update_mt + k_update" if generated else "k_update"}
+        prof = profile_numbers(names[dom].split(" + ")[0], args.case, mixed)
         out = {
-            "metric": "fp64 factorization GF/s (numeric level loop, F_ref flops) on 3-D Laplacian",
+            "metric": "fp64 factorization GF/s (numeric level loop, F_ref flops) on 3-D Laplacian" if not mixed else
+                      "fp32 factorization GF/s (numeric level loop, F_ref flops) on 3-D Laplacian; solution refined to fp64 accuracy",
             "value": round(value, 3), "unit": "GF/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32 factor + f64 iterative refinement" if mixed else "f64",
             "data": "synthetic (generated Laplacian, ordering and clusters)" if generated else "reference fixture (matrix, ordering and cluster files from the reference's tests/, copied as data); no random data anywhere",
             "config": {"workload": (f"generated {gn}^3 7-point Laplacian, geometric nested dissection ({glv} levels, tile {gtile}), cholamd_generate_laplacian" if generated else
                                     f"tests/{args.case} (reference fixture: 7-point Laplacian, nested-dissection ordering from the fixture files)"),
                        "n": plan.n, "levels": plan.levels, "separators": plan.nsep, "F_ref_flops": plan.flops,
-                       "B_alg_bytes": plan.alg_bytes, "parallelism": f"subtree-sharded x{world}" if world > 1 else "single GPU",
-                       "factor_info": list(info)},
-            "roofline": {"bound": "mfma", "kernel": {"potrf": "k_potrf_trsm" if fused else "k_potrf_rr", "trsm": "k_trsm_rr", "update": "k_update_mt + k_update" if generated else "k_update"}[dom], "achieved": None if achieved is None else round(achieved, 5),
-                         "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": None if achieved is None else round(achieved / PEAK_FP64_TFLOPS, 6),
-                         "traffic": pmc_traffic({"potrf": "k_potrf_trsm" if fused else "k_potrf_rr", "trsm": "k_trsm_rr", "update": "k_update"}[dom]) if world == 1 and not generated else None,
-                         "traffic_note": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r1/pmc_summary.json (separate rocprofv3 --pmc passes of this command); algorithmic bytes of the same launch in alg_bytes_per_launch",
-                         "alg_bytes_per_launch": (alg_bytes[dom] / max(launches_per_factor, 1)) if alg_bytes[dom] else None,
-                         "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": launches_per_factor,
+                       "B_alg_bytes": plan.alg_bytes, "parallelism": f"subtree-sharded x{world}, one RCCL all-reduce of the arena tail (cholamd_factor_sharded)" if world > 1 else "single GPU",
+                       "precision": args.precision, "factor_info": list(info)},
+            "roofline": {"bound": "mfma", "kernel": names[dom], "achieved": None if achieved is None else round(achieved, 5),
+                         "peak": peak, "unit": "TFLOP/s",
+                         "frac": None if achieved is None else round(achieved / peak, 6),
+                         "traffic": prof.get("hbm_bytes_per_launch") if world == 1 else None,
+                         "traffic_note": "HBM bytes per launch of that kernel, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the committed rocprofv3 --pmc passes of this command (" + prof.get("source", "no profile committed for this case") + "); to compare with alg_bytes_per_launch",
+                         "alg_bytes_per_launch": plan.alg_bytes / max(launches_per_factor, 1),
+                         "alg_bytes_note": "SURVEY 8(d): B_alg = 8 (nnz(tril A) + nnz(L)) per factorisation / launches of the kernel per factorisation; dense_panel_bytes_per_launch = what the dense panels (structural zeros included) make those launches move",
+                         "dense_panel_bytes_per_launch": (panel_bytes[dom] / max(launches_per_factor, 1)) if panel_bytes[dom] else None,
+                         "avg_launch_us": round(avg_s * 1e6, 2), "avg_launch_us_events_raw": round(avg_s_raw * 1e6, 2), "event_pair_overhead_us": round(ev_ms * 1e3, 2),
+                         "avg_launch_us_rocprof": prof.get("avg_launch_us"), "mfma_busy_frac_rocprof": prof.get("mfma_busy_frac"),
+                         "launches_per_step": launches_per_factor,
                          "alg_flops_per_launch": flops_per_launch,
-                         "whole_step_frac_of_fp64_peak": round(value * 1e-3 / PEAK_FP64_TFLOPS, 6),
+                         "whole_step_frac_of_peak": round(value * 1e-3 / peak, 6),
                          "whole_step_alg_GBs": round(plan.alg_bytes * K / dt * 1e-9, 3), "hbm_peak_GBs": PEAK_HBM_GBS,
-                         "kernel_ms_per_step": {k: round(timing[k][0] / reps, 5) for k in ("potrf", "trsm", "update")}},
+                         "kernel_ms_per_step_events_raw": {k: round(timing[k][0] / reps, 5) for k in ("potrf", "trsm", "update")}},
         }
+        if refine is not None:
+            out["config"]["refinement"] = refine
         if world == 1 and not args.no_cpu_baseline and not generated:
             out["cpu_baseline"] = cpu_baseline(files, plan.flops)
         print(json.dumps(out))

@@ -117,6 +117,12 @@ def load():
     L.cholamd_factor_levels.argtypes = [vp, vp, ci, ci, vp]
     L.cholamd_factor_info.argtypes = [vp, C.POINTER(ci)]
     L.cholamd_solve.argtypes = [vp, vp, vp, vp, vp]
+    L.cholamd_device_fill_f32.argtypes = [vp, vp, vp]
+    L.cholamd_factor_f32.argtypes = [vp, vp, vp]
+    L.cholamd_factor_levels_f32.argtypes = [vp, vp, ci, ci, vp]
+    L.cholamd_solve_f32.argtypes = [vp, vp, vp, vp, vp]
+    L.cholamd_solve_refine.argtypes = [vp, vp, vp, vp, ci, cd, C.POINTER(ci), C.POINTER(cd), vp]
+    L.cholamd_residual.argtypes = [vp, vp, vp, vp, C.POINTER(cd), vp]
     L.cholamd_device_set_timing.argtypes = [vp, ci]
     L.cholamd_device_get_timing.argtypes = [vp, vp, vp]
     L.cholamd_device_event_overhead.argtypes = [vp, vp, C.POINTER(C.c_float)]

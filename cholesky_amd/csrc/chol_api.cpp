@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -56,6 +57,11 @@ struct cholamd_device {
   bool timing = false;
   std::vector<timed_launch> tl;
   std::vector<hipEvent_t> pool;
+  // mixed precision (fp32 factor + fp64 refinement): work lists of the fp32 kernels, their workspace, A as a device CSR
+  std::vector<level_dev> lv32;
+  float *ws32 = nullptr;
+  int64_t *csr_ptr = nullptr; int *csr_col = nullptr; double *csr_val = nullptr;
+  double *rvec = nullptr, *dxvec = nullptr, *partial = nullptr;
   // switches, read from the environment once at cholamd_device_create (cholamd_device_set_option changes them later)
   chol_sched_opts opt;
   bool solve_reference_shape = false; // cholamd_solve with the per-call (deterministic) kernels of the BLAS-level entry points
@@ -92,6 +98,8 @@ static void free_levels(cholamd_device *d)
 {
   for (auto &l : d->lv) free_level(l);
   d->lv.clear();
+  for (auto &l : d->lv32) free_level(l);
+  d->lv32.clear();
 }
 static int upload_level(level_dev &l, const chol_level_work &w)
 {
@@ -156,6 +164,7 @@ extern "C" void cholamd_device_destroy(cholamd_device *d)
   (void)hipSetDevice(d->dev);
   free_levels(d);
   for (auto &s : d->sv) { (void)hipFree(s.trsv); (void)hipFree(s.fw); (void)hipFree(s.bw); (void)hipFree(s.grp_start); (void)hipFree(s.grp_rows); (void)hipFree(s.bw_start); (void)hipFree(s.ifw); (void)hipFree(s.ibw); }
+  (void)hipFree(d->ws32); (void)hipFree(d->csr_ptr); (void)hipFree(d->csr_col); (void)hipFree(d->csr_val); (void)hipFree(d->rvec); (void)hipFree(d->dxvec); (void)hipFree(d->partial);
   (void)hipFree(d->ws); (void)hipFree(d->ws_solve); (void)hipFree(d->info); (void)hipFree(d->progress); (void)hipFree(d->a_dst); (void)hipFree(d->a_val); (void)hipFree(d->perm); (void)hipFree(d->ytmp);
   for (auto &t : d->tl) { d->pool.push_back(t.a); d->pool.push_back(t.b); }
   for (auto e : d->pool) (void)hipEventDestroy(e);
@@ -381,42 +390,186 @@ static int build_solve(cholamd_device *d)
   return 0;
 }
 
+// the streamed solve (every panel read once) with a factor of element type TL; vectors and arithmetic are fp64
+static int lsolve_dinv(const double *a, const chol_trsv_desc *t, int n, int mx, double *W, hipStream_t st) { return chol_launch_solve_dinv(a, t, n, mx, W, st); }
+static int lsolve_dinv(const float *a, const chol_trsv_desc *t, int n, int mx, double *W, hipStream_t st) { return chol32_launch_solve_dinv(a, t, n, mx, W, st); }
+static int lsolve_trsv(const double *a, const chol_trsv_desc *t, int n, int mx, const double *W, double *y, int bw, hipStream_t st) { return chol_launch_solve_trsv(a, t, n, mx, W, y, bw, st); }
+static int lsolve_trsv(const float *a, const chol_trsv_desc *t, int n, int mx, const double *W, double *y, int bw, hipStream_t st) { return chol32_launch_solve_trsv(a, t, n, mx, W, y, bw, st); }
+static int lsolve_off(const double *a, const chol_gemv_desc *g, const int *it, int n, double *y, int bw, hipStream_t st) { return chol_launch_solve_offdiag(a, g, it, n, y, bw, st); }
+static int lsolve_off(const float *a, const chol_gemv_desc *g, const int *it, int n, double *y, int bw, hipStream_t st) { return chol32_launch_solve_offdiag(a, g, it, n, y, bw, st); }
+template <class TL> static int solve_streamed(cholamd_device *d, const TL *d_arena, const double *d_b, double *d_x, hipStream_t st)
+{
+  const int L = d->plan->levels, n = d->plan->n;
+  double *y = d->ytmp;
+  HIPCHK((hipError_t)chol_launch_permute(d_b, d->perm, y, n, 0, st));
+  // the 16x16 inverses of this arena's diagonal blocks (the factorisation's workspace belongs to the last arena factored)
+  for (int lvl = 0; lvl < L; lvl++) {
+    const solve_dev &s = d->sv[lvl];
+    HIPCHK((hipError_t)lsolve_dinv(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, st));
+  }
+  for (int lvl = L - 1; lvl >= 0; lvl--) { // forward, mmat.rg:1395-1435: TRSV per separator, then its panel into the ancestors
+    const solve_dev &s = d->sv[lvl];
+    HIPCHK((hipError_t)lsolve_trsv(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, y, 0, st));
+    HIPCHK((hipError_t)lsolve_off(d_arena, s.bw, s.ifw, s.n_ifw, y, 0, st));
+  }
+  for (int lvl = 0; lvl < L; lvl++) { // backward, mmat.rg:1438-1479: gather from the ancestors, then TRSV^T
+    const solve_dev &s = d->sv[lvl];
+    HIPCHK((hipError_t)lsolve_off(d_arena, s.bw, s.ibw, s.n_ibw, y, 1, st));
+    HIPCHK((hipError_t)lsolve_trsv(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, y, 1, st));
+  }
+  HIPCHK((hipError_t)chol_launch_permute(y, d->perm, d_x, n, 1, st));
+  return 0;
+}
 extern "C" int cholamd_solve(cholamd_device *d, const double *d_arena, const double *d_b, double *d_x, void *stream)
 {
   HIPCHK(hipSetDevice(d->dev));
   if (!d->solve_ready) { int rc = build_solve(d); if (rc) return rc; }
   hipStream_t st = (hipStream_t)stream;
+  if (!d->solve_reference_shape) return solve_streamed(d, d_arena, d_b, d_x, st);
+  // the per-call kernels the BLAS-level entry points use (deterministic, slow at scale)
   const int L = d->plan->levels, n = d->plan->n;
   double *y = d->ytmp;
   HIPCHK((hipError_t)chol_launch_permute(d_b, d->perm, y, n, 0, st));
-  if (d->solve_reference_shape) { // the per-call kernels the BLAS-level entry points use (deterministic, slow at scale)
-    for (int lvl = L - 1; lvl >= 0; lvl--) { // forward, mmat.rg:1395-1435
-      const solve_dev &s = d->sv[lvl];
-      HIPCHK((hipError_t)chol_launch_trsv_fwd(d_arena, s.trsv, s.n_trsv, y, st));
-      HIPCHK((hipError_t)chol_launch_gemv_fwd(d_arena, s.fw, s.grp_start, s.grp_rows, s.n_grp, y, st));
-    }
-    for (int lvl = 0; lvl < L; lvl++) { // backward, mmat.rg:1438-1479
-      const solve_dev &s = d->sv[lvl];
-      HIPCHK((hipError_t)chol_launch_bwd(d_arena, s.trsv, s.bw, s.bw_start, s.n_trsv, y, st));
-    }
-  } else {
-    // the 16x16 inverses of this arena's diagonal blocks (the factorisation's workspace belongs to the last arena factored)
-    for (int lvl = 0; lvl < L; lvl++) {
-      const solve_dev &s = d->sv[lvl];
-      HIPCHK((hipError_t)chol_launch_solve_dinv(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, st));
-    }
-    for (int lvl = L - 1; lvl >= 0; lvl--) { // forward, mmat.rg:1395-1435: TRSV per separator, then its panel into the ancestors
-      const solve_dev &s = d->sv[lvl];
-      HIPCHK((hipError_t)chol_launch_solve_trsv(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, y, 0, st));
-      HIPCHK((hipError_t)chol_launch_solve_offdiag(d_arena, s.bw, s.ifw, s.n_ifw, y, 0, st));
-    }
-    for (int lvl = 0; lvl < L; lvl++) { // backward, mmat.rg:1438-1479: gather from the ancestors, then TRSV^T
-      const solve_dev &s = d->sv[lvl];
-      HIPCHK((hipError_t)chol_launch_solve_offdiag(d_arena, s.bw, s.ibw, s.n_ibw, y, 1, st));
-      HIPCHK((hipError_t)chol_launch_solve_trsv(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, y, 1, st));
-    }
+  for (int lvl = L - 1; lvl >= 0; lvl--) { // forward, mmat.rg:1395-1435
+    const solve_dev &s = d->sv[lvl];
+    HIPCHK((hipError_t)chol_launch_trsv_fwd(d_arena, s.trsv, s.n_trsv, y, st));
+    HIPCHK((hipError_t)chol_launch_gemv_fwd(d_arena, s.fw, s.grp_start, s.grp_rows, s.n_grp, y, st));
+  }
+  for (int lvl = 0; lvl < L; lvl++) { // backward, mmat.rg:1438-1479
+    const solve_dev &s = d->sv[lvl];
+    HIPCHK((hipError_t)chol_launch_bwd(d_arena, s.trsv, s.bw, s.bw_start, s.n_trsv, y, st));
   }
   HIPCHK((hipError_t)chol_launch_permute(y, d->perm, d_x, n, 1, st));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Mixed precision (BASELINE config 5): fp32 factor, fp64 iterative refinement of the solve.
+// The fp32 arena has the element layout of the fp64 one (cholamd_plan_arena_doubles() floats).
+// ---------------------------------------------------------------------------------------------
+static int ensure_f32(cholamd_device *d)
+{
+  if (!d->lv32.empty()) return 0;
+  const int L = d->plan->levels;
+  chol_sched_opts o = d->opt;
+  o.split_min = CHOL32_MAXN; o.split_nb = CHOL32_MAXN; o.fuse = 0; o.fuse_update_max = 0; // pivot blocks the LDS-resident fp32 POTRF takes, one launch per phase
+  d->lv32.resize(L);
+  for (int lvl = 0; lvl < L; lvl++) {
+    chol_level_work w;
+    int rc = chol_build_level_work(d->plan, &o, lvl, d->rank, d->world, &w);
+    if (!rc) rc = upload_level(d->lv32[lvl], w);
+    chol_level_work_free(&w);
+    if (rc) { for (auto &l : d->lv32) free_level(l); d->lv32.clear(); return rc; }
+  }
+  if (!d->ws32) HIPCHK(hipMalloc((void **)&d->ws32, (size_t)(d->plan->ws_doubles > 0 ? d->plan->ws_doubles : 1) * sizeof(float)));
+  return 0;
+}
+extern "C" int cholamd_device_fill_f32(cholamd_device *d, float *d_arena32, void *stream)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipMemsetAsync(d_arena32, 0, (size_t)d->plan->arena * sizeof(float), st));
+  int64_t nnz = d->plan->nnz_a;
+  if (d->world > 1 && d->rank != 0) { // the shared top starts from A on rank 0 only (see cholamd_device_fill)
+    const int64_t tail = d->plan->panel_off[d->plan->nsep - (d->world - 1) + 1];
+    int64_t lo = 0, hi = nnz;
+    while (lo < hi) { int64_t mid = (lo + hi) / 2; if (d->plan->a_dst[mid] < tail) lo = mid + 1; else hi = mid; }
+    nnz = lo;
+  }
+  HIPCHK((hipError_t)chol32_launch_scatter(d_arena32, d->a_dst, d->a_val, nnz, st));
+  return 0;
+}
+extern "C" int cholamd_factor_levels_f32(cholamd_device *d, float *d_arena32, int level_hi, int level_lo, void *stream)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  int rc = ensure_f32(d);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int L = d->plan->levels;
+  if (level_hi >= L) level_hi = L - 1;
+  if (level_lo < 0) level_lo = 0;
+  if (level_hi == L - 1) HIPCHK(hipMemsetAsync(d->info, 0, 2 * sizeof(int), st));
+  for (int lvl = level_hi; lvl >= level_lo; lvl--) {
+    const level_dev &l = d->lv32[lvl];
+    for (const chol_phase &ph : l.phase) {
+      scoped_timer t(d, st, ph.kind == 3 ? 2 : ph.kind == 4 ? 1 : ph.kind, ph.n > 0);
+      if (ph.kind == 0) HIPCHK((hipError_t)chol32_launch_potrf(d_arena32, d->ws32, l.potrf + ph.first, ph.n, d->info, st));
+      else if (ph.kind == 1 || ph.kind == 4) HIPCHK((hipError_t)chol32_launch_trsm(d_arena32, d->ws32, l.trsm + ph.first, ph.n, st));
+      else if (ph.kind == 2) HIPCHK((hipError_t)chol32_launch_update(d_arena32, l.task + ph.first, l.src, ph.n, st));
+      else if (ph.kind == 3) HIPCHK((hipError_t)chol32_launch_update_mt(d_arena32, l.task_mt + ph.first, l.src, ph.n, st));
+      else { chol_set_error("internal: phase kind %d in the fp32 schedule", ph.kind); return CHOLAMD_ERR_ARG; }
+    }
+  }
+  return 0;
+}
+extern "C" int cholamd_factor_f32(cholamd_device *d, float *d_arena32, void *stream)
+{
+  return cholamd_factor_levels_f32(d, d_arena32, d->plan->levels - 1, 0, stream);
+}
+extern "C" int cholamd_solve_f32(cholamd_device *d, const float *d_arena32, const double *d_b, double *d_x, void *stream)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  if (!d->solve_ready) { int rc = build_solve(d); if (rc) return rc; }
+  return solve_streamed(d, d_arena32, d_b, d_x, (hipStream_t)stream);
+}
+static int ensure_refine(cholamd_device *d)
+{
+  if (d->csr_ptr) return 0;
+  const cholamd_plan *p = d->plan;
+  const int n = p->n;
+  int rc = upload_vec(&d->csr_ptr, p->csr_ptr, (size_t)n + 1);
+  if (!rc) rc = upload_vec(&d->csr_col, p->csr_col, (size_t)(p->csr_ptr[n] > 0 ? p->csr_ptr[n] : 1));
+  if (!rc) rc = upload_vec(&d->csr_val, p->csr_val, (size_t)(p->csr_ptr[n] > 0 ? p->csr_ptr[n] : 1));
+  if (rc) return rc;
+  HIPCHK(hipMalloc((void **)&d->rvec, (size_t)n * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&d->dxvec, (size_t)n * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&d->partial, (size_t)2 * ((n + 255) / 256) * sizeof(double)));
+  return 0;
+}
+// r = b - A x on the device (fp64, A = the matrix file's entries, both triangles), ||r|| / ||b|| back on the host
+static int residual_norm(cholamd_device *d, const double *d_b, const double *d_x, double *d_r, double *relres, hipStream_t st)
+{
+  const int n = d->plan->n, nb = (n + 255) / 256;
+  HIPCHK((hipError_t)chol_launch_residual(d->csr_ptr, d->csr_col, d->csr_val, d_b, d_x, d_r, n, d->partial, st));
+  std::vector<double> h((size_t)2 * nb);
+  HIPCHK(hipMemcpyAsync(h.data(), d->partial, h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  double r2 = 0.0, b2 = 0.0;
+  for (int i = 0; i < nb; i++) { r2 += h[2 * i]; b2 += h[2 * i + 1]; }
+  *relres = b2 > 0.0 ? std::sqrt(r2 / b2) : std::sqrt(r2);
+  return 0;
+}
+extern "C" int cholamd_residual(cholamd_device *d, const double *d_b, const double *d_x, double *d_r, double *relres_out, void *stream)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  int rc = ensure_refine(d);
+  if (rc) return rc;
+  return residual_norm(d, d_b, d_x, d_r, relres_out, (hipStream_t)stream);
+}
+extern "C" int cholamd_solve_refine(cholamd_device *d, const float *d_arena32, const double *d_b, double *d_x, int max_iter, double tol,
+                                    int *iters_out, double *relres_out, void *stream)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  int rc = ensure_refine(d);
+  if (!rc && !d->solve_ready) rc = build_solve(d);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int n = d->plan->n;
+  if (max_iter < 0) max_iter = 0;
+  // x0 = M^-1 b with M = L32 L32^T; then x += M^-1 (b - A x) until ||b - A x|| <= tol ||b||
+  rc = solve_streamed(d, d_arena32, d_b, d_x, st);
+  if (rc) return rc;
+  double rel = 0.0;
+  int it = 0;
+  for (;; ++it) {
+    if ((rc = residual_norm(d, d_b, d_x, d->rvec, &rel, st))) return rc;
+    if (!(rel > tol) || it >= max_iter) break; // also leaves on NaN
+    if ((rc = solve_streamed(d, d_arena32, d->rvec, d->dxvec, st))) return rc;
+    HIPCHK((hipError_t)chol_launch_axpy1(d_x, d->dxvec, n, st));
+  }
+  if (iters_out) *iters_out = it;
+  if (relres_out) *relres_out = rel;
+  if (rel != rel) { chol_set_error("iterative refinement produced NaN (fp32 factorisation broke down)"); return CHOLAMD_ERR_ARG; }
   return 0;
 }
 

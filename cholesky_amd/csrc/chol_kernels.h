@@ -26,6 +26,17 @@ int chol_launch_solve_offdiag(const double *base, const chol_gemv_desc *blocks, 
 int chol_launch_trsv_fwd(const double *base, const chol_trsv_desc *descs, int n, double *y, hipStream_t st);
 int chol_launch_gemv_fwd(const double *base, const chol_gemv_desc *descs, const int *grp_start, const int *grp_rows, int ngroups, double *y, hipStream_t st);
 int chol_launch_bwd(const double *base, const chol_trsv_desc *descs, const chol_gemv_desc *gd, const int *gstart, int n, double *y, hipStream_t st);
+/* fp32 factor (chol_kernels_f32.hip) and the fp64 refinement helpers */
+int chol32_launch_scatter(float *arena, const int64_t *dst, const double *val, int64_t nnz, hipStream_t st);
+int chol32_launch_potrf(float *base, float *ws, const chol_potrf_desc *descs, int n, int *info, hipStream_t st);
+int chol32_launch_trsm(float *base, const float *ws, const chol_trsm_desc *descs, int n, hipStream_t st);
+int chol32_launch_update(float *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st);
+int chol32_launch_update_mt(float *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st);
+int chol32_launch_solve_dinv(const float *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st);
+int chol32_launch_solve_trsv(const float *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, hipStream_t st);
+int chol32_launch_solve_offdiag(const float *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st);
+int chol_launch_residual(const int64_t *ptr, const int *col, const double *val, const double *b, const double *x, double *r, int n, double *partial, hipStream_t st);
+int chol_launch_axpy1(double *x, const double *dx, int n, hipStream_t st);
 #ifdef __cplusplus
 }
 #endif

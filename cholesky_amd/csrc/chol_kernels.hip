@@ -1578,13 +1578,16 @@ __global__ __launch_bounds__(256) void k_bwd(const double *__restrict__ base, co
 //     the solution agrees from run to run to rounding, not bit for bit)
 // ------------------------------------------------------------------------------------------------
 #define SNB 64
-__global__ __launch_bounds__(64) void k_solve_dinv(const double *__restrict__ base, const chol_trsv_desc *__restrict__ descs, double *__restrict__ W)
+// The driver-level solve kernels are templates over the factor's element type TL (double, or float for the fp32 factor of
+// the mixed-precision path): L is converted on load, vectors and arithmetic are fp64 either way.
+template <class TL>
+__global__ __launch_bounds__(64) void k_solve_dinv(const TL *__restrict__ base, const chol_trsv_desc *__restrict__ descs, double *__restrict__ W)
 { // grid (separators of the level, 16-column blocks of the widest one)
   __shared__ double sYd[4][TS];
   const chol_trsv_desc d = descs[blockIdx.x];
   const int j0 = blockIdx.y * TS;
   if (j0 >= d.n) return;
-  const double *Lp = base + d.a_off;
+  const TL *Lp = base + d.a_off;
   const int n = d.n, ldl = d.lda;
   const int lane = threadIdx.x, r15 = lane & 15, g = lane >> 4;
   const int row = j0 + r15, b4 = r15 & ~3, qi = r15 & 3;
@@ -1593,7 +1596,7 @@ __global__ __launch_bounds__(64) void k_solve_dinv(const double *__restrict__ ba
   for (int k = 0; k < 4; ++k) {
     const int col = j0 + b4 + k;
     double v = (k == qi) ? 1.0 : 0.0; // identity padding past n
-    if (row < n && col < n) v = (k <= qi) ? Lp[row + (int64_t)col * ldl] : 0.0;
+    if (row < n && col < n) v = (k <= qi) ? (double)Lp[row + (int64_t)col * ldl] : 0.0;
     blk[k] = v;
   }
   double diag = blk[0];
@@ -1611,7 +1614,7 @@ __global__ __launch_bounds__(64) void k_solve_dinv(const double *__restrict__ ba
   for (int b = 0; b < 3; ++b) {
     const int c = g + 4 * b;
     double v = (r15 == c) ? 1.0 : 0.0;
-    if (row < n && j0 + c < n) v = (c <= r15) ? Lp[row + (int64_t)(j0 + c) * ldl] : 0.0;
+    if (row < n && j0 + c < n) v = (c <= r15) ? (double)Lp[row + (int64_t)(j0 + c) * ldl] : 0.0;
     Lr[b] = v;
   }
   store_linv16(W + d.dinv_off + (int64_t)blockIdx.y * TS * TS, Lr, sYd[g][r15], r15, g);
@@ -1624,8 +1627,8 @@ __global__ __launch_bounds__(64) void k_solve_dinv(const double *__restrict__ ba
 // in (forward) / gathered (backward) by k_solve_panel over all CUs, so a wide separator's triangle is not streamed by
 // one workgroup.
 #define SSPAN 256
-template <bool BWD>
-__global__ __launch_bounds__(256) void k_solve_trsv(const double *__restrict__ base, const chol_trsv_desc *__restrict__ descs, const double *__restrict__ Wall,
+template <bool BWD, class TL>
+__global__ __launch_bounds__(256) void k_solve_trsv(const TL *__restrict__ base, const chol_trsv_desc *__restrict__ descs, const double *__restrict__ Wall,
                                                     double *__restrict__ y, int col0)
 {
   __shared__ double sL[SNB][SNB + 1]; // [r][c] of the diagonal block
@@ -1633,7 +1636,7 @@ __global__ __launch_bounds__(256) void k_solve_trsv(const double *__restrict__ b
   __shared__ double sx[SNB];
   __shared__ double sred[4][SNB];
   const chol_trsv_desc d = descs[blockIdx.x];
-  const double *Lm = base + d.a_off;
+  const TL *Lm = base + d.a_off;
   const double *W = Wall + d.dinv_off;
   double *x = y + d.x_off;
   const int lda = d.lda, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1645,7 +1648,7 @@ __global__ __launch_bounds__(256) void k_solve_trsv(const double *__restrict__ b
     // stage the block: triangle, inverses, right-hand side
     for (int e = tid; e < SNB * SNB; e += 256) {
       const int r = e & (SNB - 1), c = e >> 6;
-      sL[r][c] = (r < jb && c <= r) ? Lm[(J0 + r) + (int64_t)(J0 + c) * lda] : 0.0;
+      sL[r][c] = (r < jb && c <= r) ? (double)Lm[(J0 + r) + (int64_t)(J0 + c) * lda] : 0.0;
     }
     for (int e = tid; e < (SNB / TS) * TS * TS; e += 256) {
       const int t = e >> 8;
@@ -1656,7 +1659,7 @@ __global__ __launch_bounds__(256) void k_solve_trsv(const double *__restrict__ b
       for (int c = wave; c < SNB; c += 4) {
         double acc = 0.0;
         if (c < jb)
-          for (int i = J0 + jb + lane; i < n; i += 64) acc += Lm[i + (int64_t)(J0 + c) * lda] * x[i];
+          for (int i = J0 + jb + lane; i < n; i += 64) acc += (double)Lm[i + (int64_t)(J0 + c) * lda] * x[i];
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
         if (lane == 0) sx[c] = (c < jb) ? x[J0 + c] - acc : 0.0;
       }
@@ -1692,7 +1695,7 @@ __global__ __launch_bounds__(256) void k_solve_trsv(const double *__restrict__ b
     if (!BWD) { // rows below the block: x[r] -= L(r, J) x_J
       for (int r = J0 + jb + tid; r < n; r += 256) {
         double acc = 0.0;
-        for (int k = 0; k < jb; ++k) acc += Lm[r + (int64_t)(J0 + k) * lda] * sx[k];
+        for (int k = 0; k < jb; ++k) acc += (double)Lm[r + (int64_t)(J0 + k) * lda] * sx[k];
         x[r] -= acc;
       }
     }
@@ -1703,27 +1706,27 @@ __global__ __launch_bounds__(256) void k_solve_trsv(const double *__restrict__ b
 
 // rows below the span of a wide separator: forward x[r] -= L(r, span) x_span (one thread per row, deterministic);
 // backward x_span[c] -= L(rows, c)^T x[rows] for a chunk of CHOL_SOLVE_BW_ROWS rows (atomics).  grid (separators, chunks)
-template <bool BWD>
-__global__ __launch_bounds__(256) void k_solve_panel(const double *__restrict__ base, const chol_trsv_desc *__restrict__ descs, double *__restrict__ y, int col0)
+template <bool BWD, class TL>
+__global__ __launch_bounds__(256) void k_solve_panel(const TL *__restrict__ base, const chol_trsv_desc *__restrict__ descs, double *__restrict__ y, int col0)
 {
   __shared__ double sx[SSPAN];
   const chol_trsv_desc d = descs[blockIdx.x];
   const int r0 = col0 + SSPAN;
   const int rows = BWD ? CHOL_SOLVE_BW_ROWS : 256;
   if (d.n <= r0 + (int)blockIdx.y * rows) return;
-  const double *Lm = base + d.a_off;
+  const TL *Lm = base + d.a_off;
   double *x = y + d.x_off;
   const int n = d.n, lda = d.lda, tid = threadIdx.x;
   if (!BWD) {
     sx[tid] = x[col0 + tid];
     __syncthreads();
     const int r = r0 + blockIdx.y * 256 + tid;
-    const double *A = Lm + min(r, n - 1) + (int64_t)col0 * lda;
+    const TL *A = Lm + min(r, n - 1) + (int64_t)col0 * lda;
     double acc = 0.0;
     for (int k = 0; k < SSPAN; k += 8) {
       double a[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] = A[(int64_t)(k + u) * lda];
+      for (int u = 0; u < 8; ++u) a[u] = (double)A[(int64_t)(k + u) * lda];
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += a[u] * sx[k + u];
     }
@@ -1739,10 +1742,10 @@ __global__ __launch_bounds__(256) void k_solve_panel(const double *__restrict__ 
       xa[u] = i < n ? x[i] : 0.0;
     }
     for (int c = wave; c < SSPAN; c += 4) {
-      const double *Ac = Lm + (int64_t)(col0 + c) * lda;
+      const TL *Ac = Lm + (int64_t)(col0 + c) * lda;
       double a[PER];
 #pragma unroll
-      for (int u = 0; u < PER; ++u) a[u] = Ac[min(row0 + lane + 64 * u, n - 1)];
+      for (int u = 0; u < PER; ++u) a[u] = (double)Ac[min(row0 + lane + 64 * u, n - 1)];
       double acc = 0.0;
 #pragma unroll
       for (int u = 0; u < PER; ++u) acc += a[u] * xa[u];
@@ -1753,13 +1756,14 @@ __global__ __launch_bounds__(256) void k_solve_panel(const double *__restrict__ 
 }
 
 // forward: y_anc[rows] -= A(rows, :) y_s for one row chunk of the block A = (anc, s); y_s staged through LDS
-__global__ __launch_bounds__(256) void k_solve_gemv_fwd(const double *__restrict__ base, const chol_gemv_desc *__restrict__ blocks, const int *__restrict__ items,
+template <class TL>
+__global__ __launch_bounds__(256) void k_solve_gemv_fwd(const TL *__restrict__ base, const chol_gemv_desc *__restrict__ blocks, const int *__restrict__ items,
                                                         double *__restrict__ y)
 {
   __shared__ double sx[256];
   const chol_gemv_desc d = blocks[items[2 * blockIdx.x]];
   const int r = items[2 * blockIdx.x + 1] + threadIdx.x;
-  const double *A = base + d.a_off + min(r, d.m - 1);
+  const TL *A = base + d.a_off + min(r, d.m - 1);
   const double *xs = y + d.y_off; // the separator's (already solved) part
   double acc = 0.0;
   for (int k0 = 0; k0 < d.n; k0 += 256) {
@@ -1767,23 +1771,24 @@ __global__ __launch_bounds__(256) void k_solve_gemv_fwd(const double *__restrict
     __syncthreads();
     if ((int)threadIdx.x < kb) sx[threadIdx.x] = xs[k0 + threadIdx.x];
     __syncthreads();
-    const double *Ak = A + (int64_t)k0 * d.lda;
+    const TL *Ak = A + (int64_t)k0 * d.lda;
     int k = 0;
     for (; k + 8 <= kb; k += 8) {
       double a[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] = Ak[(int64_t)(k + u) * d.lda];
+      for (int u = 0; u < 8; ++u) a[u] = (double)Ak[(int64_t)(k + u) * d.lda];
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += a[u] * sx[k + u];
     }
-    for (; k < kb; ++k) acc += Ak[(int64_t)k * d.lda] * sx[k];
+    for (; k < kb; ++k) acc += (double)Ak[(int64_t)k * d.lda] * sx[k];
   }
   if (r < d.m) unsafeAtomicAdd(&y[d.x_off + r], -acc);
 }
 
 // backward: y_s[c] -= A(rows, c)^T y_anc[rows] for one row chunk of the block; every lane keeps its rows' y_anc in
 // registers, wave w takes the columns w, w+4, ...
-__global__ __launch_bounds__(256) void k_solve_gather_bwd(const double *__restrict__ base, const chol_gemv_desc *__restrict__ blocks, const int *__restrict__ items,
+template <class TL>
+__global__ __launch_bounds__(256) void k_solve_gather_bwd(const TL *__restrict__ base, const chol_gemv_desc *__restrict__ blocks, const int *__restrict__ items,
                                                           double *__restrict__ y)
 {
   const chol_gemv_desc d = blocks[items[2 * blockIdx.x]];
@@ -1791,23 +1796,54 @@ __global__ __launch_bounds__(256) void k_solve_gather_bwd(const double *__restri
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int PER = CHOL_SOLVE_BW_ROWS / 64;
   double ya[PER];
-  const double *A = base + d.a_off;
+  const TL *A = base + d.a_off;
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
     const int i = row0 + lane + 64 * u;
     ya[u] = i < d.m ? y[d.x_off + i] : 0.0;
   }
   for (int c = wave; c < d.n; c += 4) {
-    const double *Ac = A + (int64_t)c * d.lda;
+    const TL *Ac = A + (int64_t)c * d.lda;
     double a[PER];
 #pragma unroll
-    for (int u = 0; u < PER; ++u) a[u] = Ac[min(row0 + lane + 64 * u, d.m - 1)];
+    for (int u = 0; u < PER; ++u) a[u] = (double)Ac[min(row0 + lane + 64 * u, d.m - 1)];
     double acc = 0.0;
 #pragma unroll
     for (int u = 0; u < PER; ++u) acc += a[u] * ya[u];
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if (lane == 0) unsafeAtomicAdd(&y[d.y_off + c], -acc);
   }
+}
+
+template <class TL> static int launch_solve_dinv_t(const TL *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st)
+{
+  if (n <= 0 || max_n <= 0) return 0;
+  hipLaunchKernelGGL(k_solve_dinv<TL>, dim3(n, (max_n + TS - 1) / TS), dim3(64), 0, st, base, descs, W);
+  return (int)hipGetLastError();
+}
+template <class TL> static int launch_solve_trsv_t(const TL *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, hipStream_t st)
+{ // all separators of a level; wide ones in spans of SSPAN columns: diagonal span by one workgroup each, the rows below by all CUs
+  if (n <= 0) return 0;
+  const int nspan = (max_n + SSPAN - 1) / SSPAN;
+  for (int i = 0; i < nspan; i++) {
+    const int sp = backward ? nspan - 1 - i : i, col0 = sp * SSPAN;
+    const int below = max_n - (col0 + SSPAN); // rows under the span in the widest separator
+    if (backward) {
+      if (below > 0) hipLaunchKernelGGL((k_solve_panel<true, TL>), dim3(n, (below + CHOL_SOLVE_BW_ROWS - 1) / CHOL_SOLVE_BW_ROWS), dim3(256), 0, st, base, descs, y, col0);
+      hipLaunchKernelGGL((k_solve_trsv<true, TL>), dim3(n), dim3(256), 0, st, base, descs, W, y, col0);
+    } else {
+      hipLaunchKernelGGL((k_solve_trsv<false, TL>), dim3(n), dim3(256), 0, st, base, descs, W, y, col0);
+      if (below > 0) hipLaunchKernelGGL((k_solve_panel<false, TL>), dim3(n, (below + 255) / 256), dim3(256), 0, st, base, descs, y, col0);
+    }
+  }
+  return (int)hipGetLastError();
+}
+template <class TL> static int launch_solve_offdiag_t(const TL *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st)
+{
+  if (n_items <= 0) return 0;
+  if (backward) hipLaunchKernelGGL(k_solve_gather_bwd<TL>, dim3(n_items), dim3(256), 0, st, base, blocks, items, y);
+  else hipLaunchKernelGGL(k_solve_gemv_fwd<TL>, dim3(n_items), dim3(256), 0, st, base, blocks, items, y);
+  return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1891,36 +1927,12 @@ int chol_launch_permute(const double *in, const int *perm, double *out, int n, i
   else hipLaunchKernelGGL(k_permute_in, dim3((n + 255) / 256), dim3(256), 0, st, in, perm, out, n);
   return (int)hipGetLastError();
 }
-int chol_launch_solve_dinv(const double *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st)
-{
-  if (n <= 0 || max_n <= 0) return 0;
-  hipLaunchKernelGGL(k_solve_dinv, dim3(n, (max_n + TS - 1) / TS), dim3(64), 0, st, base, descs, W);
-  return (int)hipGetLastError();
-}
-int chol_launch_solve_trsv(const double *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, hipStream_t st)
-{ // all separators of a level; wide ones in spans of SSPAN columns: diagonal span by one workgroup each, the rows below by all CUs
-  if (n <= 0) return 0;
-  const int nspan = (max_n + SSPAN - 1) / SSPAN;
-  for (int i = 0; i < nspan; i++) {
-    const int sp = backward ? nspan - 1 - i : i, col0 = sp * SSPAN;
-    const int below = max_n - (col0 + SSPAN); // rows under the span in the widest separator
-    if (backward) {
-      if (below > 0) hipLaunchKernelGGL(k_solve_panel<true>, dim3(n, (below + CHOL_SOLVE_BW_ROWS - 1) / CHOL_SOLVE_BW_ROWS), dim3(256), 0, st, base, descs, y, col0);
-      hipLaunchKernelGGL(k_solve_trsv<true>, dim3(n), dim3(256), 0, st, base, descs, W, y, col0);
-    } else {
-      hipLaunchKernelGGL(k_solve_trsv<false>, dim3(n), dim3(256), 0, st, base, descs, W, y, col0);
-      if (below > 0) hipLaunchKernelGGL(k_solve_panel<false>, dim3(n, (below + 255) / 256), dim3(256), 0, st, base, descs, y, col0);
-    }
-  }
-  return (int)hipGetLastError();
-}
-int chol_launch_solve_offdiag(const double *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st)
-{
-  if (n_items <= 0) return 0;
-  if (backward) hipLaunchKernelGGL(k_solve_gather_bwd, dim3(n_items), dim3(256), 0, st, base, blocks, items, y);
-  else hipLaunchKernelGGL(k_solve_gemv_fwd, dim3(n_items), dim3(256), 0, st, base, blocks, items, y);
-  return (int)hipGetLastError();
-}
+int chol_launch_solve_dinv(const double *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st) { return launch_solve_dinv_t(base, descs, n, max_n, W, st); }
+int chol_launch_solve_trsv(const double *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, hipStream_t st) { return launch_solve_trsv_t(base, descs, n, max_n, W, y, backward, st); }
+int chol_launch_solve_offdiag(const double *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st) { return launch_solve_offdiag_t(base, blocks, items, n_items, y, backward, st); }
+int chol32_launch_solve_dinv(const float *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st) { return launch_solve_dinv_t(base, descs, n, max_n, W, st); }
+int chol32_launch_solve_trsv(const float *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, hipStream_t st) { return launch_solve_trsv_t(base, descs, n, max_n, W, y, backward, st); }
+int chol32_launch_solve_offdiag(const float *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st) { return launch_solve_offdiag_t(base, blocks, items, n_items, y, backward, st); }
 int chol_launch_trsv_fwd(const double *base, const chol_trsv_desc *descs, int n, double *y, hipStream_t st)
 {
   if (n <= 0) return 0;

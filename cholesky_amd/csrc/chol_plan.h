@@ -21,6 +21,7 @@ extern "C" {
 
 #define CHOL_NB 16        /* diagonal-block width of the POTRF/TRSM kernels = one fp64 MFMA tile */
 #define CHOL_RR_MAXN 272  /* largest pivot the register-resident kernels take (17 tiles) */
+#define CHOL32_MAXN 128   /* widest pivot block of the fp32 path: its lower triangle is factored out of LDS (chol_kernels_f32.hip) */
 
 typedef struct {
   int n_int;    /* number of intervals */
@@ -137,6 +138,8 @@ struct cholamd_plan {
   int64_t *dinv_off;              /* per label */
   /* tril(A) mapped into the arena */
   int64_t nnz_a, dropped; int64_t *a_dst; double *a_val;
+  /* A, both triangles, CSR over ORIGINAL dof indices (residual of the iterative refinement) */
+  int64_t *csr_ptr; int *csr_col; double *csr_val;
   /* fill snapshots per interval label */
   int64_t *snap_n; cholamd_filled **snap;
   /* reference-order BLAS call list */

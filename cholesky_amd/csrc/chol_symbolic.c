@@ -247,6 +247,28 @@ int chol_plan_finish(plan_t *p, int nz, const int *a_row, const int *a_col, cons
   }
   scalar_symbolic(p, px, py);
   free(px); free(py);
+  { /* A as a full symmetric CSR in ORIGINAL dof order (both triangles, explicit zeros skipped, entries the schedule
+     * dropped included): the operator of the fp64 residual r = b - A x of the iterative refinement */
+    int64_t *ptr = calloc((size_t)n + 1, sizeof(int64_t));
+    for (int e = 0; e < nz; e++) {
+      if (a_val[e] == 0.0) continue;
+      ptr[a_row[e] + 1]++;
+      if (a_row[e] != a_col[e]) ptr[a_col[e] + 1]++;
+    }
+    for (int i = 0; i < n; i++) ptr[i + 1] += ptr[i];
+    p->csr_col = malloc((size_t)(ptr[n] > 0 ? ptr[n] : 1) * sizeof(int));
+    p->csr_val = malloc((size_t)(ptr[n] > 0 ? ptr[n] : 1) * sizeof(double));
+    int64_t *fillp = malloc((size_t)(n > 0 ? n : 1) * sizeof(int64_t));
+    memcpy(fillp, ptr, (size_t)n * sizeof(int64_t));
+    for (int e = 0; e < nz; e++) {
+      if (a_val[e] == 0.0) continue;
+      const int i = a_row[e], j = a_col[e];
+      p->csr_col[fillp[i]] = j; p->csr_val[fillp[i]++] = a_val[e];
+      if (i != j) { p->csr_col[fillp[j]] = i; p->csr_val[fillp[j]++] = a_val[e]; }
+    }
+    free(fillp);
+    p->csr_ptr = ptr;
+  }
   { /* ascending arena offsets: coalesced device scatter, and the entries of the shared top of the
      * tree (the tail of the arena) form a suffix that non-root ranks skip (multi-GPU fill) */
     typedef struct { int64_t d; double v; } dv_t;
@@ -530,6 +552,7 @@ void cholamd_plan_destroy(cholamd_plan *p)
   free(p->cl); free(p->snap); free(p->snap_n); free(p->perm); free(p->iperm); free(p->sep_of_pos); free(p->sep_size);
   free(p->sep_off); free(p->tree); free(p->heap_of); free(p->level_of); free(p->blk); free(p->blk_index);
   free(p->panel_off); free(p->panel_ld); free(p->panel_rows); free(p->dinv_off); free(p->a_dst); free(p->a_val); free(p->ops);
+  free(p->csr_ptr); free(p->csr_col); free(p->csr_val);
   free(p);
 }
 

@@ -109,6 +109,33 @@ class Device:
     def solve(self, arena, b, x, stream=None):
         check(self.L.cholamd_solve(self.h, self.ptr(arena), self.ptr(b), self.ptr(x), _stream_ptr(stream)), "cholamd_solve")
 
+    # -- mixed precision: fp32 factor + fp64 iterative refinement (BASELINE config 5) -----------------
+    def new_arena_f32(self):
+        import torch
+        return torch.empty(self.plan.arena_doubles, dtype=torch.float32, device=f"cuda:{self.device_id}")
+
+    def fill_f32(self, arena32, stream=None):
+        check(self.L.cholamd_device_fill_f32(self.h, self.ptr(arena32), _stream_ptr(stream)), "cholamd_device_fill_f32")
+
+    def factor_f32(self, arena32, stream=None):
+        check(self.L.cholamd_factor_f32(self.h, self.ptr(arena32), _stream_ptr(stream)), "cholamd_factor_f32")
+
+    def solve_f32(self, arena32, b, x, stream=None):
+        check(self.L.cholamd_solve_f32(self.h, self.ptr(arena32), self.ptr(b), self.ptr(x), _stream_ptr(stream)), "cholamd_solve_f32")
+
+    def solve_refine(self, arena32, b, x, max_iter=20, tol=1e-12, stream=None):
+        """x = A^-1 b by iterative refinement on the fp32 factor; returns (corrections applied, ||b - A x|| / ||b||)."""
+        it, rel = C.c_int(0), C.c_double(0.0)
+        check(self.L.cholamd_solve_refine(self.h, self.ptr(arena32), self.ptr(b), self.ptr(x), int(max_iter), float(tol),
+                                          C.byref(it), C.byref(rel), _stream_ptr(stream)), "cholamd_solve_refine")
+        return it.value, rel.value
+
+    def residual(self, b, x, r=None, stream=None):
+        """||b - A x|| / ||b|| in fp64 on the device (A = the matrix file's entries)."""
+        rel = C.c_double(0.0)
+        check(self.L.cholamd_residual(self.h, self.ptr(b), self.ptr(x), self.ptr(r) if r is not None else None, C.byref(rel), _stream_ptr(stream)), "cholamd_residual")
+        return rel.value
+
     def set_timing(self, on):
         check(self.L.cholamd_device_set_timing(self.h, int(on)), "set_timing")
 

@@ -253,6 +253,21 @@ int cholamd_device_set_option(cholamd_device *d, const char *name, int value);
  * rounding (~1e-16 relative), NOT bit for bit; option "solve_reference_shape" selects the deterministic per-call
  * kernels of the BLAS-level entry points instead (slow beyond ~10^5 unknowns). */
 int cholamd_solve(cholamd_device *d, const double *d_arena, const double *d_b, double *d_x, void *stream);
+/* ---- mixed precision (BASELINE config 5; not in the reference, whose arithmetic is fp64 CBLAS throughout): fp32 factor +
+ * fp64 iterative refinement.  The fp32 arena has the fp64 arena's element layout: cholamd_plan_arena_doubles() FLOATS.
+ * The fp32 schedule factors pivots in blocks of at most 128 columns out of LDS (v_mfma_f32 kernels, one launch per phase);
+ * info as for the fp64 path (cholamd_factor_info).  cholamd_solve_f32 is one solve with the fp32 factor (vectors and
+ * arithmetic fp64, L converted on load); cholamd_solve_refine iterates x += (L32 L32^T)^-1 (b - A x) with the residual
+ * in fp64 against the matrix file's A until ||b - A x|| / ||b|| <= tol or max_iter corrections have been applied, and
+ * returns the corrections used and the final relative residual.  cholamd_residual computes that residual for any x
+ * (d_r may be NULL); both synchronise the stream. */
+int cholamd_device_fill_f32(cholamd_device *d, float *d_arena32, void *stream);
+int cholamd_factor_f32(cholamd_device *d, float *d_arena32, void *stream);
+int cholamd_factor_levels_f32(cholamd_device *d, float *d_arena32, int level_hi, int level_lo, void *stream);
+int cholamd_solve_f32(cholamd_device *d, const float *d_arena32, const double *d_b, double *d_x, void *stream);
+int cholamd_solve_refine(cholamd_device *d, const float *d_arena32, const double *d_b, double *d_x, int max_iter, double tol,
+                         int *iters_out, double *relres_out, void *stream);
+int cholamd_residual(cholamd_device *d, const double *d_b, const double *d_x, double *d_r, double *relres_out, void *stream);
 /* average device time (ms) of the three kernel families of the last cholamd_factor call measured
  * with HIP events on its stream; valid after cholamd_device_sync.  Enable with set_timing(1). */
 int cholamd_device_set_timing(cholamd_device *d, int on);
