@@ -80,7 +80,9 @@ int main(int argc, char **argv)
     fclose(f);
   }
 
-  if (strcmp(precision, "fp64")) DIE("--precision %s is not supported (fp64)", precision);
+  const int mixed = !strcmp(precision, "mixed");
+  if (!mixed && strcmp(precision, "fp64")) DIE("--precision %s: fp64 or mixed", precision);
+  if (mixed && gpus > 1) DIE("--precision mixed is a single-GPU path");
   if (gpus < 1 || gpus > 64 || (gpus & (gpus - 1))) DIE("--gpus must be a power of two");
   if (cholamd_device_count() < gpu + gpus) DIE("--gpus %d from device %d: only %d HIP devices are visible", gpus, gpu, cholamd_device_count());
   /* one device object + arena per GPU; devs[0] ends up with the complete factor */
@@ -99,13 +101,13 @@ int main(int argc, char **argv)
   double t_factor = 0;
   for (int it = 0; it < iterations; it++) { /* mmat.rg:1212-1358 */
     for (int g = 0; g < gpus; g++)
-      if (cholamd_device_fill(devs[g], arenas[g], NULL) || cholamd_device_sync(devs[g], NULL)) DIE("fill: %s", cholamd_last_error());
+      if ((mixed ? cholamd_device_fill_f32(devs[g], (float *)arenas[g], NULL) : cholamd_device_fill(devs[g], arenas[g], NULL)) || cholamd_device_sync(devs[g], NULL)) DIE("fill: %s", cholamd_last_error());
     for (int lvl = levels - 1, interval = 0; lvl >= 0; lvl--) {
       printf("Factoring Level: %d Interval: %d Iteration: %d\n", lvl, interval, it);
       if (lvl <= levels - 2) interval++;
     }
     double t1 = now_s();
-    if (cholamd_factor_multi(devs, arenas, comms, gpus, NULL)) DIE("factor: %s", cholamd_last_error());
+    if (mixed ? cholamd_factor_f32(dev, (float *)d_arena, NULL) : cholamd_factor_multi(devs, arenas, comms, gpus, NULL)) DIE("factor: %s", cholamd_last_error());
     for (int g = 0; g < gpus; g++) if (cholamd_device_sync(devs[g], NULL)) DIE("factor: %s", cholamd_last_error());
     t_factor = now_s() - t1;
     for (int g = 0; g < gpus; g++) {
@@ -124,6 +126,10 @@ int main(int argc, char **argv)
 
   if (*factor_file) { /* mmat.rg:1360-1362 */
     if (cholamd_device_download(dev, h_arena, d_arena, na, NULL)) DIE("download: %s", cholamd_last_error());
+    if (mixed) { /* the device arena holds na floats (in the first half of the buffer): widen in place, back to front */
+      const float *f = (const float *)h_arena;
+      for (int64_t i = na - 1; i >= 0; i--) h_arena[i] = (double)f[i];
+    }
     printf("saving matrix to: %s\n\n", factor_file);
     if (cholamd_plan_write_matrix(plan, h_arena, factor_file, full)) DIE("%s", cholamd_last_error());
   }
@@ -132,7 +138,12 @@ int main(int argc, char **argv)
     if (cholamd_read_vector(b_file, n, b)) DIE("%s", cholamd_last_error());
     if (cholamd_device_alloc(dev, n, &d_b) || cholamd_device_alloc(dev, n, &d_x) || cholamd_device_upload(dev, d_b, b, n, NULL)) DIE("%s", cholamd_last_error());
     printf("Forward Substitution\nBackward Substitution\n");
-    if (cholamd_solve(dev, d_arena, d_b, d_x, NULL) || cholamd_device_download(dev, x, d_x, n, NULL)) DIE("solve: %s", cholamd_last_error());
+    if (mixed) {
+      int iters = 0; double rel = 0.0;
+      if (cholamd_solve_refine(dev, (const float *)d_arena, d_b, d_x, 30, 1e-14, &iters, &rel, NULL)) DIE("solve: %s", cholamd_last_error());
+      fprintf(stderr, "[cholamd] iterative refinement: %d corrections, ||b - A x|| / ||b|| = %.3e\n", iters, rel);
+      if (cholamd_device_download(dev, x, d_x, n, NULL)) DIE("solve: %s", cholamd_last_error());
+    } else if (cholamd_solve(dev, d_arena, d_b, d_x, NULL) || cholamd_device_download(dev, x, d_x, n, NULL)) DIE("solve: %s", cholamd_last_error());
     printf("Done solve.\n");
     if (*solution_file) {
       printf("Saving solution to: %s\n", solution_file);

@@ -29,6 +29,10 @@ gen)    for c in gen:40:6 gen:60:8; do n=$(echo $c | tr ':' '_')
           (cd /tmp && run stats_$n 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$n -o s -- python3 /root/repo/bench.py --case $c --steps 5 --warmup 1 > $out/bench_$n.json 2> $out/stats_$n.err); cat $out/bench_$n.json
           (cd /tmp && run pmc_$n 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_$n -o p -- python3 /root/repo/bench.py --case $c --steps 3 --warmup 1 > $out/pmc_$n.json 2> $out/pmc_$n.err) || tail -5 $out/pmc_$n.err
         done ;;
+mixed)  for c in gen:60:8 gen:100:10; do n=$(echo $c | tr ':' '_')
+          run mixed_$n 600 python bench.py --case $c --precision mixed --steps 3 --warmup 1 > $out/bench_mixed_$n.json 2> $out/bench_mixed_$n.err; cat $out/bench_mixed_$n.json; tail -3 $out/bench_mixed_$n.err
+        done ;;
+mixedtests) run mixedtests 900 python -m pytest tests/test_gpu_mixed.py -x -q > $out/pytest_mixed.log 2>&1; tail -15 $out/pytest_mixed.log ;;
 *) echo "unknown step $s" ;;
 esac; done
 echo "batch done"

@@ -52,3 +52,37 @@ def test_cli_full_precision_and_iterations(tmp_path, golden):
 def test_cli_reports_missing_input(tmp_path):
     r = subprocess.run([BIN, "-i", str(tmp_path / "nope.mtx"), "-s", "a", "-c", "b"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "cannot open" in r.stderr
+
+
+def test_cli_mixed_precision_and_repeat(tmp_path, golden):
+    """--precision mixed: fp32 factor (written widened), solution refined to fp64 accuracy; --repeat = --iterations."""
+    m, o, c, b = case_paths("lapl_3375x3375")
+    fac, sol = tmp_path / "f.mtx", tmp_path / "x.txt"
+    r = subprocess.run([BIN, "-i", m, "-s", o, "-c", c, "-b", b, "-o", str(sol), "-m", str(fac), "--precision", "mixed", "--repeat", "2", "--full-precision"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Done factoring Iteration: 1." in r.stdout and "iterative refinement" in r.stderr
+    g = golden("lapl_3375x3375")
+    L = np.tril(scipy.io.mmread(str(fac)).toarray())
+    assert np.abs(L - g["L"]).max() <= 2e-5
+    assert np.abs(np.genfromtxt(str(sol)) - g["x"]).max() <= 1e-10 * max(1.0, np.abs(g["x"]).max())
+
+
+def test_cli_gpus_flag_is_honest(tmp_path):
+    """--gpus N needs N devices (the test box has one): the program must refuse, not fall back to one GPU;
+    --gpus 1 is the plain path; a non-power-of-two is an argument error."""
+    m, o, c, b = case_paths("lapl_400x400")
+    import torch
+    n = torch.cuda.device_count()
+    r = subprocess.run([BIN, "-i", m, "-s", o, "-c", c, "--gpus", str(2 * n if n & (n - 1) == 0 else 16)], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "HIP devices are visible" in r.stderr
+    r = subprocess.run([BIN, "-i", m, "-s", o, "-c", c, "--gpus", "3"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "power of two" in r.stderr
+    sol = tmp_path / "x.txt"
+    r = subprocess.run([BIN, "-i", m, "-s", o, "-c", c, "-b", b, "-o", str(sol), "--gpus", "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    if n >= 2:  # a node: the sharded path through cholamd_factor_multi (one process, RCCL group of all-reduces)
+        sol2 = tmp_path / "x2.txt"
+        r = subprocess.run([BIN, "-i", m, "-s", o, "-c", c, "-b", b, "-o", str(sol2), "--gpus", "2", "--full-precision"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert np.allclose(np.genfromtxt(str(sol)), np.genfromtxt(str(sol2)), rtol=1e-6, atol=1e-6)

@@ -216,3 +216,16 @@ def test_partition_work_lists(ca, plans):
             assert len(mine) == (P.nsep - (world - 1)) // world
         top = sorted(s for s, o in owners.items() if o == -1)
         assert top == list(range(P.nsep - (world - 1) + 1, P.nsep + 1))
+
+
+def test_bench_gpus_flag_never_mislabels(tmp_path):
+    """bench.py --gpus N (VERDICT r1 / ADVICE): a world size that differs from --gpus is an error, and without a launcher the
+    ranks are started as children before anything touches the GPU -- on this GPU-less box they must all fail loudly."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, bench, "--gpus", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing to report a mislabelled run" in r.stderr and "{" not in r.stdout
+    r = subprocess.run([sys.executable, bench, "--gpus", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "power of two" in r.stderr
