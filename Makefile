@@ -45,3 +45,22 @@ clean:
 	$(MAKE) -s -C oracle clean
 
 .PHONY: all oracle clean
+
+# ---- sanitizer build of the HOST code (ingest, symbolic phase, schedules, generator, C-ABI glue): AddressSanitizer +
+# UBSan; the device code is built as usual (GPU sanitizers are not available on the pool).  `make asan` builds
+# cholesky_amd/lib/asan/libcholamd.so and runs the CPU test-suite of the host logic against it.
+ASAN_OUT := cholesky_amd/lib/asan
+SAN := -fsanitize=address,undefined -fno-omit-frame-pointer -g
+ASAN_HOST_OBJS := $(ASAN_OUT)/chol_ingest.o $(ASAN_OUT)/chol_symbolic.o $(ASAN_OUT)/chol_schedule.o $(ASAN_OUT)/chol_generate.o
+$(ASAN_OUT)/%.o: $(CSRC)/%.c $(CSRC)/chol_plan.h include/cholamd.h
+	@mkdir -p $(ASAN_OUT)
+	$(CC) $(CFLAGS) -O1 $(SAN) -c $< -o $@
+$(ASAN_OUT)/chol_api.o: $(CSRC)/chol_api.cpp $(CSRC)/chol_plan.h $(CSRC)/chol_kernels.h include/cholamd.h
+	@mkdir -p $(ASAN_OUT)
+	$(HIPCC) $(HIPFLAGS) -O1 $(SAN) -fno-gpu-sanitize -x hip -c $< -o $@
+$(ASAN_OUT)/libcholamd.so: $(ASAN_HOST_OBJS) $(ASAN_OUT)/chol_api.o $(OUT)/chol_kernels.o $(OUT)/chol_kernels_f32.o
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(SAN) -fno-gpu-sanitize -o $@ $^ -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+asan: $(ASAN_OUT)/libcholamd.so oracle
+	CHOLAMD_LIB=$(abspath $(ASAN_OUT)/libcholamd.so) LD_PRELOAD=$$($(CC) -print-file-name=libasan.so):$$($(CC) -print-file-name=libubsan.so) \
+	ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 python3 -m pytest tests/test_host.py -x -q -p no:cacheprovider
+.PHONY: asan

@@ -253,9 +253,10 @@ def main():
 
     if rank == 0:
         calls, flops = plan.counts()
-        kinds = {"potrf": float(flops[0]), "trsm": float(flops[1]), "update": float(flops[2] + flops[3])}
+        kinds = {"potrf": float(flops[0]), "trsm": float(flops[1]), "update": float(flops[2] + flops[3]), "other": float(plan.flops)}
         # the fp64 library fuses the POTRF and TRSM of a column-block step into one launch (k_potrf_trsm), timed as
         # "potrf"; separate TRSM launches exist in the fp32 schedule (and with option fuse = 0)
+        program = timing["other"][1] > 0  # the whole factorisation as ONE launch (k_program), timed as "other"
         fused = timing["trsm"][1] == 0
         if fused:
             kinds["potrf"] += kinds["trsm"]
@@ -267,8 +268,8 @@ def main():
         piv_entries = sum(n * (n + 1) // 2 for n in sizes.values())
         anc_entries = sum(int(b[4] - b[2] + 1) * sizes[int(b[1])] for b in blocks if b[0] != b[1])
         panel_bytes = {"potrf": 2 * eb * piv_entries + (2 * eb * anc_entries + eb * piv_entries if fused else 0.0),
-                       "trsm": 2 * eb * anc_entries + eb * piv_entries, "update": None}
-        dom = max(("potrf", "trsm", "update"), key=lambda k: timing[k][0])
+                       "trsm": 2 * eb * anc_entries + eb * piv_entries, "update": None, "other": 2 * eb * (piv_entries + anc_entries)}
+        dom = max(("potrf", "trsm", "update", "other"), key=lambda k: timing[k][0])
         ms, n_launch = timing[dom]
         launches_per_factor = n_launch / reps
         # launch duration: HIP events around every launch on the launch stream, minus the empty-pair reading (the event
@@ -282,7 +283,7 @@ def main():
         if mixed:
             names = {"potrf": "k32_potrf", "trsm": "k32_trsm", "update": "k32_update_mt + k32_update"}
         else:
-            names = {"potrf": "k_potrf_trsm" if fused else "k_potrf_rr", "trsm": "k_trsm_rr", "update": "k_update_mt + k_update" if generated else "k_update"}
+            names = {"potrf": "k_potrf_trsm" if fused else "k_potrf_rr", "trsm": "k_trsm_rr", "update": "k_update_mt + k_update" if generated else "k_update", "other": "k_program"}
         prof = profile_numbers(names[dom].split(" + ")[0], args.case, mixed)
         out = {
             "metric": "fp64 factorization GF/s (numeric level loop, F_ref flops) on 3-D Laplacian" if not mixed else
@@ -310,7 +311,8 @@ def main():
                          "alg_flops_per_launch": flops_per_launch,
                          "whole_step_frac_of_peak": round(value * 1e-3 / peak, 6),
                          "whole_step_alg_GBs": round(plan.alg_bytes * K / dt * 1e-9, 3), "hbm_peak_GBs": PEAK_HBM_GBS,
-                         "kernel_ms_per_step_events_raw": {k: round(timing[k][0] / reps, 5) for k in ("potrf", "trsm", "update")}},
+                         "kernel_ms_per_step_events_raw": {k: round(timing[k][0] / reps, 5) for k in ("potrf", "trsm", "update", "other")},
+                         "launch_structure": "one program launch per factorisation (resident workgroups, job queue, followers)" if program else "per level and column-block step: fused POTRF+TRSM launch + update launch(es)"},
         }
         if refine is not None:
             out["config"]["refinement"] = refine

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcholamd.so")
+LIB_PATH = os.environ.get("CHOLAMD_LIB") or os.path.join(_HERE, "lib", "libcholamd.so")  # CHOLAMD_LIB: the sanitizer build of `make asan`
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cholamd.h")
 
 
@@ -91,6 +91,10 @@ def load():
     L.cholamd_plan_arena_to_dense.argtypes = [vp, vp, vp]
     L.cholamd_plan_fill_host_part.argtypes = [vp, vp, ci, ci, C.POINTER(i64)]
     L.cholamd_plan_level_work_counts.argtypes = [vp, ci, ci, ci, vp]
+    L.cholamd_plan_program_check.argtypes = [vp, ci, ci]
+    L.cholamd_plan_program_counts.argtypes = [vp, ci, vp]
+    L.cholamd_plan_program_jobs.argtypes = [vp, ci, i64, vp]
+    L.cholamd_plan_program_jobs.restype = i64
     L.cholamd_plan_write_matrix.argtypes = [vp, vp, C.c_char_p, ci]
     L.cholamd_plan_write_debug_log.argtypes = [vp, vp]
     L.cholamd_device_create.argtypes = [vp, ci, C.POINTER(vp)]
@@ -115,6 +119,7 @@ def load():
     L.cholamd_device_fill.argtypes = [vp, vp, vp]
     L.cholamd_factor.argtypes = [vp, vp, vp]
     L.cholamd_factor_levels.argtypes = [vp, vp, ci, ci, vp]
+    L.cholamd_device_program_trace.argtypes = [vp, vp, vp, i64, vp, C.POINTER(ci)]
     L.cholamd_factor_info.argtypes = [vp, C.POINTER(ci)]
     L.cholamd_solve.argtypes = [vp, vp, vp, vp, vp]
     L.cholamd_device_fill_f32.argtypes = [vp, vp, vp]

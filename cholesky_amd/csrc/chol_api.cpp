@@ -57,6 +57,14 @@ struct cholamd_device {
   bool timing = false;
   std::vector<timed_launch> tl;
   std::vector<hipEvent_t> pool;
+  // the one-launch program of the whole factorisation (single GPU, small problems: chol_build_program / k_program)
+  level_dev prog;
+  chol_job *jobs = nullptr; chol_wait *pwaits = nullptr; chol_ext *exts = nullptr;
+  int *pctr = nullptr, *pctr_total = nullptr; // counters (last one: the queue head) and what one factorisation adds to each
+  int n_job = 0, n_pctr = 0, prog_grid = 0, prog_epoch = 0, prog_epoch_limit = 0;
+  bool prog_ready = false;
+  unsigned long long *trace = nullptr; // diagnostic: per-job clock stamps of the next program launches (cholamd_device_program_trace)
+  std::vector<chol_job> jobs_host;
   // mixed precision (fp32 factor + fp64 refinement): work lists of the fp32 kernels, their workspace, A as a device CSR
   std::vector<level_dev> lv32;
   float *ws32 = nullptr;
@@ -100,6 +108,10 @@ static void free_levels(cholamd_device *d)
   d->lv.clear();
   for (auto &l : d->lv32) free_level(l);
   d->lv32.clear();
+  free_level(d->prog);
+  (void)hipFree(d->jobs); (void)hipFree(d->pwaits); (void)hipFree(d->exts); (void)hipFree(d->pctr); (void)hipFree(d->pctr_total);
+  d->jobs = nullptr; d->pwaits = nullptr; d->exts = nullptr; d->pctr = nullptr; d->pctr_total = nullptr;
+  d->prog_ready = false;
 }
 static int upload_level(level_dev &l, const chol_level_work &w)
 {
@@ -125,6 +137,41 @@ static int build_levels(cholamd_device *d)
     rc = upload_level(d->lv[lvl], w);
     chol_level_work_free(&w);
     if (rc) return rc;
+  }
+  // single GPU, small problem: the same factorisation as one program launch (the per-level lists above stay for level
+  // ranges, the partitioned run and the per-launch timing)
+  if (d->world == 1 && d->opt.program) {
+    chol_level_work w;
+    chol_program g;
+    if (chol_build_program(d->plan, &d->opt, &w, &g) == 0) {
+      int rc = upload_level(d->prog, w);
+      std::vector<int> tot(g.ctr_total, g.ctr_total + g.n_ctr);
+      int ncu = 256;
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, d->dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+      d->prog_grid = g.n_job < ncu ? g.n_job : ncu;
+      tot.push_back(g.n_job + d->prog_grid); // the queue head: every workgroup draws one index past the end
+      int mx = 1;
+      for (int t : tot) mx = t > mx ? t : mx;
+      d->prog_epoch_limit = (1 << 30) / mx;
+      d->n_job = g.n_job; d->n_pctr = (int)tot.size(); d->prog_epoch = 0;
+      d->jobs_host.assign(g.job, g.job + g.n_job);
+      if (!rc) rc = upload_vec(&d->jobs, g.job, (size_t)g.n_job);
+      const chol_wait no_wait = { 0, 0 };
+      chol_ext no_ext;
+      std::memset(&no_ext, 0, sizeof no_ext);
+      if (!rc) rc = g.n_wait > 0 ? upload_vec(&d->pwaits, g.wait, (size_t)g.n_wait) : upload_vec(&d->pwaits, &no_wait, (size_t)1);
+      if (!rc) rc = g.n_ext > 0 ? upload_vec(&d->exts, g.ext, (size_t)g.n_ext) : upload_vec(&d->exts, &no_ext, (size_t)1);
+      if (!rc) rc = upload_vec(&d->pctr_total, tot.data(), tot.size());
+      if (!rc) {
+        HIPCHK(hipMalloc((void **)&d->pctr, tot.size() * sizeof(int)));
+        HIPCHK(hipMemset(d->pctr, 0, tot.size() * sizeof(int)));
+      }
+      chol_level_work_free(&w);
+      chol_program_free(&g);
+      if (rc) return rc;
+      d->prog_ready = d->n_job > 0;
+    }
   }
   return 0;
 }
@@ -193,6 +240,8 @@ extern "C" int cholamd_device_set_option(cholamd_device *d, const char *name, in
   else if (n == "fuse_update_max") d->opt.fuse_update_max = value;
   else if (n == "mt_min_tiles") d->opt.mt_min_tiles = value;
   else if (n == "cells") d->opt.cells = value != 0;
+  else if (n == "program") d->opt.program = value != 0;
+  else if (n == "follow") d->opt.follow = value != 0;
   else if (n == "solve_reference_shape") { d->solve_reference_shape = value != 0; rebuild = false; }
   else { chol_set_error("unknown option '%s'", n.c_str()); return CHOLAMD_ERR_ARG; }
   return rebuild ? build_levels(d) : 0;
@@ -347,7 +396,48 @@ extern "C" int cholamd_factor_levels(cholamd_device *d, double *d_arena, int lev
 }
 extern "C" int cholamd_factor(cholamd_device *d, double *d_arena, void *stream)
 {
-  return cholamd_factor_levels(d, d_arena, d->plan->levels - 1, 0, stream);
+  if (!d->prog_ready) return cholamd_factor_levels(d, d_arena, d->plan->levels - 1, 0, stream);
+  HIPCHK(hipSetDevice(d->dev));
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipMemsetAsync(d->info, 0, 2 * sizeof(int), st));
+  // counters are monotonic across factorisations (no reset between them); they start over, in stream order, long before
+  // any of them can wrap
+  if (d->prog_epoch >= d->prog_epoch_limit) { HIPCHK(hipMemsetAsync(d->pctr, 0, (size_t)d->n_pctr * sizeof(int), st)); d->prog_epoch = 0; }
+  const level_dev &l = d->prog;
+  {
+    scoped_timer t(d, st, 3, true);
+    HIPCHK((hipError_t)chol_launch_program(d_arena, d->ws, d->jobs, d->n_job, d->pwaits, l.potrf, l.trsm, l.task, l.src, d->exts, d->pctr, d->pctr_total, d->prog_epoch,
+                                           d->pctr + d->n_pctr - 1, d->prog_epoch * (d->n_job + d->prog_grid), d->prog_grid, d->info, d->trace, st));
+  }
+  d->prog_epoch++;
+  return 0;
+}
+extern "C" int cholamd_device_program_trace(cholamd_device *d, double *d_arena, void *stream, int64_t cap, int64_t *out, int *njobs_out)
+{ // diagnostic: one program launch on d_arena with per-job stamps; out[5 j ..] = kind, drawn, waits over, ended (10 ns ticks since
+  // the first job was drawn), workgroup
+  HIPCHK(hipSetDevice(d->dev));
+  if (!d->prog_ready) { chol_set_error("no program launch for this problem / these options"); return CHOLAMD_ERR_ARG; }
+  *njobs_out = d->n_job;
+  if (cap < (int64_t)5 * d->n_job) return 0;
+  HIPCHK(hipMalloc((void **)&d->trace, (size_t)4 * d->n_job * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(d->trace, 0, (size_t)4 * d->n_job * sizeof(unsigned long long)));
+  int rc = cholamd_factor(d, d_arena, stream);
+  std::vector<unsigned long long> h((size_t)4 * d->n_job);
+  if (!rc) {
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    HIPCHK(hipMemcpy(h.data(), d->trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(d->trace);
+  d->trace = nullptr;
+  if (rc) return rc;
+  unsigned long long t0 = ~0ull;
+  for (int j = 0; j < d->n_job; j++) if (h[4 * j] && h[4 * j] < t0) t0 = h[4 * j];
+  for (int j = 0; j < d->n_job; j++) {
+    out[5 * j] = d->jobs_host[j].kind + (d->jobs_host[j].kind == 0 && d->jobs_host[j].n_ext > 0 ? 10 : 0);
+    for (int q = 0; q < 3; q++) out[5 * j + 1 + q] = (int64_t)(h[4 * j + q] - t0);
+    out[5 * j + 4] = (int64_t)h[4 * j + 3];
+  }
+  return 0;
 }
 extern "C" int cholamd_factor_info(cholamd_device *d, int *sep_out)
 {
@@ -1151,7 +1241,7 @@ extern "C" int cholamd_exchange_tail(cholamd_device *d, double *d_arena, cholamd
 extern "C" int cholamd_factor_sharded(cholamd_device *d, double *d_arena, cholamd_comm *c, void *stream)
 {
   const int L = d->plan->levels, split = chol_split_level(d->world);
-  if (d->world == 1) return cholamd_factor_levels(d, d_arena, L - 1, 0, stream);
+  if (d->world == 1) return cholamd_factor(d, d_arena, stream);
   int rc = cholamd_factor_levels(d, d_arena, L - 1, split, stream);
   if (!rc) rc = cholamd_exchange_tail(d, d_arena, c, stream);
   if (!rc) rc = cholamd_factor_levels(d, d_arena, split - 1, 0, stream);
@@ -1160,7 +1250,7 @@ extern "C" int cholamd_factor_sharded(cholamd_device *d, double *d_arena, cholam
 extern "C" int cholamd_factor_multi(cholamd_device *const *devs, double *const *arenas, cholamd_comm *const *comms, int n, void *const *streams)
 { // one process, n devices: everything is asynchronous on each device's stream
   if (n < 1) { chol_set_error("no devices"); return CHOLAMD_ERR_ARG; }
-  if (n == 1) return cholamd_factor_levels(devs[0], arenas[0], devs[0]->plan->levels - 1, 0, streams ? streams[0] : nullptr);
+  if (n == 1) return cholamd_factor(devs[0], arenas[0], streams ? streams[0] : nullptr);
   const int L = devs[0]->plan->levels, split = chol_split_level(n);
   for (int g = 0; g < n; g++) {
     if (devs[g]->world != n || devs[g]->rank != g) { chol_set_error("device %d is not partitioned as rank %d of %d", g, g, n); return CHOLAMD_ERR_ARG; }

@@ -69,6 +69,30 @@ __device__ __forceinline__ d4 rank_k_16x16(d4 acc, const double *__restrict__ X,
   const double *px = X + r + (int64_t)kq * ldx;
   const double *py = Y + r + (int64_t)kq * ldy;
   int k0 = 0;
+  if (PUB) {
+    // in-launch hand-offs are read past the L2 of the producer's XCD: a memory round trip per batch.  Two batches of sixteen
+    // loads are kept in flight (the next trip's loads are issued ahead of this trip's MFMAs)
+    double x[8], y[8];
+    if (K >= 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { x[u] = vx ? gload<PUB>(&px[(int64_t)(4 * u) * ldx]) : 0.0; y[u] = vy ? gload<PUB>(&py[(int64_t)(4 * u) * ldy]) : 0.0; }
+    }
+    for (; k0 + 32 <= K; k0 += 32) {
+      double xn[8], yn[8];
+      px += 32 * (int64_t)ldx; py += 32 * (int64_t)ldy;
+      const bool more = k0 + 64 <= K;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { xn[u] = vx ? gload<PUB>(&px[(int64_t)(4 * u) * ldx]) : 0.0; yn[u] = vy ? gload<PUB>(&py[(int64_t)(4 * u) * ldy]) : 0.0; }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y[u], x[u], acc, 0, 0, 0);
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { x[u] = xn[u]; y[u] = yn[u]; }
+      }
+    }
+  } else
   for (; k0 + 32 <= K; k0 += 32) { // eight MFMAs per trip, sixteen loads in flight
     double x[8], y[8];
 #pragma unroll
@@ -133,7 +157,10 @@ __device__ __forceinline__ void update_task_body(double *__restrict__ base, cons
   double *C = base + t.c_off;
   if (live && wave == 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cv[q] = *(const volatile double *)(C + min(r, t.mv - 1) + (int64_t)min(g + 4 * q, t.nv - 1) * t.ldc);
+    for (int q = 0; q < 4; ++q) {
+      const double *cp = C + min(r, t.mv - 1) + (int64_t)min(g + 4 * q, t.nv - 1) * t.ldc;
+      cv[q] = PUB ? gload<true>(cp) : *(const volatile double *)cp; // in-launch hand-off: the last writer may be another workgroup of this launch
+    }
   }
   if (PUB && wait) (void)wait_progress(wait, wait_target, 0, info);
   d4 acc = { 0.0, 0.0, 0.0, 0.0 };
@@ -169,8 +196,30 @@ __device__ __forceinline__ void update_task_body(double *__restrict__ base, cons
     for (int q = 0; q < 4; ++q) {
       const int c = g + 4 * q;
       const double v = ((acc[q] + sAcc[0][q][lane]) + sAcc[1][q][lane]) + sAcc[2][q][lane];
-      if (r < t.mv && c < t.nv && (!t.lower || r >= c)) C[r + (int64_t)c * t.ldc] = cv[q] - v;
+      if (r < t.mv && c < t.nv && (!t.lower || r >= c)) gstore<PUB>(&C[r + (int64_t)c * t.ldc], cv[q] - v);
     }
+  }
+}
+// the same task by ONE wave (program launch: twelve tasks of a job at a time, one per wave -- no K split, no LDS reduction,
+// no barrier; sources in program order, K in order: deterministic)
+template <bool PUB>
+__device__ __forceinline__ void update_task_wave(double *__restrict__ base, const chol_upd_task t, const chol_upd_src *__restrict__ srcs, int lane)
+{
+  const int r = lane & 15, g = lane >> 4;
+  double cv[4];
+  double *C = base + t.c_off;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) cv[q] = gload<PUB>(C + min(r, t.mv - 1) + (int64_t)min(g + 4 * q, t.nv - 1) * t.ldc);
+  d4 acc = { 0.0, 0.0, 0.0, 0.0 };
+  for (int s = t.src_begin; s < t.src_end; ++s) {
+    const chol_upd_src sd = srcs[s];
+    const int r0 = sd.range & 255, r1 = sd.range ? (sd.range >> 8) & 255 : t.mv, c0 = (sd.range >> 16) & 255, c1 = sd.range ? (sd.range >> 24) & 255 : t.nv;
+    acc = rank_k_16x16<PUB>(acc, base + sd.a_off + t.ar, sd.lda, r1, base + sd.b_off + t.br, sd.ldb, c1, sd.k, lane, r0, c0);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = g + 4 * q;
+    if (r < t.mv && c < t.nv && (!t.lower || r >= c)) gstore<PUB>(&C[r + (int64_t)c * t.ldc], cv[q] - acc[q]);
   }
 }
 __global__ __launch_bounds__(256) void k_update(double *__restrict__ base, const chol_upd_task *__restrict__ tasks,
@@ -601,7 +650,7 @@ __device__ __forceinline__ void lds_inc(int *cnt, int lane)
 }
 // tile (ti, tj) of the lower triangle of the n x n matrix A in accumulator layout; the last partial diagonal
 // tile is padded with the identity, everything else past n and above the diagonal with zeros
-__device__ __forceinline__ d4 load_tile(const double *A, int lda, int n, int ti, int tj, int r15, int g)
+template <bool PUB> __device__ __forceinline__ d4 load_tile(const double *A, int lda, int n, int ti, int tj, int r15, int g)
 {
   const int row = ti * TS + r15;
   const bool rowok = row < n;
@@ -611,15 +660,110 @@ __device__ __forceinline__ d4 load_tile(const double *A, int lda, int n, int ti,
   for (int q = 0; q < 4; ++q) {
     const int c = g + 4 * q, col = tj * TS + c;
     double e = (row == col) ? 1.0 : 0.0;
-    if (rowok && col < n) e = (ti > tj || c <= r15) ? src[(int64_t)(4 * q) * lda] : 0.0;
+    if (rowok && col < n) e = (ti > tj || c <= r15) ? gload<PUB>(&src[(int64_t)(4 * q) * lda]) : 0.0;
     v[q] = e;
   }
   return v;
 }
-template <bool PUB>
-__device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double *__restrict__ ws, const chol_potrf_desc d, int *__restrict__ info,
-                                              int *__restrict__ progress, int progress_base, double *smem)
+// ---- follower: external panel steps (program launch).  A pivot block that follows its children (or the previous column
+// block of its own pivot) starts from ZERO accumulators and, before it reads its own tiles, applies the contributions
+//   T(i, j) -= E_i E_j^T,   E = (the block's rows) x (16 columns of a source pivot block)
+// as the source's TRSM strips publish them, column tile by column tile (chol_ext: where the rows are, how many columns,
+// the per-column counters the strips raise once their stores have completed).  By the time the last source column is in,
+// the diagonal block's update is complete and the block's own tiles are added on top by the prologue: no update launch,
+// no kernel boundary and no wait for the slowest pivot of the level between a pivot and its parent.  Sources are taken
+// in the order of the list (deterministic summation order).
+// A follower's pivot block has at most CHOL_FOLLOW_MAXT = 10 column tiles (the schedule's blocks have 9): its register tiles are
+// the slots [0, FOLLOW_SLOTS) of rr_owner's deal, an external panel is FOLLOW_LOADS doubles per thread.
+#define FOLLOW_SLOTS 4
+#define FOLLOW_LOADS ((CHOL_FOLLOW_MAXT * TS * TS + RR_THREADS - 1) / RR_THREADS)
+struct follow_args { const chol_ext *ext; int n_ext; const int *ctr; const int *ctr_total; int epoch; };
+// leading column tiles of `x` whose strips have all published (every lane polls one counter: one round trip for all of them)
+__device__ __forceinline__ int ext_ready(const chol_ext &x, int nct, const int *ctr, const int *ctr_total, int epoch, int lane)
 {
+  bool ok = true;
+  if (lane < nct) {
+    const int c = x.chan + lane;
+    ok = __hip_atomic_load(&ctr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch * ctr_total[c] >= x.nstrip;
+  }
+  const unsigned long long notok = __ballot(!ok);
+  return notok ? __builtin_ctzll(notok) : nct;
+}
+template <bool UPD>
+__device__ __forceinline__ void follow_external(const double *__restrict__ base, const follow_args f, int T, int n, double *sE, d4 (&tile)[11], d4 (&stage)[3],
+                                                const int (&ijp)[12], int w, int lane, int tid, int *info)
+{
+  const int lp = lane; // accumulator layout: register q of lane l at q * 64 + l
+  int buf = 0;
+  for (int xi = 0; xi < f.n_ext; ++xi) {
+    const chol_ext x = f.ext[xi];
+    const int nct = (x.k + TS - 1) / TS;
+    const double *src = base + x.off;
+    // Column tiles are consumed in order.  `ready` = leading column tiles known to be published; the poll for more is issued
+    // before the barrier and update of the tile at hand and read after them (its round trip is off the step), and the loads of
+    // tile ee + 1 are issued before the update with tile ee whenever it is known to be ready.
+    int ready = 0, loaded = -1;
+    double va[FOLLOW_LOADS];
+#define EXT_LOAD(E_)                                                                                                 \
+  _Pragma("unroll") for (int it = 0; it < FOLLOW_LOADS; ++it) {                                                      \
+    const int idx = tid + it * RR_THREADS;                                                                           \
+    const int row = (idx >> 8) * TS + (idx & 15), col = (E_) * TS + ((idx >> 4) & 15);                               \
+    va[it] = (idx < T * TS * TS && row < n && col < x.k) ? gload<true>(&src[row + (int64_t)col * x.ld]) : 0.0;       \
+  }
+    for (int ee = 0; ee < nct; ++ee) {
+      if (ready <= ee) {
+        ready = ext_ready(x, nct, f.ctr, f.ctr_total, f.epoch, lane);
+        for (int it = 0; ready <= ee; ++it) { // bounded like wait_progress: a stall fails the factorisation through info
+          if (it >= (1 << 16)) { if (lane == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); ready = nct; break; }
+          __builtin_amdgcn_s_sleep(4);
+          ready = ext_ready(x, nct, f.ctr, f.ctr_total, f.epoch, lane);
+        }
+      }
+      if (loaded != ee) { EXT_LOAD(ee); }
+      double *sB = sE + buf * (RR_MAXT * TS * TS);
+#pragma unroll
+      for (int it = 0; it < FOLLOW_LOADS; ++it) {
+        const int idx = tid + it * RR_THREADS;
+        if (idx < T * TS * TS) sB[idx] = va[it];
+      }
+      int pv = 0, pneed = 0;
+      bool polled = false;
+      if (ee + 1 < ready) { EXT_LOAD(ee + 1); loaded = ee + 1; }
+      else if (ee + 1 < nct) { // ask now, look after the update
+        polled = true;
+        if (lane < nct) { const int c = x.chan + lane; pv = __hip_atomic_load(&f.ctr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pneed = f.epoch * f.ctr_total[c] + x.nstrip; }
+      }
+      lds_barrier();
+      if (UPD) {
+#define EXT_UPDATE(acc_, ti_, tj_)                                                                                   \
+  _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                                   \
+    acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(sB[(tj_) * (TS * TS) + st * 64 + lp], -sB[(ti_) * (TS * TS) + st * 64 + lp], acc_, 0, 0, 0);
+#pragma unroll
+        for (int it = 0; it < 3; ++it) { // the tiles of columns 0 and 1 (parked in LDS by the prologue later on)
+          const int u = w + it * RR_NW;
+          if (u < 2 * T - 1) { const int tj = u < T ? 0 : 1, ti = u < T ? u : u - T + 1; EXT_UPDATE(stage[it], ti, tj); }
+        }
+#pragma unroll
+        for (int s = 0; s < FOLLOW_SLOTS; ++s)
+          if (ijp[s] != 0xffff) { const int ti = ijp[s] & 0xff, tj = ijp[s] >> 8; EXT_UPDATE(tile[s], ti, tj); }
+#undef EXT_UPDATE
+      }
+      buf ^= 1;
+      if (polled) {
+        const unsigned long long notok = __ballot(lane < nct && pv < pneed);
+        const int r2 = notok ? __builtin_ctzll(notok) : nct;
+        ready = r2 > ready ? r2 : ready;
+      }
+    }
+#undef EXT_LOAD
+  }
+}
+
+template <bool PUB, bool FOLLOW = false>
+__device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double *__restrict__ ws, const chol_potrf_desc d, int *__restrict__ info,
+                                              int *__restrict__ progress, int progress_base, double *smem, const follow_args fa = follow_args(), const int tid = threadIdx.x)
+{ // tid: the thread index, passed in by k_program as a value the compiler cannot see through (nothing derived from it may be
+  // hoisted out of the job loop: that is what would spill)
   // tiles in LDS are stored like accumulator registers: element (r, c) at c * 16 + r, so lane (r15, g)
   // register q sits at q * 64 + lp with lp = g * 16 + r15 (conflict free, and directly an MFMA operand)
   // the workgroup's LDS image (RR_SMEM_DOUBLES doubles, carved by the caller: the roles of the fused launch share it)
@@ -641,14 +785,14 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
   const int n = d.n, lda = d.lda;
   const int T = (n + TS - 1) / TS;
   const int ntl = T * (T + 1) / 2;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r15 = lane & 15, g = lane >> 4;
   const int lp0 = g * TS + r15;
 
-  for (int t = threadIdx.x; t < RR_SLOTS * RR_NW; t += RR_THREADS) sIJ[t] = (unsigned short)0xffff;
-  if (threadIdx.x < 8) sFlag[threadIdx.x] = (threadIdx.x == 6 || threadIdx.x == 7) ? 1 : 0; // (1,0) and (1,1) are parked by the prologue
-  if (threadIdx.x < TS * TS) sConv[TS + (threadIdx.x >> 4)][threadIdx.x & 15] = (threadIdx.x >> 4) == (threadIdx.x & 15) ? 1.0 : 0.0;
+  for (int t = tid; t < RR_SLOTS * RR_NW; t += RR_THREADS) sIJ[t] = (unsigned short)0xffff;
+  if (tid < 8) sFlag[tid] = (tid == 6 || tid == 7) ? 1 : 0; // (1,0) and (1,1) are parked by the prologue
+  if (tid < TS * TS) sConv[TS + (tid >> 4)][tid & 15] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
   __syncthreads();
   // Columns 0 and 1 never live in registers (column 0 receives no update, column 1 exactly one): the
   // prologue parks them in LDS.  The tiles of columns >= 2 are dealt in REVERSE column-major order (last
@@ -656,7 +800,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
   // over the waves, and walking the slots downwards visits column k+1 -- next step's panel, the look-ahead
   // tiles first -- before the rest
   const int ntl2 = (T - 2) * (T - 1) / 2; // tiles of columns >= 2 (0 for T <= 2)
-  for (int t = threadIdx.x + 2 * T - 1; t < ntl; t += RR_THREADS) {
+  for (int t = tid + 2 * T - 1; t < ntl; t += RR_THREADS) {
     int ti, tj, ow, os;
     tile_of_index(t, T, ti, tj);
     rr_owner(ntl - 1 - t, ow, os);
@@ -666,6 +810,12 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
 
   if (wave == 0) {
     // ================================================================== factor wave
+    if (FOLLOW && fa.n_ext > 0) { // loads and barriers of the external panel steps (it owns no tile)
+      d4 tdummy[RR_RSLOTS], sdummy[3];
+      int idummy[RR_SLOTS];
+      follow_external<false>(base, fa, T, n, smem + RR_OFF_SOL, tdummy, sdummy, idummy, 0, lane, tid, info);
+      lds_barrier(); // the last panel has been read: the prologue may park column 1 in its place
+    }
     __builtin_amdgcn_s_setprio(3);
     lds_wait_ge(cUpd, RR_NW); // prologue of the tile waves done: (0,0), (1,1) are in sDg, column 0 in sRaw
     int cupd_seen = RR_NW; // last value of cUpd read
@@ -735,16 +885,33 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
     //      Every load of the prologue is issued before the first wait: three tiles of columns 0 / 1 per wave at
     //      most (2 T - 1 <= 33 tiles over 11 waves), then the register tiles.
     d4 stage[3];
+    if (FOLLOW && fa.n_ext > 0) { // the block's own tiles first (their memory round trip overlaps the wait for the first followed
+                                  // column), the followed contributions on top
+#pragma unroll
+      for (int it = 0; it < 3; ++it) {
+        const int u = min(w + it * RR_NW, 2 * T - 2);
+        stage[it] = load_tile<PUB>(A, lda, n, u < T ? u : u - T + 1, u < T ? 0 : 1, r15, g);
+      }
+#pragma unroll
+      for (int s = 0; s < RR_RSLOTS; ++s) {
+        d4 v = { 0.0, 0.0, 0.0, 0.0 };
+        if (ijp[s] != 0xffff) v = load_tile<PUB>(A, lda, n, ijp[s] & 0xff, ijp[s] >> 8, r15, g);
+        tile[s] = v;
+      }
+      follow_external<true>(base, fa, T, n, smem + RR_OFF_SOL, tile, stage, ijp, w, lane, tid, info);
+      lds_barrier();
+    } else {
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
       const int u = min(w + it * RR_NW, 2 * T - 2);
-      stage[it] = load_tile(A, lda, n, u < T ? u : u - T + 1, u < T ? 0 : 1, r15, g);
+      stage[it] = load_tile<PUB>(A, lda, n, u < T ? u : u - T + 1, u < T ? 0 : 1, r15, g);
     }
 #pragma unroll
     for (int s = 0; s < RR_RSLOTS; ++s) {
       d4 v = { 0.0, 0.0, 0.0, 0.0 };
-      if (ijp[s] != 0xffff) v = load_tile(A, lda, n, ijp[s] & 0xff, ijp[s] >> 8, r15, g);
+      if (ijp[s] != 0xffff) v = load_tile<PUB>(A, lda, n, ijp[s] & 0xff, ijp[s] >> 8, r15, g);
       tile[s] = v;
+    }
     }
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
@@ -758,7 +925,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       }
     }
     if (ijp[RR_RSLOTS] != 0xffff) { // heavy waves only (rr_owner)
-      const d4 v = load_tile(A, lda, n, ijp[RR_RSLOTS] & 0xff, ijp[RR_RSLOTS] >> 8, r15, g);
+      const d4 v = load_tile<PUB>(A, lda, n, ijp[RR_RSLOTS] & 0xff, ijp[RR_RSLOTS] >> 8, r15, g);
 #pragma unroll
       for (int q = 0; q < 4; ++q) sOv[hw][q * 64 + lp0] = v[q];
     }
@@ -1065,8 +1232,10 @@ __global__ __launch_bounds__(64) void k_dinv(const double *__restrict__ Lp, int 
 // one strip, four waves (wave = 0..3 of the strip's group); sX = the group's three LDS tiles
 template <bool PUB, int SLOTS>
 __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const double *__restrict__ ws, const chol_trsm_desc d, double (*sX)[TS * TS],
-                                             int wave, int lane, const int *__restrict__ progress, int progress_base, int *__restrict__ info)
-{
+                                             int wave, int lane, const int *__restrict__ progress, int progress_base, int *__restrict__ info,
+                                             int *__restrict__ chan = nullptr)
+{ // chan (program launch): the strip's rows are followed by a POTRF workgroup -- counter chan[J] is raised once column tile J
+  // of the strip has been stored (follow_external)
   const double *Lm = base + d.l_off;
   const double *W = ws + d.dinv_off;
   double *B = base + d.b_off;
@@ -1087,7 +1256,7 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int col = J * TS + g + 4 * q;
-        v[q] = (vrow && col < n) ? B[r15 + (int64_t)col * ldb] : 0.0;
+        v[q] = (vrow && col < n) ? gload<PUB>(&B[r15 + (int64_t)col * ldb]) : 0.0; // program launch: last written by an update job of the same launch
       }
     }
     tile[s] = v;
@@ -1116,6 +1285,10 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
       const int col_ = (J_) * TS + g + 4 * q;                                                           \
       sX[(J_) % 3][q * 64 + lp] = x_[q];                                                                \
       if (vrow && col_ < n) gstore<PUB>(&B[r15 + (int64_t)col_ * ldb], x_[q]);                          \
+    }                                                                                                   \
+    if (PUB && chan && m > 0) { /* this wave stored the whole column tile: tell the follower once it has landed */ \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
+      if (lane == 0) __hip_atomic_fetch_add(&chan[J_], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  \
     }                                                                                                   \
   }
 #define APPLY_X(JX_, s_)                                                                                \
@@ -1248,6 +1421,101 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_trsm(double *__restrict__ 
       const bool live = tid < n_task;
       update_task_body<true>(base, tasks[live ? tid : t0], srcs, sAcc[round & 1][grp], wave & 3, lane, live, round == 0 ? done : nullptr, done_target, info);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PROGRAM launch: the whole factorisation of a small problem as ONE launch.  A grid of resident 768-thread workgroups draws
+// jobs from a queue in a topological order (chol_build_program): POTRF of a pivot block, a group of three TRSM strips, a
+// group of 16x16 update tasks of one target block -- the role bodies of the fused launch.  Jobs hand data to each other
+// inside the launch through agent-scope stores / loads and monotonic counters (a job waits for its list of (counter, value)
+// pairs, every lane polling one of them; it raises its own counters once every wave's stores have completed).  What this
+// removes from the critical path of the level-by-level schedule: 13 kernel boundaries, the ramp of each launch, the wait for
+// the slowest pivot of a level, and -- with followers (follow_external) -- the update launch and the prologue between a
+// pivot and its parent / the next column block of a split pivot.
+// Liveness: a workgroup only takes a job once it is running, jobs are taken in queue order, and a job waits for jobs that
+// are ahead of it in the queue or for the strips of a source that the queue places within reach of the resident
+// workgroups (checked on the host: chol_program_check); every spin is bounded and fails the factorisation through info.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wait_list(const chol_wait *__restrict__ wl, int n, const int *ctr, const int *__restrict__ ctr_total, int epoch, int lane, int *info)
+{
+  for (int b0 = 0; b0 < n; b0 += 64) {
+    int c = 0, need = 0;
+    const bool mine = b0 + lane < n;
+    if (mine) { const chol_wait wt = wl[b0 + lane]; c = wt.ctr; need = wt.value + epoch * ctr_total[wt.ctr]; }
+    for (int it = 0;; ++it) {
+      const bool ok = !mine || __hip_atomic_load(&ctr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+      if (!__ballot(!ok)) break;
+      if (it >= (1 << 15)) { if (lane == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); break; }
+      __builtin_amdgcn_s_sleep(32); // ~1 us between polls: a blocked job is not on anybody's critical path by less than that
+    }
+  }
+}
+__global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ base, double *__restrict__ ws, const chol_job *__restrict__ jobs, int njobs,
+                                                        const chol_wait *__restrict__ waits, const chol_potrf_desc *__restrict__ pdescs,
+                                                        const chol_trsm_desc *__restrict__ tdescs, const chol_upd_task *__restrict__ tasks,
+                                                        const chol_upd_src *__restrict__ srcs, const chol_ext *__restrict__ exts,
+                                                        int *__restrict__ ctr, const int *__restrict__ ctr_total, int epoch, int *__restrict__ head, int head_base,
+                                                        int *__restrict__ info, unsigned long long *__restrict__ trace)
+{ // trace (diagnostic runs only, else nullptr): per job the 100 MHz real-time clock when it was drawn, when its waits were over
+  // and when it ended, and the workgroup that ran it
+  __shared__ double smem[RR_SMEM_DOUBLES];
+  __shared__ int s_job;
+  for (;;) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid)); // opaque per job: lane-dependent addresses of the role bodies are not hoisted out of this loop (and spilled)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int grp = wave >> 2;
+    __syncthreads(); // the previous job is through with the LDS image
+    if (tid == 0) s_job = atomicAdd(head, 1) - head_base;
+    __syncthreads();
+    const int j = s_job;
+    if (j >= njobs) break; // every workgroup draws exactly one job index past the end: head advances by njobs + gridDim.x per launch
+    const chol_job jb = jobs[j];
+    if (trace && tid == 0) { trace[4 * j] = __builtin_amdgcn_s_memrealtime(); trace[4 * j + 3] = blockIdx.x; }
+    // ONE wave polls (hundreds of blocked workgroups are resident at a time: twelve polling waves each would sit on the L2 the
+    // working jobs hand their data through); the others park at the barrier
+    if (jb.n_wait > 0) {
+      if (wave == 0) wait_list(waits + jb.wait_first, jb.n_wait, ctr, ctr_total, epoch, lane, info);
+      lds_barrier();
+    }
+    if (trace && tid == 0) trace[4 * j + 1] = __builtin_amdgcn_s_memrealtime();
+    if (jb.kind == 0) {
+      const chol_potrf_desc pd = pdescs[jb.first];
+      follow_args fa;
+      fa.ext = exts + jb.ext_first; fa.n_ext = jb.n_ext; fa.ctr = ctr; fa.ctr_total = ctr_total; fa.epoch = epoch;
+      potrf_rr_body<true, true>(base, ws, pd, info, ctr + pd.ctr, epoch * ctr_total[pd.ctr], smem, fa, tid);
+    } else if (jb.kind == 1) {
+      double (*sX)[3][TS * TS] = (double (*)[3][TS * TS])smem;
+      chol_trsm_desc d = tdescs[jb.first + min(grp, jb.n - 1)];
+      if (grp >= jb.n) d.m = 0; // every group runs the same number of barriers: the strips of a job share one pivot block
+      trsm_rr_body<true, FUSED_SLOTS>(base, ws, d, sX[grp], wave & 3, lane, ctr + d.flag, epoch * ctr_total[d.flag], info, d.chan >= 0 ? ctr + d.chan : nullptr);
+    } else {
+      if (jb.mode == 0) {
+        for (int t0 = jb.first; t0 < jb.first + jb.n; t0 += RR_NW + 1) { // light tasks: one per wave
+          const int tk = t0 + wave;
+          if (tk < jb.first + jb.n) update_task_wave<true>(base, tasks[tk], srcs, lane);
+        }
+      } else { // heavy tasks: three at a time, four waves each (K or the sources split, fixed-order LDS reduction)
+        double (*sAcc)[3][3][4][64] = (double (*)[3][3][4][64])smem; // [parity of the round][group]
+        int round = 0;
+        for (int t0 = jb.first; t0 < jb.first + jb.n; t0 += 3, ++round) {
+          const int tk = t0 + grp;
+          const bool live = tk < jb.first + jb.n;
+          update_task_body<true>(base, tasks[live ? tk : t0], srcs, sAcc[round & 1][grp], wave & 3, lane, live, nullptr, 0, info);
+        }
+      }
+    }
+    if (jb.sig[0] >= 0) { // the job's stores have completed (every wave's) before its counters move
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_barrier();
+      if (tid == 0) {
+        __hip_atomic_fetch_add(&ctr[jb.sig[0]], jb.sig_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (jb.sig[1] >= 0) __hip_atomic_fetch_add(&ctr[jb.sig[1]], jb.sig_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (trace && tid == 0) trace[4 * j + 2] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -1892,6 +2160,14 @@ int chol_launch_potrf_trsm(double *base, double *ws, const chol_potrf_desc *pdes
   if (n_upd_wg > 1024) n_upd_wg = 1024;
   hipLaunchKernelGGL(k_potrf_trsm, dim3(n_potrf + (n_trsm + 2) / 3 + n_upd_wg), dim3(RR_THREADS), 0, st, base, ws, pdescs, n_potrf, tdescs, n_trsm,
                      tasks, srcs, n_task, n_upd_wg, info, progress, progress_base, done, done_target);
+  return (int)hipGetLastError();
+}
+int chol_launch_program(double *base, double *ws, const chol_job *jobs, int njobs, const chol_wait *waits, const chol_potrf_desc *pdescs, const chol_trsm_desc *tdescs,
+                        const chol_upd_task *tasks, const chol_upd_src *srcs, const chol_ext *exts, int *ctr, const int *ctr_total, int epoch, int *head, int head_base,
+                        int grid, int *info, unsigned long long *trace, hipStream_t st)
+{
+  if (njobs <= 0) return 0;
+  hipLaunchKernelGGL(k_program, dim3(grid), dim3(RR_THREADS), 0, st, base, ws, jobs, njobs, waits, pdescs, tdescs, tasks, srcs, exts, ctr, ctr_total, epoch, head, head_base, info, trace);
   return (int)hipGetLastError();
 }
 int chol_launch_trsm_w(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st)

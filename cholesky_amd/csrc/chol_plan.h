@@ -21,6 +21,7 @@ extern "C" {
 
 #define CHOL_NB 16        /* diagonal-block width of the POTRF/TRSM kernels = one fp64 MFMA tile */
 #define CHOL_RR_MAXN 272  /* largest pivot the register-resident kernels take (17 tiles) */
+#define CHOL_FOLLOW_MAXT 10 /* most column tiles of a pivot block that follows its sources inside the program launch (chol_kernels.hip, follow_external) */
 #define CHOL32_MAXN 128   /* widest pivot block of the fp32 path: its lower triangle is factored out of LDS (chol_kernels_f32.hip) */
 
 typedef struct {
@@ -45,6 +46,7 @@ typedef struct {
   int n, lda;
   int sep;            /* label (for info reporting) */
   int col0;           /* first column of this diagonal block inside its pivot (blocked big pivots) */
+  int ctr, pad;       /* program launch: the block's progress counter (columns published) */
 } chol_potrf_desc;
 
 typedef struct {
@@ -52,7 +54,8 @@ typedef struct {
   int64_t dinv_off;
   int64_t b_off;      /* first row of this row chunk inside the panel */
   int n, ldl, m, ldb; /* m rows (<= CHOL_TRSM_ROWS) */
-  int flag, pad;      /* fused POTRF+TRSM launch: index of the pivot block's POTRF descriptor in the same launch */
+  int flag;           /* fused POTRF+TRSM launch: index of the pivot block's POTRF descriptor in the same launch; program launch: its progress counter */
+  int chan;           /* program launch: first counter of the follow channel the strip reports its column tiles on, or -1 */
 } chol_trsm_desc;
 
 #define CHOL_TRSM_W_MAXN 64 /* widest pivot block the one-wave-per-strip TRSM kernel takes (4 tiles); measured against k_trsm_rr: 6.6 vs 8.0 us at 32, 8.4 vs 9.6 at 64, 12.6 vs 11.1 at 128 */
@@ -75,8 +78,36 @@ typedef struct {
   int lower;          /* 1: diagonal sub-tile of a SYRK target, store only row >= col */
   int src_begin, src_end;
   int ar, br;         /* row offset of this sub-tile inside the A tile rows / B tile rows */
-  int pad;
+  int blk;            /* target block index (program launch: tasks of one block form the update jobs) */
 } chol_upd_task;
+
+/* ---- program launch (chol_build_program, k_program): the whole factorisation as ONE launch of resident workgroups that
+ * draw jobs from a queue in a topological order and hand data to each other through counters in global memory.
+ * Counters are monotonic across factorisations: a wait for `value` on counter c means  ctr[c] - epoch * total[c] >= value,
+ * total[c] = what one factorisation adds to c. */
+typedef struct { int ctr, value; } chol_wait;
+typedef struct {
+  int kind;            /* 0 POTRF of one pivot block, 1 TRSM group (<= 3 strips of one pivot block), 2 update group (16x16 tasks of one target block) */
+  int first, n;        /* POTRF: descriptor index; TRSM: strips [first, first + n); update: tasks [first, first + n) */
+  int wait_first, n_wait; /* chol_wait entries that must hold before the job touches its data */
+  int sig[2], sig_add; /* counters raised by sig_add once the job's stores have completed (-1: none); POTRF jobs publish
+                        * their column progress themselves */
+  int ext_first, n_ext;/* POTRF: the external panels it follows (chol_ext), none = plain POTRF */
+  int mode, pad;       /* update: 0 = one wave per task (light tasks, twelve at a time), 1 = four waves per task splitting K / the sources
+                        * (heavy tasks, three at a time) */
+} chol_job;
+typedef struct {       /* one followed source: (rows of the follower's block) x (columns of a source pivot block) */
+  int64_t off;         /* first of those rows in the first column of the source block */
+  int ld, k;           /* leading dimension of the source panel, columns of the source block */
+  int chan, nstrip;    /* counter chan + e is raised by every one of the nstrip strips covering the rows once it has stored column tile e */
+} chol_ext;
+typedef struct {
+  int n_job; chol_job *job;
+  int n_wait; chol_wait *wait;
+  int n_ext; chol_ext *ext;
+  int n_ctr; int *ctr_total;
+  int follow;          /* followers in use */
+} chol_program;
 
 /* one batched launch: descriptors [first, first + n) of the level's array of that kind */
 typedef struct {
@@ -93,6 +124,8 @@ typedef struct {
   int fuse_update_max;      /* most 16x16 update tasks such a launch carries */
   int mt_min_tiles;
   int cells;                /* extend-add of small phases by 16x16 grid cells of the target blocks */
+  int program;              /* small problems: the whole factorisation as one launch (chol_build_program) */
+  int follow;               /* ... in which pivot blocks follow their children's / predecessor's TRSM strips */
 } chol_sched_opts;
 void chol_sched_opts_default(chol_sched_opts *o);
 void chol_sched_opts_from_env(chol_sched_opts *o);
@@ -155,6 +188,13 @@ int chol_plan_finish(struct cholamd_plan *p, int nz, const int *a_row, const int
 const chol_block *chol_plan_block(const struct cholamd_plan *p, int r, int c);
 int chol_ntiles(const struct cholamd_plan *p, int sep, int interval);
 /* Build the device work lists of one tree level for (rank, world); caller frees with chol_level_work_free */
+/* the whole factorisation as one program (single GPU); descriptors in `w`, jobs in `prog`; CHOLAMD_ERR_ARG (with the reason in
+ * cholamd_last_error) if the problem does not qualify (a pivot block wider than CHOL_FUSE_MAXN, macro-tile phases) */
+int chol_build_program(const struct cholamd_plan *p, const chol_sched_opts *opts, chol_level_work *w, chol_program *prog);
+void chol_program_free(chol_program *prog);
+/* host-side self-check: every wait is satisfiable by the signals of jobs the queue order lets run (simulated with `workers`
+ * resident workgroups), counters total up, the jobs cover the work of the per-level lists */
+int chol_program_check(const struct cholamd_plan *p, const chol_sched_opts *opts, int workers);
 int chol_build_level_work(const struct cholamd_plan *p, const chol_sched_opts *opts /* NULL: defaults */, int level, int rank, int world, chol_level_work *out);
 void chol_level_work_free(chol_level_work *w);
 int chol_owner_of(const struct cholamd_plan *p, int label, int world); /* -1: shared top of the tree */

@@ -68,8 +68,8 @@ static void index_snapshot(const plan_t *p, int lbl, int64_t *first, int *count)
 }
 
 /* growable arrays of the level work */
-typedef struct { int64_t c_off; int ldc, m, n, syrk, src_begin, src_end; } upd_target;
-typedef struct { chol_level_work *w; const chol_sched_opts *o; int cap_p, cap_t, cap_k, cap_km, cap_s, cap_ph; upd_target *pend; int n_pend, cap_pend; } builder;
+typedef struct { int64_t c_off; int ldc, m, n, syrk, src_begin, src_end, blk; } upd_target;
+typedef struct { chol_level_work *w; const chol_sched_opts *o; int force_fine; int cur_blk; const int *follow_lim; int cap_p, cap_t, cap_k, cap_km, cap_s, cap_ph; upd_target *pend; int n_pend, cap_pend; } builder;
 /* Blocking of a pivot at the schedule level.  The POTRF kernel takes pivots up to CHOL_RR_MAXN whole, but one
  * workgroup's MFMA throughput bounds the early steps of a large one (the trailing update of step 0 of a
  * 17 x 17 tile grid is 120 tile updates on one CU); a pivot wider than CHOL_SPLIT_MIN is therefore factored
@@ -81,7 +81,7 @@ static int env_int(const char *name, int dflt) { const char *e = getenv(name); r
 void chol_sched_opts_default(chol_sched_opts *o)
 {
   o->split_min = CHOL_SPLIT_MIN; o->split_nb = CHOL_SPLIT_NB; o->fuse = 1; o->fuse_update_max = CHOL_FUSE_UPDATE_MAX;
-  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1;
+  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1; o->program = 1; o->follow = 1;
 }
 void chol_sched_opts_from_env(chol_sched_opts *o)
 {
@@ -92,6 +92,8 @@ void chol_sched_opts_from_env(chol_sched_opts *o)
   o->fuse_update_max = env_int("CHOLAMD_FUSE_UPDATE_MAX", o->fuse_update_max);
   o->mt_min_tiles = env_int("CHOLAMD_MT_MIN_TILES", o->mt_min_tiles);
   o->cells = !env_int("CHOLAMD_NO_CELLS", 0);
+  o->program = !env_int("CHOLAMD_NO_PROGRAM", 0);
+  o->follow = !env_int("CHOLAMD_NO_FOLLOW", 0);
 }
 static int split_nb(const chol_sched_opts *o) { int v = o->split_nb; if (v > CHOL_RR_MAXN) v = CHOL_RR_MAXN; v = (v + 15) / 16 * 16; if (v < 16) v = 16; return v; }
 static int pivot_blocks(const chol_sched_opts *o, int n) { return n > o->split_min || n > CHOL_RR_MAXN ? (n + split_nb(o) - 1) / split_nb(o) : 1; }
@@ -122,7 +124,7 @@ static void push_trsm_run(builder *B, int64_t l_off, int64_t dinv_off, int64_t b
   for (int r0 = 0; r0 < m; r0 += CHOL_TRSM_ROWS) {
     if (w->n_trsm == B->cap_t) { B->cap_t = B->cap_t ? 2 * B->cap_t : 64; w->trsm = realloc(w->trsm, B->cap_t * sizeof(chol_trsm_desc)); }
     const int mm = m - r0 < CHOL_TRSM_ROWS ? m - r0 : CHOL_TRSM_ROWS;
-    chol_trsm_desc td = { l_off, dinv_off, b_off + r0, n, ld, mm, ld, flag, 0 };
+    chol_trsm_desc td = { l_off, dinv_off, b_off + r0, n, ld, mm, ld, flag, -1 };
     w->trsm[w->n_trsm++] = td;
   }
 }
@@ -133,7 +135,7 @@ static void pad_trsm_group(builder *B, int phase_first, int group, int64_t l_off
   chol_level_work *w = B->w;
   while ((w->n_trsm - phase_first) % group != 0) {
     if (w->n_trsm == B->cap_t) { B->cap_t = B->cap_t ? 2 * B->cap_t : 64; w->trsm = realloc(w->trsm, B->cap_t * sizeof(chol_trsm_desc)); }
-    chol_trsm_desc td = { l_off, dinv_off, b_off, n, ld, 0, ld, flag, 0 };
+    chol_trsm_desc td = { l_off, dinv_off, b_off, n, ld, 0, ld, flag, -1 };
     w->trsm[w->n_trsm++] = td;
   }
 }
@@ -146,7 +148,7 @@ static int push_src(builder *B, chol_upd_src sd)
 }
 /* tasks of one m x n target whose sources are [src_begin, src_end): 16x16 sub-tiles for small targets
  * (k_update: the four waves split K), 64x64 macro tiles otherwise (k_update_mt: LDS-staged panels) */
-static void emit_tasks(builder *B, int macro, int64_t c_off, int ldc, int m, int n, int syrk, int src_begin, int src_end)
+static void emit_tasks(builder *B, int macro, int64_t c_off, int ldc, int m, int n, int syrk, int src_begin, int src_end, int blk)
 {
   chol_level_work *w = B->w;
   const int ts = macro ? 64 : 16;
@@ -170,6 +172,7 @@ static void emit_tasks(builder *B, int macro, int64_t c_off, int ldc, int m, int
       t->lower = (syrk && a == b);
       t->src_begin = src_begin; t->src_end = src_end;
       t->ar = a * ts; t->br = b * ts;
+      t->blk = blk;
     }
 }
 
@@ -177,7 +180,7 @@ static void emit_tasks(builder *B, int macro, int64_t c_off, int ldc, int m, int
 static void push_tasks(builder *B, int64_t c_off, int ldc, int m, int n, int syrk, int src_begin, int src_end)
 {
   if (B->n_pend == B->cap_pend) { B->cap_pend = B->cap_pend ? 2 * B->cap_pend : 256; B->pend = realloc(B->pend, B->cap_pend * sizeof(upd_target)); }
-  upd_target t = { c_off, ldc, m, n, syrk, src_begin, src_end };
+  upd_target t = { c_off, ldc, m, n, syrk, src_begin, src_end, B->cur_blk };
   B->pend[B->n_pend++] = t;
 }
 static void flush_targets(builder *B)
@@ -187,10 +190,10 @@ static void flush_targets(builder *B)
     const int64_t tr = (B->pend[i].m + 15) / 16, tc = (B->pend[i].n + 15) / 16;
     fine += B->pend[i].syrk ? tr * (tr + 1) / 2 : tr * tc;
   }
-  const int big = fine >= B->o->mt_min_tiles;
+  const int big = fine >= B->o->mt_min_tiles && !B->force_fine;
   for (int i = 0; i < B->n_pend; i++) {
     const upd_target *t = &B->pend[i];
-    emit_tasks(B, big && (t->m > 16 || t->n > 16), t->c_off, t->ldc, t->m, t->n, t->syrk, t->src_begin, t->src_end);
+    emit_tasks(B, big && (t->m > 16 || t->n > 16), t->c_off, t->ldc, t->m, t->n, t->syrk, t->src_begin, t->src_end, t->blk);
   }
   B->n_pend = 0;
 }
@@ -221,6 +224,9 @@ static int emit_cell_tasks(builder *B, const plan_t *p, const upd_tuple *tu, int
     for (int I = u->crow / 16; I <= (u->crow + u->m - 1) / 16; I++)
       for (int J = u->ccol / 16; J <= (u->ccol + u->n - 1) / 16; J++) {
         if (diag && J > I) continue;
+        /* program launch with followers: the leading lim x lim part of a parent's diagonal block receives its children's
+         * contributions inside the parent's POTRF job (follow_external), not from update tasks */
+        if (B->follow_lim && B->follow_lim[u->bc] > 0 && 16 * I < B->follow_lim[u->bc] && 16 * J < B->follow_lim[u->bc]) continue;
         if (np == cap) { cap *= 2; pc = realloc(pc, (size_t)cap * sizeof(cell_piece)); }
         cell_piece *q = &pc[np++];
         const int r0 = (u->crow > 16 * I ? u->crow : 16 * I) - 16 * I, r1 = (u->crow + u->m < 16 * I + 16 ? u->crow + u->m : 16 * I + 16) - 16 * I;
@@ -268,6 +274,7 @@ static int emit_cell_tasks(builder *B, const plan_t *p, const upd_tuple *tu, int
     t->mv = (short)pc[i].mv; t->nv = (short)pc[i].nv;
     t->lower = pc[i].lower;
     t->src_begin = sb; t->src_end = w->n_src;
+    t->blk = (int)(pc[i].key >> 40);
     ntask++;
     i = e;
   }
@@ -358,7 +365,7 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
       const int nb = n - c0 < bw ? n - c0 : bw;
       const int64_t diag = p->panel_off[s] + c0 + (int64_t)c0 * ld;          /* element (c0, c0) of the pivot */
       const int64_t dinv = p->dinv_off[s] + (int64_t)(c0 / CHOL_NB) * CHOL_NB * CHOL_NB;
-      chol_potrf_desc pd = { diag, dinv, nb, ld, s, c0 };
+      chol_potrf_desc pd = { diag, dinv, nb, ld, s, c0, 0, 0 };
       push_potrf(B, pd);
       const int64_t colbase = (int64_t)c0 * ld;                              /* column c0 of the panel */
       const int below = n - c0 - nb;                                         /* pivot rows under the diagonal block */
@@ -463,6 +470,610 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
     push_phase(B, 3, km0, w->n_task_mt - km0);
   }
   free(tu); free(first); free(count); free(hs); free(B->pend); B->pend = NULL; B->cap_pend = 0;
+  return 0;
+}
+
+
+/* ---------------------------------------------------------------------------------------- */
+/* The whole factorisation as ONE program launch (single GPU, small problems): k_program.     */
+/*                                                                                            */
+/* Same work as the per-level lists -- the same pivot blocks, strips and, per output element, */
+/* the same sources in the same order -- as a queue of jobs for resident workgroups, with the  */
+/* kernel boundaries replaced by counters:                                                     */
+/*   prog[pb]     columns a pivot block's POTRF job has published (its strips follow it)       */
+/*   strips[pb]   TRSM jobs of the pivot block that have finished                              */
+/*   upd[s]       update jobs into panel s that have finished; updd[s]: into its diagonal block */
+/*   chan + e     strips of a follow channel that have stored column tile e                    */
+/* Queue order per tree level (bottom-up) and column-block step: POTRF jobs, TRSM jobs (the     */
+/* strips a follower waits for first), the POTRF job of the pivot's NEXT column block (it       */
+/* follows the strips of the rows it owns), the trailing-update jobs; after the last step the    */
+/* POTRF jobs of the PARENTS (they follow their children's strips of the parent rows), then the  */
+/* extend-add jobs of the level.  A job waits for counters raised by jobs ahead of it in the     */
+/* queue, except a follower, which is queued ahead of some of the strips it follows; the host     */
+/* self-check (chol_program_check) simulates the queue with a bounded number of resident          */
+/* workgroups to show that this cannot dead-lock.                                                 */
+/* ---------------------------------------------------------------------------------------- */
+#define PROG_JOB_TASKS 12    /* light 16x16 update tasks per update job (one per wave) */
+#define PROG_HEAVY_STEPS 48   /* MFMA k-steps (of 4 columns) from which a task is split over four waves */
+#define PROG_MAX_TASKS 24000 /* beyond this the per-level launches (macro tiles) are the better schedule */
+typedef struct { int potrf, c_prog, c_strips, n_groups, c0, nb, emitted; int ch_below, ns_below; int ch_par, ns_par; int64_t par_off; } pblock;
+typedef struct { chol_program *pg; int cap_j, cap_w, cap_e, cap_c; } pbuild;
+static int new_ctr(pbuild *P, int total)
+{
+  chol_program *g = P->pg;
+  if (g->n_ctr == P->cap_c) { P->cap_c = P->cap_c ? 2 * P->cap_c : 256; g->ctr_total = realloc(g->ctr_total, P->cap_c * sizeof(int)); }
+  g->ctr_total[g->n_ctr] = total;
+  return g->n_ctr++;
+}
+static void add_wait(pbuild *P, int ctr, int value)
+{
+  chol_program *g = P->pg;
+  if (value <= 0) return;
+  if (g->n_wait == P->cap_w) { P->cap_w = P->cap_w ? 2 * P->cap_w : 1024; g->wait = realloc(g->wait, P->cap_w * sizeof(chol_wait)); }
+  chol_wait wt = { ctr, value };
+  g->wait[g->n_wait++] = wt;
+}
+static int add_ext(pbuild *P, chol_ext e)
+{
+  chol_program *g = P->pg;
+  if (g->n_ext == P->cap_e) { P->cap_e = P->cap_e ? 2 * P->cap_e : 64; g->ext = realloc(g->ext, P->cap_e * sizeof(chol_ext)); }
+  g->ext[g->n_ext] = e;
+  return g->n_ext++;
+}
+/* a job whose waits are the entries added since wait_first */
+static chol_job *add_job(pbuild *P, int kind, int first, int n, int wait_first)
+{
+  chol_program *g = P->pg;
+  if (g->n_job == P->cap_j) { P->cap_j = P->cap_j ? 2 * P->cap_j : 1024; g->job = realloc(g->job, P->cap_j * sizeof(chol_job)); }
+  chol_job j = { kind, first, n, wait_first, g->n_wait - wait_first, { -1, -1 }, 0, g->n_ext, 0, 0, 0 };
+  g->job[g->n_job] = j;
+  return &g->job[g->n_job++];
+}
+void chol_program_free(chol_program *g)
+{
+  free(g->job); free(g->wait); free(g->ext); free(g->ctr_total);
+  memset(g, 0, sizeof *g);
+}
+/* strips of the filled rows of block (anc, s) that lie in rows [lo, hi) of anc (relative to the block), for the column block
+ * at column c0: appended to the TRSM list with `chan`; returns the number of strips */
+static int push_block_rows(builder *B, const plan_t *p, int anc, int s, int lo, int hi, const cholamd_filled *snap, const int64_t *first, const int *count,
+                           int64_t diag, int64_t dinv, int nb, int ld, int64_t colbase, int flag, int chan)
+{
+  chol_level_work *w = B->w;
+  const int b = BIDX(p, anc, s);
+  const chol_block *Bk = &p->blk[b];
+  const int t_before = w->n_trsm;
+  int run_lo = -1, run_hi = -1; /* current merged run, rows relative to the block */
+  for (int q = 0; q <= count[b]; q++) {
+    int a0 = -1, a1 = -1;
+    if (q < count[b]) {
+      const cholamd_filled *f = &snap[first[b] + q];
+      a0 = f->lo_x - Bk->lo_x; a1 = f->hi_x - Bk->lo_x + 1;
+      if (a0 < lo) a0 = lo;
+      if (a1 > hi) a1 = hi;
+      if (a0 >= a1) continue;
+      if (run_hi == a0) { run_hi = a1; continue; }
+    }
+    if (run_lo >= 0) {
+      push_trsm_run(B, diag, dinv, Bk->off + run_lo + colbase, nb, ld, run_hi - run_lo, flag);
+    }
+    run_lo = a0; run_hi = a1;
+  }
+  for (int i = t_before; i < w->n_trsm; i++) w->trsm[i].chan = chan;
+  return w->n_trsm - t_before;
+}
+/* TRSM jobs over the strips [t0, n_trsm): groups of three, never mixing channels */
+static int emit_trsm_jobs(pbuild *P, builder *B, int t0, int c_upd, int need_upd, int c_strips)
+{
+  chol_level_work *w = B->w;
+  int njobs = 0;
+  for (int i = t0; i < w->n_trsm;) {
+    int e = i + 1;
+    while (e < w->n_trsm && e - i < 3 && w->trsm[e].chan == w->trsm[i].chan) e++;
+    const int wf = P->pg->n_wait;
+    add_wait(P, c_upd, need_upd);
+    chol_job *j = add_job(P, 1, i, e - i, wf);
+    j->sig[0] = c_strips; j->sig_add = 1;
+    njobs++;
+    i = e;
+  }
+  return njobs;
+}
+/* update jobs over the tasks [k0, n_task): consecutive tasks of one target block, at most PROG_JOB_TASKS each; every job waits
+ * for the strips of its source pivot blocks (src_ctr / src_need pairs) and for the update jobs of earlier phases into its panel */
+static void emit_update_jobs(pbuild *P, builder *B, const plan_t *p, int k0, const int *c_upd, const int *c_updd, const int *snap_upd, int *cnt_upd, int *cnt_updd,
+                             const int *src_ctr, const int *src_need, int n_src_ctr, const int *src_sep_of /* NULL: all sources apply */)
+{
+  chol_level_work *w = B->w;
+  (void)src_sep_of;
+  for (int i = k0; i < w->n_task;) {
+    /* a task is heavy when its sources add up to PROG_HEAVY_STEPS MFMA k-steps or more (one wave would take them one memory
+     * round trip after the other): heavy tasks go three to a job, four waves each; light ones twelve to a job, one wave each */
+#define TASK_STEPS(T_) ({ int st_ = 0; for (int q_ = w->task[T_].src_begin; q_ < w->task[T_].src_end; q_++) st_ += (w->src[q_].k + 3) / 4; st_; })
+    const int heavy = TASK_STEPS(i) >= PROG_HEAVY_STEPS;
+    const int lim = heavy ? 3 : PROG_JOB_TASKS;
+    int e = i + 1;
+    while (e < w->n_task && e - i < lim && w->task[e].blk == w->task[i].blk && (TASK_STEPS(e) >= PROG_HEAVY_STEPS) == heavy) e++;
+#undef TASK_STEPS
+    const chol_block *Bc = &p->blk[w->task[i].blk];
+    const int wf = P->pg->n_wait;
+    for (int q = 0; q < n_src_ctr; q++) add_wait(P, src_ctr[q], src_need[q]);
+    add_wait(P, c_upd[Bc->c], snap_upd[Bc->c]);
+    chol_job *j = add_job(P, 2, i, e - i, wf);
+    j->mode = heavy;
+    j->sig[0] = c_upd[Bc->c]; j->sig[1] = Bc->r == Bc->c ? c_updd[Bc->c] : -1; j->sig_add = 1;
+    cnt_upd[Bc->c]++;
+    if (Bc->r == Bc->c) cnt_updd[Bc->c]++;
+    i = e;
+  }
+}
+
+int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_work *w, chol_program *pg)
+{
+  memset(w, 0, sizeof *w);
+  memset(pg, 0, sizeof *pg);
+  w->level = -1;
+  chol_sched_opts dflt;
+  if (!opts) { chol_sched_opts_default(&dflt); opts = &dflt; }
+  builder Bd; memset(&Bd, 0, sizeof Bd); Bd.w = w; Bd.o = opts; Bd.force_fine = 1;
+  builder *B = &Bd;
+  pbuild Pd; memset(&Pd, 0, sizeof Pd); Pd.pg = pg;
+  pbuild *P = &Pd;
+  const int L = p->levels, ns = p->nsep;
+  int rc = 0;
+  /* eligibility: every pivot block fits both fused roles */
+  for (int s = 1; s <= ns && !rc; s++) {
+    const int bw = pivot_block_width(opts, p->sep_size[s]);
+    if (bw > CHOL_FUSE_MAXN || bw > CHOL_RR_MAXN) { chol_set_error("program launch: pivot block of %d columns (separator %d) exceeds %d", bw, s, CHOL_FUSE_MAXN); rc = CHOLAMD_ERR_ARG; }
+  }
+  { /* cheap early refusal of large problems: 16x16 tiles of the trailing updates of split pivots, and of every panel once per
+     * tree level below it (extend-add cells) */
+    double est = 0;
+    for (int s = 1; s <= ns; s++) {
+      const int n = p->sep_size[s], rows = p->panel_rows[s];
+      if (n <= 0) continue;
+      const int nbk = pivot_blocks(opts, n), bw = pivot_block_width(opts, n);
+      for (int st = 0; st + 1 < nbk; st++) est += (double)((rows - (st + 1) * bw) / 16 + 1) * ((n - (st + 1) * bw) / 16 + 1);
+      est += (double)(rows / 16 + 1) * (n / 16 + 1) * (L - 1 - p->level_of[s]);
+    }
+    if (est > 2.0 * PROG_MAX_TASKS) { chol_set_error("program launch: about %.0f update tasks", est); return CHOLAMD_ERR_ARG; }
+  }
+  if (rc) return rc;
+  const int follow = opts->follow && opts->cells;
+  pg->follow = follow;
+  int64_t *first = malloc(p->nblk * sizeof(int64_t));
+  int *count = malloc(p->nblk * sizeof(int));
+  /* per panel: counters and running counts of update jobs; per separator: its pivot blocks */
+  int *c_upd = malloc((ns + 1) * sizeof(int)), *c_updd = malloc((ns + 1) * sizeof(int));
+  int *cnt_upd = calloc(ns + 1, sizeof(int)), *cnt_updd = calloc(ns + 1, sizeof(int)), *snap_upd = calloc(ns + 1, sizeof(int));
+  int *nblk_of = calloc(ns + 1, sizeof(int));
+  pblock **pb = calloc(ns + 1, sizeof(pblock *));
+  int *follow_lim = calloc(p->nblk, sizeof(int));
+  for (int s = 1; s <= ns; s++) {
+    c_upd[s] = new_ctr(P, 0); c_updd[s] = new_ctr(P, 0);
+    const int n = p->sep_size[s];
+    const int nbk = n > 0 ? pivot_blocks(opts, n) : 0, bw = pivot_block_width(opts, n);
+    nblk_of[s] = nbk;
+    pb[s] = calloc(nbk > 0 ? nbk : 1, sizeof(pblock));
+    for (int st = 0; st < nbk; st++) {
+      pblock *b = &pb[s][st];
+      b->c0 = st * bw; b->nb = n - b->c0 < bw ? n - b->c0 : bw;
+      b->potrf = -1; b->ch_below = b->ch_par = -1;
+      b->c_prog = new_ctr(P, (b->nb + CHOL_NB - 1) / CHOL_NB);
+      b->c_strips = new_ctr(P, 0);
+    }
+  }
+  /* POTRF job of block st of separator s; exts were added just before (ext_first .. n_ext) */
+  #define EMIT_POTRF(s_, st_, ext_first_)                                                                        \
+    do {                                                                                                          \
+      pblock *b_ = &pb[s_][st_];                                                                                  \
+      const int ld_ = p->panel_ld[s_];                                                                            \
+      const int64_t diag_ = p->panel_off[s_] + b_->c0 + (int64_t)b_->c0 * ld_;                                    \
+      const int64_t dinv_ = p->dinv_off[s_] + (int64_t)(b_->c0 / CHOL_NB) * CHOL_NB * CHOL_NB;                    \
+      chol_potrf_desc pd_ = { diag_, dinv_, b_->nb, ld_, s_, b_->c0, b_->c_prog, 0 };                             \
+      push_potrf(B, pd_);                                                                                         \
+      b_->potrf = w->n_potrf - 1;                                                                                 \
+      const int wf_ = pg->n_wait;                                                                                 \
+      add_wait(P, c_updd[s_], cnt_updd[s_]);                                                                      \
+      chol_job *j_ = add_job(P, 0, b_->potrf, 1, wf_);                                                            \
+      j_->ext_first = (ext_first_); j_->n_ext = pg->n_ext - (ext_first_);                                         \
+      b_->emitted = 1;                                                                                            \
+    } while (0)
+
+  for (int level = L - 1; level >= 0 && !rc; level--) {
+    const int lbl = L - 1 - level;
+    index_snapshot(p, lbl, first, count);
+    const cholamd_filled *snap = p->snap[lbl];
+    const int h0 = 1 << level, h1 = (1 << (level + 1)) - 1;
+    int *hs = malloc((h1 - h0 + 1) * sizeof(int)), nh = 0, steps = 0;
+    for (int h = h0; h <= h1; h++) {
+      const int s = p->tree[h];
+      if (count[BIDX(p, s, s)] == 0 || p->sep_size[s] == 0) continue;
+      hs[nh++] = h;
+      if (nblk_of[s] > steps) steps = nblk_of[s];
+    }
+    for (int st = 0; st < steps; st++) {
+      /* (A) POTRF jobs of this step that no follower placement has emitted yet */
+      for (int q = 0; q < nh; q++) {
+        const int s = p->tree[hs[q]];
+        if (st < nblk_of[s] && !pb[s][st].emitted) EMIT_POTRF(s, st, pg->n_ext);
+      }
+      /* (B) TRSM jobs: per pivot block the followed rows first (next column block of the pivot, rows of the parent's first
+       *     column block), then everything else */
+      for (int q = 0; q < nh; q++) {
+        const int h = hs[q], s = p->tree[h], n = p->sep_size[s], ld = p->panel_ld[s];
+        if (st >= nblk_of[s]) continue;
+        pblock *b = &pb[s][st];
+        const int c0 = b->c0, nb = b->nb;
+        const int64_t diag = p->panel_off[s] + c0 + (int64_t)c0 * ld;
+        const int64_t dinv = p->dinv_off[s] + (int64_t)(c0 / CHOL_NB) * CHOL_NB * CHOL_NB;
+        const int64_t colbase = (int64_t)c0 * ld;
+        const int below = n - c0 - nb;
+        const int t0 = w->n_trsm;
+        /* rows of the next column block of this pivot */
+        int nb1 = 0;
+        if (below > 0) {
+          nb1 = pb[s][st + 1].nb;
+          const int fol = follow && (nb1 + CHOL_NB - 1) / CHOL_NB <= CHOL_FOLLOW_MAXT;
+          if (fol) { b->ns_below = (nb1 + CHOL_TRSM_ROWS - 1) / CHOL_TRSM_ROWS; b->ch_below = new_ctr(P, b->ns_below); for (int e = 1; e < (nb + CHOL_NB - 1) / CHOL_NB; e++) new_ctr(P, b->ns_below); }
+          push_trsm_run(B, diag, dinv, p->panel_off[s] + (c0 + nb) + colbase, nb, ld, nb1, b->c_prog);
+          for (int i = w->n_trsm - (nb1 + CHOL_TRSM_ROWS - 1) / CHOL_TRSM_ROWS; i < w->n_trsm; i++) w->trsm[i].chan = fol ? b->ch_below : -1;
+        }
+        /* rows of the parent's first column block */
+        int par_lim = 0;
+        const int hp = h / 2;
+        if (hp >= 1 && follow) {
+          const int par = p->tree[hp];
+          if (nblk_of[par] > 0 && (pb[par][0].nb + CHOL_NB - 1) / CHOL_NB <= CHOL_FOLLOW_MAXT && count[BIDX(p, par, s)] > 0) {
+            par_lim = pb[par][0].nb;
+            const int tb = w->n_trsm;
+            const int nstr = push_block_rows(B, p, par, s, 0, par_lim, snap, first, count, diag, dinv, nb, ld, colbase, b->c_prog, -2);
+            if (nstr > 0) {
+              b->ns_par = nstr; b->ch_par = new_ctr(P, nstr);
+              for (int e = 1; e < (nb + CHOL_NB - 1) / CHOL_NB; e++) new_ctr(P, nstr);
+              for (int i = tb; i < w->n_trsm; i++) w->trsm[i].chan = b->ch_par;
+              b->par_off = p->blk[BIDX(p, par, s)].off + colbase; /* row 0 of the parent block in column c0 of the panel */
+            } else par_lim = 0;
+          }
+        }
+        /* the rest: remaining pivot rows, remaining parent rows, every other ancestor */
+        if (below - nb1 > 0) push_trsm_run(B, diag, dinv, p->panel_off[s] + (c0 + nb + nb1) + colbase, nb, ld, below - nb1, b->c_prog);
+        for (int ha = hp; ha >= 1; ha /= 2) {
+          const int anc = p->tree[ha];
+          if (BIDX(p, anc, s) < 0) continue;
+          push_block_rows(B, p, anc, s, ha == hp ? par_lim : 0, p->sep_size[anc], snap, first, count, diag, dinv, nb, ld, colbase, b->c_prog, -1);
+        }
+        b->n_groups = emit_trsm_jobs(P, B, t0, c_upd[s], cnt_upd[s], b->c_strips);
+        pg->ctr_total[b->c_strips] = b->n_groups;
+      }
+      /* (C) the next column block of a split pivot follows the strips of its own rows */
+      for (int q = 0; q < nh; q++) {
+        const int s = p->tree[hs[q]];
+        if (st + 1 >= nblk_of[s] || pb[s][st].ch_below < 0) continue;
+        const pblock *b = &pb[s][st];
+        const int ld = p->panel_ld[s];
+        const int ef = pg->n_ext;
+        chol_ext e = { p->panel_off[s] + (b->c0 + b->nb) + (int64_t)b->c0 * ld, ld, b->nb, b->ch_below, b->ns_below };
+        add_ext(P, e);
+        EMIT_POTRF(s, st + 1, ef);
+      }
+      /* (D) trailing update of the step: columns right of the block in the pivot rows below it (lower triangle) and in the
+       *     ancestor rows; the diagonal block of a following next column block is left out (follow_external does it) */
+      {
+        memcpy(snap_upd, cnt_upd, (ns + 1) * sizeof(int));
+        for (int q = 0; q < nh; q++) {
+          const int h = hs[q], s = p->tree[h], n = p->sep_size[s], ld = p->panel_ld[s];
+          if (st >= nblk_of[s]) continue;
+          const pblock *b = &pb[s][st];
+          const int c0 = b->c0, nb = b->nb, below = n - c0 - nb;
+          if (below <= 0) continue;
+          const int64_t colbase = (int64_t)c0 * ld;
+          const int64_t x_piv = p->panel_off[s] + (c0 + nb) + colbase; /* solved pivot rows below the block, k = nb */
+          const int k0 = w->n_task;
+          B->cur_blk = BIDX(p, s, s);
+          if (b->ch_below >= 0) {
+            const int nb1 = pb[s][st + 1].nb, r2 = below - nb1;
+            if (r2 > 0) {
+              const int64_t x2 = x_piv + nb1;
+              chol_upd_src s1 = { x2, x_piv, ld, ld, nb, 0 }, s2 = { x2, x2, ld, ld, nb, 0 };
+              const int i1 = push_src(B, s1);
+              push_tasks(B, p->panel_off[s] + (c0 + nb + nb1) + (int64_t)(c0 + nb) * ld, ld, r2, nb1, 0, i1, i1 + 1);
+              const int i2 = push_src(B, s2);
+              push_tasks(B, p->panel_off[s] + (c0 + nb + nb1) + (int64_t)(c0 + nb + nb1) * ld, ld, r2, r2, 1, i2, i2 + 1);
+            }
+          } else {
+            chol_upd_src sp = { x_piv, x_piv, ld, ld, nb, 0 };
+            const int sidx = push_src(B, sp);
+            push_tasks(B, p->panel_off[s] + (c0 + nb) + (int64_t)(c0 + nb) * ld, ld, below, below, 1, sidx, sidx + 1);
+          }
+          row_run *runs; const int nr = ancestor_runs(p, h, snap, first, count, &runs);
+          for (int r = 0; r < nr; r++) {
+            /* which ancestor block the run lies in (runs never span two blocks' targets differently: the target is panel s) */
+            chol_upd_src sa = { runs[r].off + colbase, x_piv, ld, ld, nb, 0 };
+            const int si = push_src(B, sa);
+            push_tasks(B, runs[r].off + (int64_t)(c0 + nb) * ld, ld, runs[r].m, below, 0, si, si + 1);
+          }
+          free(runs);
+          flush_targets(B);
+          /* all of these target panel s: blk = the diagonal block for the pivot rows; the ancestor rows are counted into the
+           * same panel counter, their `blk` only has to be constant within a job and must not claim the diagonal counter */
+          /* ancestor-row targets: give them the block of the first ancestor so that they do not raise updd[s] */
+          for (int i = k0; i < w->n_task; i++) {
+            const int64_t row_in_panel = (w->task[i].c_off - p->panel_off[s]) % ld;
+            if (row_in_panel >= n) { const int hpp = h / 2; w->task[i].blk = hpp >= 1 ? BIDX(p, p->tree[hpp], s) : w->task[i].blk; }
+          }
+          const int sc[1] = { b->c_strips }, sn[1] = { b->n_groups };
+          emit_update_jobs(P, B, p, k0, c_upd, c_updd, snap_upd, cnt_upd, cnt_updd, sc, sn, 1, NULL);
+        }
+      }
+    }
+    if (level == 0) { free(hs); break; }
+    /* (E) POTRF jobs of the parents' first column blocks: they follow their children's strips of the parent rows; children in
+     *     ascending pivot width (the one expected to finish last is consumed last), column blocks in order */
+    memset(follow_lim, 0, p->nblk * sizeof(int));
+    if (follow)
+      for (int hp = h0 / 2; hp <= h1 / 2; hp++) {
+        const int par = p->tree[hp];
+        if (nblk_of[par] == 0 || pb[par][0].emitted || count[BIDX(p, par, par)] == 0) continue;
+        int kids[2] = { p->tree[2 * hp], p->tree[2 * hp + 1] };
+        if (p->sep_size[kids[0]] > p->sep_size[kids[1]]) { const int t = kids[0]; kids[0] = kids[1]; kids[1] = t; }
+        const int ef = pg->n_ext;
+        int all = 1; /* follow only if every contributing child has its channel (then the cells are left out of the extend-add) */
+        for (int c = 0; c < 2; c++)
+          for (int st = 0; st < nblk_of[kids[c]]; st++)
+            if (count[BIDX(p, par, kids[c])] > 0 && pb[kids[c]][st].ch_par < 0) all = 0;
+        if (!all) continue;
+        for (int c = 0; c < 2; c++)
+          for (int st = 0; st < nblk_of[kids[c]]; st++) {
+            const pblock *b = &pb[kids[c]][st];
+            if (b->ch_par < 0) continue;
+            chol_ext e = { b->par_off, p->panel_ld[kids[c]], b->nb, b->ch_par, b->ns_par };
+            add_ext(P, e);
+          }
+        if (pg->n_ext == ef) continue;
+        follow_lim[BIDX(p, par, par)] = pb[par][0].nb;
+        EMIT_POTRF(par, 0, ef);
+      }
+    /* (F) extend-add of the level (tuples in program order, grouped by target), without the followed cells */
+    {
+      int cap_u = 256, ntu = 0;
+      upd_tuple *tu = malloc(cap_u * sizeof(upd_tuple));
+      int64_t seq = 0;
+      for (int q = 0; q < nh; q++) {
+        const int h = hs[q], s = p->tree[h], n = p->sep_size[s];
+        for (int hp = h / 2; hp >= 1; hp /= 2) {
+          const int par = p->tree[hp], bb = BIDX(p, par, s);
+          const chol_block *Bb = &p->blk[bb];
+          for (int hg = hp; hg >= 1; hg /= 2) {
+            const int gp = p->tree[hg], ba = BIDX(p, gp, s), bc = BIDX(p, gp, par);
+            const chol_block *Ba = &p->blk[ba], *Bc = &p->blk[bc];
+            for (int i = 0; i < count[ba]; i++) {
+              const cholamd_filled *fa = &snap[first[ba] + i];
+              for (int j = 0; j < count[bb]; j++) {
+                const cholamd_filled *fb_ = &snap[first[bb] + j];
+                if (gp == par && fb_->cluster > fa->cluster) continue; /* col > row skipped, blas.rg:396-431 */
+                if (ntu == cap_u) { cap_u *= 2; tu = realloc(tu, cap_u * sizeof(upd_tuple)); }
+                upd_tuple *u = &tu[ntu++];
+                const int crow = fa->lo_x - Bc->lo_x, ccol = fb_->lo_x - Bc->lo_y;
+                u->key = ((int64_t)bc << 40) | ((int64_t)crow << 20) | (int64_t)ccol;
+                u->seq = seq++;
+                u->c_off = Bc->off + crow + (int64_t)ccol * Bc->ld; u->ldc = Bc->ld;
+                u->a_off = Ba->off + (fa->lo_x - Ba->lo_x); u->lda = Ba->ld;
+                u->b_off = Bb->off + (fb_->lo_x - Bb->lo_x); u->ldb = Bb->ld;
+                u->m = fa->hi_x - fa->lo_x + 1; u->n = fb_->hi_x - fb_->lo_x + 1; u->k = n;
+                u->syrk = (gp == par && fb_->cluster == fa->cluster);
+                u->bc = bc; u->crow = crow; u->ccol = ccol;
+              }
+            }
+          }
+        }
+      }
+      qsort(tu, ntu, sizeof(upd_tuple), cmp_tuple);
+      const int k0 = w->n_task;
+      memcpy(snap_upd, cnt_upd, (ns + 1) * sizeof(int));
+      int any_follow = 0;
+      for (int b = 0; b < p->nblk; b++) any_follow |= follow_lim[b] > 0;
+      if (any_follow && !tuples_are_small(opts, tu, ntu)) { chol_set_error("program launch: followers need the grid-cell extend-add"); rc = CHOLAMD_ERR_ARG; }
+      if (!rc) {
+        if (tuples_are_small(opts, tu, ntu) || any_follow) { B->follow_lim = follow_lim; emit_cell_tasks(B, p, tu, ntu); B->follow_lim = NULL; }
+        else {
+          for (int i = 0; i < ntu;) {
+            int e = i + 1;
+            while (e < ntu && tu[e].key == tu[i].key) e++;
+            const int sb = w->n_src;
+            for (int q = i; q < e; q++) { chol_upd_src sd = { tu[q].a_off, tu[q].b_off, tu[q].lda, tu[q].ldb, tu[q].k, 0 }; push_src(B, sd); }
+            B->cur_blk = tu[i].bc;
+            push_tasks(B, tu[i].c_off, tu[i].ldc, tu[i].m, tu[i].n, tu[i].syrk, sb, w->n_src);
+            i = e;
+          }
+          flush_targets(B);
+        }
+        /* a job's sources are the separators of this level under its target's column separator: wait for all their strips.
+         * Jobs are queued by urgency: targets deepest in the tree first (their pivots are factored next), diagonal blocks
+         * before the rows below them; the order of the tasks in memory is irrelevant to the queue */
+        typedef struct { int i, e, prio; } blk_range;
+        int nrg = 0, caprg = 64;
+        blk_range *rg = malloc(caprg * sizeof(blk_range));
+        for (int i = k0; i < w->n_task;) {
+          int e = i + 1;
+          while (e < w->n_task && w->task[e].blk == w->task[i].blk) e++;
+          const chol_block *Bc = &p->blk[w->task[i].blk];
+          if (nrg == caprg) { caprg *= 2; rg = realloc(rg, caprg * sizeof(blk_range)); }
+          rg[nrg].i = i; rg[nrg].e = e;
+          rg[nrg].prio = (L - p->level_of[Bc->c]) * 4 * L + (Bc->r == Bc->c ? 0 : 1 + (p->level_of[Bc->c] - p->level_of[Bc->r])); /* ascending = more urgent first */
+          nrg++;
+          i = e;
+        }
+        for (int a = 1; a < nrg; a++) { /* stable insertion sort (a few dozen ranges) */
+          blk_range t = rg[a];
+          int b = a - 1;
+          while (b >= 0 && rg[b].prio > t.prio) { rg[b + 1] = rg[b]; b--; }
+          rg[b + 1] = t;
+        }
+        for (int q = 0; q < nrg; q++) {
+          const int i = rg[q].i, e = rg[q].e;
+          const chol_block *Bc = &p->blk[w->task[i].blk];
+          const int hpar = p->heap_of[Bc->c], dl = level - p->level_of[Bc->c];
+          int nsc = 0, capsc = 1;
+          for (int hh = hpar << dl; hh < ((hpar + 1) << dl); hh++) capsc += nblk_of[p->tree[hh]];
+          int *sc = malloc(capsc * sizeof(int)), *sn = malloc(capsc * sizeof(int));
+          for (int hh = hpar << dl; hh < ((hpar + 1) << dl); hh++) {
+            const int s = p->tree[hh];
+            for (int st = 0; st < nblk_of[s]; st++)
+              if (pb[s][st].n_groups > 0) { sc[nsc] = pb[s][st].c_strips; sn[nsc] = pb[s][st].n_groups; nsc++; }
+          }
+          /* emit_update_jobs walks [i, n_task): hand it exactly this block's tasks */
+          const int keep = w->n_task;
+          w->n_task = e;
+          emit_update_jobs(P, B, p, i, c_upd, c_updd, snap_upd, cnt_upd, cnt_updd, sc, sn, nsc, NULL);
+          w->n_task = keep;
+          free(sc); free(sn);
+        }
+        free(rg);
+      }
+      free(tu);
+    }
+    free(hs);
+    if (w->n_task > PROG_MAX_TASKS && !rc) { chol_set_error("program launch: more than %d update tasks", PROG_MAX_TASKS); rc = CHOLAMD_ERR_ARG; }
+  }
+  #undef EMIT_POTRF
+  if (!rc && w->n_task_mt > 0) { chol_set_error("program launch: macro-tile update phases"); rc = CHOLAMD_ERR_ARG; }
+  if (!rc && w->n_task > PROG_MAX_TASKS) { chol_set_error("program launch: %d update tasks", w->n_task); rc = CHOLAMD_ERR_ARG; }
+  for (int s = 1; s <= ns; s++) { pg->ctr_total[c_upd[s]] = cnt_upd[s]; pg->ctr_total[c_updd[s]] = cnt_updd[s]; }
+  for (int s = 1; s <= ns; s++) free(pb[s]);
+  free(pb); free(nblk_of); free(first); free(count); free(c_upd); free(c_updd); free(cnt_upd); free(cnt_updd); free(snap_upd); free(follow_lim);
+  free(B->pend);
+  if (rc) { chol_level_work_free(w); chol_program_free(pg); }
+  return rc;
+}
+
+
+/* Host-side self-check of the program (CPU tests): simulated with `workers` resident workgroups that take jobs in queue
+ * order and with every counter raised only when its job has COMPLETED (stricter than the device, where strips follow a
+ * POTRF column by column), every job must become runnable -- no dead-lock for any interleaving; counters total up; the
+ * pivot blocks and TRSM rows are those of the per-level lists. */
+typedef struct { int64_t a, b, c, d; } quad;
+static int cmp_quad(const void *x, const void *y) { return memcmp(x, y, sizeof(quad)); }
+int chol_program_check(const plan_t *p, const chol_sched_opts *opts, int workers)
+{
+  chol_level_work w;
+  chol_program g;
+  int rc = chol_build_program(p, opts, &w, &g);
+  if (rc) return rc;
+  int *val = calloc(g.n_ctr > 0 ? g.n_ctr : 1, sizeof(int));
+  char *state = calloc(g.n_job > 0 ? g.n_job : 1, 1); /* 0 queued, 1 running, 2 done */
+  int next = 0, running = 0, done = 0;
+  while (done < g.n_job && !rc) {
+    while (running < workers && next < g.n_job) { state[next++] = 1; running++; }
+    int progressed = 0;
+    for (int j = 0; j < next; j++) {
+      if (state[j] != 1) continue;
+      const chol_job *jb = &g.job[j];
+      int ok = 1;
+      for (int q = 0; q < jb->n_wait && ok; q++) {
+        const chol_wait *wt = &g.wait[jb->wait_first + q];
+        if (wt->ctr < 0 || wt->ctr >= g.n_ctr || wt->value > g.ctr_total[wt->ctr]) { chol_set_error("program job %d waits for %d on counter %d (total %d)", j, wt->value, wt->ctr, wt->ctr >= 0 && wt->ctr < g.n_ctr ? g.ctr_total[wt->ctr] : -1); rc = CHOLAMD_ERR_ARG; ok = 0; break; }
+        if (val[wt->ctr] < wt->value) ok = 0;
+      }
+      if (rc) break;
+      if (ok && jb->kind == 0)
+        for (int x = 0; x < jb->n_ext && ok; x++) {
+          const chol_ext *e = &g.ext[jb->ext_first + x];
+          for (int t = 0; t < (e->k + CHOL_NB - 1) / CHOL_NB; t++) if (val[e->chan + t] < e->nstrip) ok = 0;
+        }
+      if (ok && jb->kind == 1 && val[w.trsm[jb->first].flag] < g.ctr_total[w.trsm[jb->first].flag]) ok = 0; /* its pivot block is factored */
+      if (!ok) continue;
+      /* complete */
+      if (jb->kind == 0) val[w.potrf[jb->first].ctr] = g.ctr_total[w.potrf[jb->first].ctr];
+      if (jb->kind == 1)
+        for (int i = jb->first; i < jb->first + jb->n; i++)
+          if (w.trsm[i].chan >= 0 && w.trsm[i].m > 0)
+            for (int t = 0; t < (w.trsm[i].n + CHOL_NB - 1) / CHOL_NB; t++) val[w.trsm[i].chan + t]++;
+      for (int q = 0; q < 2; q++) if (jb->sig[q] >= 0) val[jb->sig[q]] += jb->sig_add;
+      state[j] = 2; running--; done++; progressed = 1;
+    }
+    if (!rc && !progressed && (running == workers || next == g.n_job)) {
+      int j = 0;
+      while (j < next && state[j] != 1) j++;
+      chol_set_error("program dead-locks with %d resident workgroups: job %d (kind %d) can never run; %d of %d jobs done", workers, j, j < g.n_job ? g.job[j].kind : -1, done, g.n_job);
+      rc = CHOLAMD_ERR_ARG;
+    }
+  }
+  for (int c = 0; c < g.n_ctr && !rc; c++)
+    if (val[c] != g.ctr_total[c]) { chol_set_error("program counter %d ends at %d, total %d", c, val[c], g.ctr_total[c]); rc = CHOLAMD_ERR_ARG; }
+  free(val); free(state);
+  if (!rc) { /* same pivot blocks and TRSM rows as the level lists */
+    quad *a = NULL, *b = NULL;
+    int64_t na = 0, nb = 0, ca = 0, cb = 0;
+#define PUSHQ(V_, N_, C_, A_, B_, C2_, D_) do { if (N_ == C_) { C_ = C_ ? 2 * C_ : 4096; V_ = realloc(V_, C_ * sizeof(quad)); } quad q_ = { A_, B_, C2_, D_ }; V_[N_++] = q_; } while (0)
+    for (int l = 0; l < p->levels && !rc; l++) {
+      chol_level_work lw;
+      rc = chol_build_level_work(p, opts, l, 0, 1, &lw);
+      if (rc) break;
+      for (int i = 0; i < lw.n_potrf; i++) PUSHQ(a, na, ca, -1, lw.potrf[i].a_off, lw.potrf[i].n, lw.potrf[i].col0);
+      for (int i = 0; i < lw.n_trsm; i++) for (int r = 0; r < lw.trsm[i].m; r++) PUSHQ(a, na, ca, -2, lw.trsm[i].b_off + r, lw.trsm[i].n, lw.trsm[i].l_off);
+      chol_level_work_free(&lw);
+    }
+    for (int i = 0; i < w.n_potrf; i++) PUSHQ(b, nb, cb, -1, w.potrf[i].a_off, w.potrf[i].n, w.potrf[i].col0);
+    for (int i = 0; i < w.n_trsm; i++) for (int r = 0; r < w.trsm[i].m; r++) PUSHQ(b, nb, cb, -2, w.trsm[i].b_off + r, w.trsm[i].n, w.trsm[i].l_off);
+#undef PUSHQ
+    if (!rc) {
+      qsort(a, na, sizeof(quad), cmp_quad);
+      qsort(b, nb, sizeof(quad), cmp_quad);
+      if (na != nb || (na > 0 && memcmp(a, b, na * sizeof(quad)))) { chol_set_error("program pivot blocks / TRSM rows differ from the level lists (%lld vs %lld items)", (long long)nb, (long long)na); rc = CHOLAMD_ERR_ARG; }
+    }
+    free(a); free(b);
+  }
+  chol_level_work_free(&w);
+  chol_program_free(&g);
+  return rc;
+}
+int cholamd_plan_program_check(const cholamd_plan *p, int follow, int workers)
+{
+  chol_sched_opts o;
+  chol_sched_opts_default(&o);
+  o.follow = follow;
+  return chol_program_check(p, &o, workers);
+}
+int64_t cholamd_plan_program_jobs(const cholamd_plan *p, int follow, int64_t cap, int *out)
+{ /* diagnostic: per job 8 ints: kind, separator (POTRF / TRSM: the pivot's label; update: target block's column label), target
+   * block's row label (update) or column offset of the pivot block, first, n, sig0, sig1, n_wait; then the wait list as
+   * (job, ctr, value) triples appended after the jobs: returns the total number of ints */
+  chol_sched_opts o;
+  chol_sched_opts_default(&o);
+  o.follow = follow;
+  chol_level_work w; chol_program g;
+  if (chol_build_program(p, &o, &w, &g)) return -1;
+  const int64_t need = (int64_t)8 * g.n_job + (int64_t)3 * g.n_wait + 1;
+  if (cap >= need) {
+    int64_t k = 0;
+    for (int j = 0; j < g.n_job; j++) {
+      const chol_job *jb = &g.job[j];
+      int a = 0, b = 0;
+      if (jb->kind == 0) { a = w.potrf[jb->first].sep; b = w.potrf[jb->first].col0; }
+      else if (jb->kind == 1) { for (int i = 0; i < w.n_potrf; i++) if (w.potrf[i].ctr == w.trsm[jb->first].flag) { a = w.potrf[i].sep; b = w.potrf[i].col0; } }
+      else { a = p->blk[w.task[jb->first].blk].c; b = p->blk[w.task[jb->first].blk].r; }
+      out[k++] = jb->kind; out[k++] = a; out[k++] = b; out[k++] = jb->first; out[k++] = jb->n; out[k++] = jb->sig[0]; out[k++] = jb->kind == 1 ? w.trsm[jb->first].chan : jb->sig[1]; out[k++] = jb->n_wait;
+    }
+    for (int j = 0; j < g.n_job; j++)
+      for (int q = 0; q < g.job[j].n_wait; q++) { out[k++] = j; out[k++] = g.wait[g.job[j].wait_first + q].ctr; out[k++] = g.wait[g.job[j].wait_first + q].value; }
+    out[k++] = g.n_job;
+  }
+  chol_level_work_free(&w); chol_program_free(&g);
+  return need;
+}
+int cholamd_plan_program_counts(const cholamd_plan *p, int follow, int out[6])
+{ /* jobs, POTRF jobs that follow, update tasks, TRSM strips, counters, followed panels */
+  chol_sched_opts o;
+  chol_sched_opts_default(&o);
+  o.follow = follow;
+  chol_level_work w; chol_program g;
+  int rc = chol_build_program(p, &o, &w, &g);
+  if (rc) return rc;
+  int nf = 0;
+  for (int j = 0; j < g.n_job; j++) nf += g.job[j].kind == 0 && g.job[j].n_ext > 0;
+  out[0] = g.n_job; out[1] = nf; out[2] = w.n_task; out[3] = w.n_trsm; out[4] = g.n_ctr; out[5] = g.n_ext;
+  chol_level_work_free(&w); chol_program_free(&g);
   return 0;
 }
 

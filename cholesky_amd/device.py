@@ -87,6 +87,14 @@ class Device:
         """Schedule / kernel-selection switch of this device object (cholamd_device_set_option)."""
         check(self.L.cholamd_device_set_option(self.h, name.encode(), int(value)), "cholamd_device_set_option")
 
+    def program_trace(self, arena, stream=None):
+        """Diagnostic: one program launch with per-job stamps -> int64 array [jobs, 5] = kind, drawn, waits over, ended (10 ns ticks), workgroup."""
+        n = C.c_int(0)
+        check(self.L.cholamd_device_program_trace(self.h, self.ptr(arena), _stream_ptr(stream), 0, None, C.byref(n)), "cholamd_device_program_trace")
+        out = np.zeros((n.value, 5), dtype=np.int64)
+        check(self.L.cholamd_device_program_trace(self.h, self.ptr(arena), _stream_ptr(stream), out.size, out.ctypes.data, C.byref(n)), "cholamd_device_program_trace")
+        return out
+
     def tail_offset(self):
         """First double of the shared top of the tree in the arena under the current partition."""
         return int(self.L.cholamd_device_tail_offset(self.h))

@@ -132,6 +132,23 @@ class Plan:
         check(self.L.cholamd_plan_level_work_counts(self.h, level, rank, world, out.ctypes.data), "cholamd_plan_level_work_counts")
         return tuple(int(v) for v in out)
 
+    def program_check(self, follow=True, workers=64):
+        """Host-side self-check of the one-launch program (raises CholamdError on a dead-lock or a mismatch)."""
+        check(self.L.cholamd_plan_program_check(self.h, int(follow), int(workers)), "cholamd_plan_program_check")
+
+    def program_counts(self, follow=True):
+        out = np.zeros(6, dtype=np.int32)
+        check(self.L.cholamd_plan_program_counts(self.h, int(follow), out.ctypes.data), "cholamd_plan_program_counts")
+        return dict(zip(("jobs", "followers", "tasks", "strips", "counters", "followed_panels"), (int(v) for v in out)))
+
+    def program_jobs(self, follow=True):
+        """Diagnostic: (jobs [n, 8] = kind, sep, aux, first, n, sig0, sig1, n_wait; waits [m, 3] = job, counter, value)."""
+        need = self.L.cholamd_plan_program_jobs(self.h, int(follow), 0, None)
+        buf = np.zeros(need, dtype=np.int32)
+        self.L.cholamd_plan_program_jobs(self.h, int(follow), need, buf.ctypes.data)
+        nj = int(buf[-1])
+        return buf[:8 * nj].reshape(nj, 8), buf[8 * nj:-1].reshape(-1, 3)
+
     def arena_to_dense(self, arena):
         arena = np.ascontiguousarray(arena, dtype=np.float64)
         assert arena.size == self.arena_doubles

@@ -175,6 +175,13 @@ int cholamd_plan_fill_host_part(const cholamd_plan *p, double *arena, int rank, 
 /* sizes of the device work lists of one tree level for (rank, world): potrf descriptors, trsm
  * strips, update tasks, update sources */
 int cholamd_plan_level_work_counts(const cholamd_plan *p, int level, int rank, int world, int out[4]);
+/* host-side self-check of the one-launch program cholamd_factor() runs for small problems on one GPU (chol_build_program):
+ * simulated with `workers` resident workgroups and every counter raised only on job completion, no job may starve; counters
+ * total up; pivot blocks and TRSM rows equal those of the per-level lists.  0 = consistent, otherwise cholamd_last_error()
+ * says what is wrong (also when the problem does not qualify for the program launch).  follow: with / without followers. */
+int cholamd_plan_program_check(const cholamd_plan *p, int follow, int workers);
+int cholamd_plan_program_counts(const cholamd_plan *p, int follow, int out[6]);
+int64_t cholamd_plan_program_jobs(const cholamd_plan *p, int follow, int64_t cap, int *out); /* diagnostic dump of the job queue (scripts/prog_trace.py) */ /* jobs, following POTRF jobs, update tasks, strips, counters, followed panels */
 /* dense N x N col-major image of an arena (zeros outside allocated blocks) and back */
 int cholamd_plan_arena_to_dense(const cholamd_plan *p, const double *arena, double *dense);
 /* write_matrix (mmat.rg:102-147): banner, "M N nnz", "row col %0.8g" per non-zero, block by
@@ -225,8 +232,10 @@ int cholamd_device_download(cholamd_device *d, double *h_dst, const double *d_sr
 int cholamd_device_sync(cholamd_device *d, void *stream);
 /* A scatter on the device (fill_block, mmat.rg:1216-1224): zero d_arena, scatter tril(A). */
 int cholamd_device_fill(cholamd_device *d, double *d_arena, void *stream);
-/* The hot path: the whole level loop of mmat.rg:1227-1355 on d_arena, asynchronously on stream.  Per tree level
- * and column-block step of its pivots: one fused POTRF+TRSM launch and the update launch(es).  level_lo/level_hi
+/* The hot path: the whole level loop of mmat.rg:1227-1355 on d_arena, asynchronously on stream.  Small problems (every
+ * pivot block <= 192 columns, no macro-tile phase: the reference's fixtures) run as ONE launch of resident workgroups that
+ * draw POTRF / TRSM / update jobs from a queue and hand data to each other through counters (option "program"); otherwise,
+ * per tree level and column-block step of its pivots: one fused POTRF+TRSM launch and the update launch(es).  level_lo/level_hi
  * restrict the loop to tree levels [level_lo, level_hi] (inclusive; pass 0, levels-1 for everything) -- used by
  * the multi-GPU driver to run subtree levels and top levels separately.
  * A device object carries one workspace (diagonal-block inverses, progress words of the fused launches, info):
@@ -238,6 +247,11 @@ int cholamd_factor_levels(cholamd_device *d, double *d_arena, int level_hi, int 
  * separators below the split level that are not in this rank's subtrees are skipped.  world == 1
  * restores the full schedule. */
 int cholamd_device_set_partition(cholamd_device *d, int rank, int world);
+/* diagnostic: one program launch with per-job clock stamps.  out (cap >= 5 * jobs int64) receives per job, in queue order:
+ * kind (0 POTRF, 10 POTRF that follows, 1 TRSM group, 2 update group), then the 100 MHz real-time clock (10 ns ticks since the
+ * first job was drawn) when the job was drawn, when its waits were over and when it ended, and the workgroup that ran it.
+ * *njobs_out = number of jobs (call with cap = 0 to size the buffer). */
+int cholamd_device_program_trace(cholamd_device *d, double *d_arena, void *stream, int64_t cap, int64_t *out, int *njobs_out);
 /* LAPACK-style info after the stream has been synchronised: 0 ok; k > 0 = leading minor k of the
  * pivot of separator *sep_out is not positive definite (the reference ignores this, blas.rg:71);
  * < 0 = the factorisation itself failed (CHOLAMD_ERR_STALL, or a HIP error code of this call) and
@@ -246,7 +260,9 @@ int cholamd_factor_info(cholamd_device *d, int *sep_out);
 /* Schedule / kernel-selection switches of this device object.  They default to the values the environment gave when
  * the object was created (CHOLAMD_SPLIT_MIN, CHOLAMD_SPLIT_NB, CHOLAMD_NO_FUSE, CHOLAMD_FUSE_UPDATE_MAX,
  * CHOLAMD_MT_MIN_TILES, CHOLAMD_NO_CELLS, CHOLAMD_SOLVE_REFERENCE_SHAPE: read once, there); names: "split_min",
- * "split_nb", "fuse", "fuse_update_max", "mt_min_tiles", "cells", "solve_reference_shape".  Rebuilds the work lists. */
+ * "split_nb", "fuse", "fuse_update_max", "mt_min_tiles", "cells", "solve_reference_shape", "program" (the whole factorisation
+ * of a small problem as one launch; CHOLAMD_NO_PROGRAM), "follow" (its pivot blocks follow their children's TRSM strips;
+ * CHOLAMD_NO_FOLLOW).  Rebuilds the work lists. */
 int cholamd_device_set_option(cholamd_device *d, const char *name, int value);
 /* Solve phase, mmat.rg:1364-1495: b and x in ORIGINAL dof order (device pointers, n doubles).
  * The off-diagonal blocks accumulate into the vector with hardware fp64 atomics, so x agrees from run to run to

@@ -33,6 +33,10 @@ mixed)  for c in gen:60:8 gen:100:10; do n=$(echo $c | tr ':' '_')
           run mixed_$n 600 python bench.py --case $c --precision mixed --steps 3 --warmup 1 > $out/bench_mixed_$n.json 2> $out/bench_mixed_$n.err; cat $out/bench_mixed_$n.json; tail -3 $out/bench_mixed_$n.err
         done ;;
 mixedtests) run mixedtests 900 python -m pytest tests/test_gpu_mixed.py -x -q > $out/pytest_mixed.log 2>&1; tail -15 $out/pytest_mixed.log ;;
+prog)   run prog 180 python scripts/prog_check.py > $out/prog_check.txt 2>&1; cat $out/prog_check.txt ;;
+proggen) run proggen 240 python scripts/prog_check.py gen:12,12,12,4,16 gen:20,20,20,5,64 gen:10,9,8,5,8 > $out/prog_gen.txt 2>&1; cat $out/prog_gen.txt ;;
+trace)  run trace 120 python scripts/prog_trace.py lapl_3375x3375 > $out/prog_trace.txt 2>&1; cat $out/prog_trace.txt
+        run trace0 120 python scripts/prog_trace.py lapl_3375x3375 follow=0 > $out/prog_trace_nofollow.txt 2>&1; cat $out/prog_trace_nofollow.txt ;;
 *) echo "unknown step $s" ;;
 esac; done
 echo "batch done"

@@ -210,11 +210,16 @@ def _ntiles_table(case):
 
 
 @pytest.mark.parametrize("opts", [
-    {"fuse": 0},                                       # separate POTRF / TRSM launches (k_potrf_rr, k_trsm_rr, k_trsm_w)
-    {"fuse_update_max": 100000},                       # update tasks inside the fused launch
-    {"split_min": 272, "split_nb": 256},               # pivots factored whole (k_potrf_rr up to 17 tiles)
-    {"split_min": 64, "split_nb": 64},                 # many column-block steps per pivot
-    {"cells": 0},                                      # extend-add by the reference's cluster tiles instead of grid cells
+    {"follow": 0},                                     # the one-launch program without followers (update jobs carry every contribution)
+    {"program": 0},                                    # level by level: fused POTRF+TRSM launches + update launches
+    {"program": 0, "fuse": 0},                         # separate POTRF / TRSM launches (k_potrf_rr, k_trsm_rr, k_trsm_w)
+    {"program": 0, "fuse_update_max": 100000},         # update tasks inside the fused launch
+    {"program": 0, "split_min": 272, "split_nb": 256}, # pivots factored whole (k_potrf_rr up to 17 tiles)
+    {"split_min": 64, "split_nb": 64},                 # many column-block steps per pivot (program: chains of followers)
+    {"program": 0, "split_min": 64, "split_nb": 64},
+    {"split_min": 192, "split_nb": 192},               # program with blocks too wide to follow (12 tiles): plain POTRF jobs
+    {"cells": 0},                                      # extend-add by the reference's cluster tiles instead of grid cells (no followers)
+    {"program": 0, "cells": 0},
     {"solve_reference_shape": 1},                      # the per-call (deterministic) solve kernels
 ], ids=lambda o: "+".join(f"{k}={v}" for k, v in o.items()))
 def test_alternative_launch_paths_keep_parity(opts, ca, golden):

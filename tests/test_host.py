@@ -229,3 +229,30 @@ def test_bench_gpus_flag_never_mislabels(tmp_path):
     assert r.returncode != 0 and "refusing to report a mislabelled run" in r.stderr and "{" not in r.stdout
     r = subprocess.run([sys.executable, bench, "--gpus", "3"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "power of two" in r.stderr
+
+
+@pytest.mark.parametrize("case", list(CASES))
+@pytest.mark.parametrize("follow", [1, 0])
+def test_program_launch_is_live_and_covers_the_level_lists(case, follow):
+    """cholamd_factor() runs small problems as ONE launch of resident workgroups drawing jobs from a queue (k_program).  Host-side
+    check of that program: with as few as 4 resident workgroups and every counter raised only when its job has completed (stricter
+    than the device), no job starves; counters total up; pivot blocks and TRSM rows are those of the per-level lists."""
+    import cholesky_amd as ca
+    m, o, c, _ = case_paths(case)
+    P = ca.Plan(m, o, c)
+    for workers in (256, 16, 4):
+        P.program_check(follow, workers)
+    cnt = P.program_counts(follow)
+    assert cnt["jobs"] > 0 and (cnt["followers"] > 0) == bool(follow)
+
+
+def test_program_launch_on_generated_problems():
+    import cholesky_amd as ca
+    for dims in [(7, 5, 3, 3, 4), (12, 12, 12, 4, 16), (10, 9, 8, 5, 8)]:
+        P = ca.Problem(*dims).plan()
+        P.program_check(1, 32)
+        P.program_check(0, 32)
+    # a pivot block wider than the fused roles take does not qualify: the level-by-level launches serve it
+    big = ca.Problem(24, 24, 12, 2, 64).plan()
+    with pytest.raises(ca.CholamdError):
+        big.program_check(1, 256)
