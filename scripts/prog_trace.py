@@ -88,3 +88,23 @@ for (sep, col0, ch), js in sorted(seen.items(), key=lambda kv: us[pot[kv[0][:2]]
         continue
     print(f"  sep {sep:2d} (level {heap_level[sep]}) col0 {col0:3d} chan {ch:4d}: POTRF start {us[pj, 1]:6.1f} end {us[pj, 2]:6.1f} | strips drawn {min(us[q, 0] for q in js):6.1f} "
           f"start {min(us[q, 1] for q in js):6.1f}..{max(us[q, 1] for q in js):6.1f} end {min(us[q, 2] for q in js):6.1f}..{max(us[q, 2] for q in js):6.1f}")
+
+# update jobs per target panel (column separator): spread of their starts and ends, by source phase order
+print("update jobs per target panel:")
+for sep in sorted(set(int(v) for v in jobs[jobs[:, 0] == 2, 1]), key=lambda s_: (heap_level[s_], s_), reverse=True):
+    js = [j for j in range(len(jobs)) if jobs[j, 0] == 2 and jobs[j, 1] == sep]
+    if heap_level[sep] == max(heap_level.values()):
+        continue
+    line = f"  panel {sep:2d} (level {heap_level[sep]}): {len(js):3d} jobs; "
+    # group by queue position clusters (phases): split where job indices jump by > 50
+    groups, cur = [], [js[0]]
+    for j in js[1:]:
+        if j - cur[-1] > 40:
+            groups.append(cur); cur = [j]
+        else:
+            cur.append(j)
+    groups.append(cur)
+    for gq in groups:
+        d = us[gq]
+        line += f"[jobs {gq[0]}-{gq[-1]} n={len(gq)} tasks={int(jobs[gq, 4].sum())} drawn {d[:, 0].min():.0f}-{d[:, 0].max():.0f} start {d[:, 1].min():.0f}-{d[:, 1].max():.0f} end {d[:, 2].min():.0f}-{d[:, 2].max():.0f}] "
+    print(line)
