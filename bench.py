@@ -56,11 +56,24 @@ def profile_numbers(kernel, case, mixed):
         return {}
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(files, flops, budget_s=12.0):
-    """The oracle (C restatement of the reference CPU path, OpenBLAS 1 thread when one is on the box,
-    exactly as the reference links it) timed on this host on a bounded sample."""
+    """The oracle (C restatement of the reference CPU path, OpenBLAS 1 thread per call when one is on the box, exactly as the
+    reference links it, mmat.rg:1057) timed on this host on a bounded sample: single thread (`value`), and the level loop with
+    the reference's task parallelism -- 3 workers (test_matrices.py:27, -ll:cpu 3) and one worker per host core."""
     from oracle import oracle as orc
     backend = "openblas" if orc.use_openblas() else "own-c-kernels"
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         O = orc.Oracle(*files)
         O.factor()  # warm-up
@@ -70,13 +83,25 @@ def cpu_baseline(files, flops, budget_s=12.0):
             t_acc += O.factor()
             n += 1
         name = orc.backend_name()
+        variants = {}
+        for label, workers in (("workers_3", 3), ("workers_all_cores", ncores)):
+            O.factor_parallel(workers)  # thread team start-up
+            ta, k = 0.0, 0
+            t_wall = time.perf_counter()
+            while time.perf_counter() - t_wall < budget_s / 3 and k < 2000:
+                ta += O.factor_parallel(workers)
+                k += 1
+            variants[label] = {"value": round(flops * k / ta * 1e-9, 3), "unit": "GF/s", "cores": workers, "ms": round(ta / k * 1e3, 3), "factorisations": k}
     finally:
         orc.use_own_kernels()
     return {
         "value": round(flops * n / t_acc * 1e-9, 3), "unit": "GF/s", "cores": 1, "kind": "port",
         "sample": f"{n} full numeric factorisations of the same workload (level loop only, {t_acc / n * 1e3:.2f} ms each), "
                   f"oracle/chol_oracle.c with {name}",
-        "backend": backend,
+        "backend": backend, "cpu": cpu_model(), "host_cores": ncores,
+        "task_parallel": variants,
+        "task_parallel_note": "the same level loop with OpenMP task parallelism inside a level as Legion extracts it (POTRF / TRSM tasks of a level independent, "
+                              "update tasks serialised per target block), BLAS one thread per call; bit-identical factors",
     }
 
 

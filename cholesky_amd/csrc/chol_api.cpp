@@ -911,6 +911,80 @@ extern "C" int cholamd_fused_dgemm(const cholamd_region *rA, const cholamd_regio
   return fused_update(rA, rB, rC, fa, nA, fb, nB, fc, nC, ccs, level, interval, debug, stream, false);
 }
 
+// ---- the reference's debug mode: the main loop of mmat.rg:1227-1355 literally, one fused task at a time, with write_blocks dumps
+static int debug_dump(cholamd_device *d, const double *d_arena, std::vector<double> &host, const char *dir, int level, const char *op,
+                      int ax, int ay, int bx, int by, int cx, int cy, int full)
+{
+  const cholamd_plan *p = d->plan;
+  HIPCHK(hipMemcpy(host.data(), d_arena, (size_t)p->arena * sizeof(double), hipMemcpyDeviceToHost));
+  char stem[1100], file[1200], header[200];
+  if (!std::strcmp(op, "POTRF")) { snprintf(stem, sizeof stem, "%s/potrf_lvl%d_a%d%d", dir, level, ax, ay); snprintf(header, sizeof header, "Level: %d POTRF A=(%d, %d)", level, ax, ay); }
+  else if (!std::strcmp(op, "TRSM")) { snprintf(stem, sizeof stem, "%s/trsm_lvl%d_a%d%d_b%d%d", dir, level, ax, ay, bx, by); snprintf(header, sizeof header, "Level: %d TRSM A=(%d, %d) B=(%d, %d)", level, ax, ay, bx, by); }
+  else { snprintf(stem, sizeof stem, "%s/gemm_lvl%d_a%d%d_b%d%d_c%d%d", dir, level, ax, ay, bx, by, cx, cy); snprintf(header, sizeof header, "Level: %d GEMM A=(%d, %d) B=(%d, %d) C=(%d, %d)", level, ax, ay, bx, by, cx, cy); }
+  snprintf(file, sizeof file, "%s.mtx", stem);
+  printf("filename: %s\n", file);
+  printf("saving matrix to: %s\n\n", file);
+  int rc = cholamd_plan_write_matrix(p, host.data(), file, full);
+  if (rc) return rc;
+  snprintf(file, sizeof file, "%s.txt", stem);
+  printf("filename: %s\n", file);
+  return cholamd_plan_write_blocks_txt(p, host.data(), file, header);
+}
+extern "C" int cholamd_factor_debug(cholamd_device *d, double *d_arena, const char *dir, int full_precision, void *stream)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  const cholamd_plan *p = d->plan;
+  const int L = p->levels, ns = p->nsep;
+  std::vector<double> host((size_t)p->arena);
+  auto region_of = [&](int r, int c) {
+    const chol_block *B = chol_plan_block(p, r, c);
+    cholamd_region rg = { d_arena + B->off, B->ld, B->lo_x, B->lo_y, B->hi_x, B->hi_y };
+    return rg;
+  };
+  for (int lvl = L - 1; lvl >= 0; lvl--) {
+    const int lbl = L - 1 - lvl;
+    // filled tiles of the level's snapshot, grouped by block (the snapshot is ordered by (row label, col label, cluster))
+    std::vector<std::vector<cholamd_filled>> fl((size_t)(ns + 1) * (ns + 1));
+    for (int64_t i = 0; i < p->snap_n[lbl]; i++) fl[(size_t)p->snap[lbl][i].sep_x * (ns + 1) + p->snap[lbl][i].sep_y].push_back(p->snap[lbl][i]);
+    auto F = [&](int r, int c) -> std::vector<cholamd_filled> & { return fl[(size_t)r * (ns + 1) + c]; };
+    const int h0 = 1 << lvl, h1 = (1 << (lvl + 1)) - 1;
+    for (int h = h0; h <= h1; h++) { // POTRF sweep, mmat.rg:1240-1257
+      const int s = p->tree[h];
+      cholamd_region rA = region_of(s, s);
+      int rc = cholamd_fused_dpotrf(&rA, F(s, s).data(), (int)F(s, s).size(), lvl, lbl, 1, stream);
+      if (rc < 0) return rc;
+      if (rc > 0) { int h2[2] = { rc, s }; HIPCHK(hipMemcpy(d->info, h2, sizeof h2, hipMemcpyHostToDevice)); }
+      if ((rc = debug_dump(d, d_arena, host, dir, lvl, "POTRF", s, s, 0, 0, 0, 0, full_precision))) return rc;
+    }
+    for (int h = h0; h <= h1; h++) { // TRSM sweep, mmat.rg:1259-1291
+      const int s = p->tree[h];
+      for (int hp = h / 2; hp >= 1; hp /= 2) {
+        const int par = p->tree[hp];
+        cholamd_region rA = region_of(s, s), rB = region_of(par, s);
+        int rc = cholamd_fused_dtrsm(&rA, &rB, F(s, s).data(), (int)F(s, s).size(), F(par, s).data(), (int)F(par, s).size(), lvl, lbl, 1, stream);
+        if (rc) return rc;
+        if ((rc = debug_dump(d, d_arena, host, dir, lvl, "TRSM", s, s, par, s, 0, 0, full_precision))) return rc;
+      }
+    }
+    for (int h = h0; h <= h1; h++) { // SYRK / GEMM sweep, mmat.rg:1293-1347
+      const int s = p->tree[h];
+      for (int hp = h / 2; hp >= 1; hp /= 2) {
+        const int par = p->tree[hp];
+        const int ccs = cholamd_plan_ntiles_at_level(p, par, lvl);
+        for (int hg = hp; hg >= 1; hg /= 2) {
+          const int gp = p->tree[hg];
+          cholamd_region rA = region_of(gp, s), rB = region_of(par, s), rC = region_of(gp, par);
+          int rc = (gp == par ? cholamd_fused_dsyrk : cholamd_fused_dgemm)(&rA, &rB, &rC, F(gp, s).data(), (int)F(gp, s).size(), F(par, s).data(), (int)F(par, s).size(),
+                                                                             F(gp, par).data(), (int)F(gp, par).size(), ccs, lvl, lbl, 1, stream);
+          if (rc) return rc;
+          if ((rc = debug_dump(d, d_arena, host, dir, lvl, "GEMM", gp, s, par, s, gp, par, full_precision))) return rc;
+        }
+      }
+    }
+  }
+  return 0;
+}
+
 // ---- L-A: device-pointer BLAS ----------------------------------------------------------------
 extern "C" int cholamd_dpotrf_dev(int n, double *d_a, int lda, int *d_info, void *stream)
 {

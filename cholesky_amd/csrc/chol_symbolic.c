@@ -663,6 +663,69 @@ static const cholamd_filled *find_tile(const cholamd_plan *p, int lbl, int sx, i
   return NULL;
 }
 
+/* What the reference's symbolic phase prints with -d, in its order: the Block lines of partition_matrix (mmat.rg:331,352),
+ * then per tree level (bottom-up) the Cluster lines of partition_separators (every tile of every block among the separators
+ * of tree levels <= that level at the interval in force, labelled with the interval label; mmat.rg:396,432,447) and the Fill
+ * lines of the level's snapshot (filled tiles only; mmat.rg:1010).  verify.debug_factor reads the Block and Cluster lines. */
+int cholamd_plan_write_debug_header(const cholamd_plan *p, FILE *f)
+{
+  for (int b = 0; b < p->nblk; b++) {
+    const chol_block *B = &p->blk[b];
+    fprintf(f, "Block: {'Block': (%d, %d), 'Lo': (%d, %d), 'Hi': (%d, %d)}\n", B->r, B->c, B->lo_x, B->lo_y, B->hi_x, B->hi_y);
+  }
+  const int L = p->levels;
+  for (int lvl = L - 1; lvl >= 0; lvl--) {
+    const int lbl = L - 1 - lvl, t = interval_of_level(p, lvl);
+    for (int b = 0; b < p->nblk; b++) { /* blocks are ordered by (row label, column label) */
+      const chol_block *B = &p->blk[b];
+      if (p->level_of[B->r] > lvl || p->level_of[B->c] > lvl) continue;
+      const int nr = chol_ntiles(p, B->r, t), nc = chol_ntiles(p, B->c, t);
+      if (nr < 0 || nc < 0) continue;
+      fprintf(f, "\t\tPartitioning (%d, %d) Cluster: %d Rows: %d Cols: %d\n", B->r, B->c, t, nr, nc);
+      const int *rs = p->cl[B->r].start[t], *cs = p->cl[B->c].start[t];
+      for (int i = 0; i < nr; i++) {
+        for (int j = 0; j < nc; j++) {
+          const int lox = B->lo_x + rs[i], hix = B->lo_x + rs[i + 1] - 1, loy = B->lo_y + cs[j], hiy = B->lo_y + cs[j + 1] - 1;
+          fprintf(f, "\t\tCluster: {'Block': (%d, %d), 'color': (%d, %d, %d), 'Lo': (%d, %d), 'Hi': (%d, %d), 'size': (%d, %d), 'vol': %d, 'Interval': %d}\n",
+                  B->r, B->c, B->r, B->c, i * nc + j, lox, loy, hix, hiy, hix - lox + 1, hiy - loy + 1, (hix - lox + 1) * (hiy - loy + 1), lbl);
+        }
+        fprintf(f, "\n");
+      }
+    }
+    const cholamd_filled *v = p->snap[lbl];
+    for (int64_t i = 0; i < p->snap_n[lbl]; i++)
+      fprintf(f, "Fill: {'Level': %d, 'Interval': %d, 'Block': (%d, %d), 'Cluster': (%d, %d, %d), 'Filled': %d, 'Lo': (%d, %d), 'Hi': (%d, %d), 'Size': (%d, %d)}\n",
+              lvl, lbl, v[i].sep_x, v[i].sep_y, v[i].sep_x, v[i].sep_y, v[i].cluster, v[i].filled, v[i].lo_x, v[i].lo_y, v[i].hi_x, v[i].hi_y,
+              v[i].hi_x - v[i].lo_x + 1, v[i].hi_y - v[i].lo_y + 1);
+  }
+  return 0;
+}
+/* write_blocks' second file (mmat.rg:174-218): a header line naming the task, then every allocated block as
+ * "Color: r c size: RxC bounds.lo: .. bounds.hi: .. vol: V" followed by its rows, values as "%0.2f, " (a blank in front of
+ * non-negative ones) */
+int cholamd_plan_write_blocks_txt(const cholamd_plan *p, const double *arena, const char *file, const char *header)
+{
+  FILE *fp = fopen(file, "w");
+  if (!fp) { chol_set_error("cannot write %s: %s", file, strerror(errno)); return CHOLAMD_ERR_IO; }
+  fprintf(fp, "%s\n", header);
+  for (int b = 0; b < p->nblk; b++) {
+    const chol_block *B = &p->blk[b];
+    if (B->rows * B->cols == 0) continue;
+    fprintf(fp, "Color: %d %d size: %dx%d bounds.lo: %d %d bounds.hi: %d %d vol: %d\n", B->r, B->c, B->rows, B->cols, B->lo_x, B->lo_y, B->hi_x, B->hi_y, B->rows * B->cols);
+    for (int i = 0; i < B->rows; i++) {
+      for (int j = 0; j < B->cols; j++) {
+        const double v = arena[B->off + i + (int64_t)j * B->ld];
+        fprintf(fp, v < 0 ? "%0.2f, " : " %0.2f, ", v);
+      }
+      fprintf(fp, "\n");
+    }
+  }
+  fclose(fp);
+  return 0;
+}
+/* the number of tiles of separator `sep` at the interval in force at tree level `level` (col_cluster_size of the fused tasks) */
+int cholamd_plan_ntiles_at_level(const cholamd_plan *p, int sep, int level) { return chol_ntiles(p, sep, interval_of_level(p, level)); }
+
 int cholamd_plan_write_debug_log(const cholamd_plan *p, FILE *f)
 {
   for (int b = 0; b < p->nblk; b++) {

@@ -71,13 +71,9 @@ int main(int argc, char **argv)
     printf("saving matrix to: %s\n\n", permuted_file);
     if (cholamd_plan_write_matrix(plan, h_arena, permuted_file, full)) DIE("%s", cholamd_last_error());
   }
-  if (debug) {
-    char path[1100];
-    snprintf(path, sizeof path, "%s/oplog.txt", debug_path);
-    FILE *f = fopen(path, "w");
-    if (!f) DIE("cannot write %s", path);
-    cholamd_plan_write_debug_log(plan, f);
-    fclose(f);
+  if (debug) { /* Block / Cluster / Fill lines of the symbolic phase on stdout, where verify.debug_factor's log comes from */
+    if (gpus > 1 || !strcmp(precision, "mixed")) DIE("-d (debug mode) is a single-GPU fp64 path");
+    cholamd_plan_write_debug_header(plan, stdout);
   }
 
   const int mixed = !strcmp(precision, "mixed");
@@ -107,6 +103,9 @@ int main(int argc, char **argv)
       if (lvl <= levels - 2) interval++;
     }
     double t1 = now_s();
+    if (debug) { /* one fused task at a time, op lines on stdout, write_blocks dumps in debug_path (mmat.rg:1255,1288,1342) */
+      if (cholamd_factor_debug(dev, d_arena, debug_path, full, NULL)) DIE("factor (debug): %s", cholamd_last_error());
+    } else
     if (mixed ? cholamd_factor_f32(dev, (float *)d_arena, NULL) : cholamd_factor_multi(devs, arenas, comms, gpus, NULL)) DIE("factor: %s", cholamd_last_error());
     for (int g = 0; g < gpus; g++) if (cholamd_device_sync(devs[g], NULL)) DIE("factor: %s", cholamd_last_error());
     t_factor = now_s() - t1;

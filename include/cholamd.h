@@ -189,8 +189,15 @@ int cholamd_plan_arena_to_dense(const cholamd_plan *p, const double *arena, doub
 int cholamd_plan_write_matrix(const cholamd_plan *p, const double *arena, const char *file, int full_precision);
 /* write_solution (mmat.rg:785-798): n lines "%0.8g" (or %.17g), original dof order, no header */
 int cholamd_write_solution(const char *file, const double *x, int n, int full_precision);
-/* the reference's -d structured log lines for one level of the schedule (blas.rg:308,340,405) */
+/* the reference's -d structured log lines: Block lines + the POTRF / TRSM / GEMM lines of the whole op list (blas.rg:308,340,405),
+ * from the symbolic phase alone (no device) */
 int cholamd_plan_write_debug_log(const cholamd_plan *p, FILE *f);
+/* what the reference's symbolic phase prints with -d: Block (mmat.rg:331), per level Cluster (mmat.rg:396,432) and Fill
+ * (mmat.rg:1010) lines; the op lines are printed by the fused tasks as they run (cholamd_factor_debug) */
+int cholamd_plan_write_debug_header(const cholamd_plan *p, FILE *f);
+/* write_blocks' text dump (mmat.rg:183-217): `header`, then every allocated block with its values as "%0.2f, " */
+int cholamd_plan_write_blocks_txt(const cholamd_plan *p, const double *arena, const char *file, const char *header);
+int cholamd_plan_ntiles_at_level(const cholamd_plan *p, int sep, int level);
 
 /* ----------------------------------------------------------------------------------------- */
 /* Problem generator (absent from the reference, whose orderings come from an      */
@@ -252,6 +259,13 @@ int cholamd_device_set_partition(cholamd_device *d, int rank, int world);
  * first job was drawn) when the job was drawn, when its waits were over and when it ended, and the workgroup that ran it.
  * *njobs_out = number of jobs (call with cap = 0 to size the buffer). */
 int cholamd_device_program_trace(cholamd_device *d, double *d_arena, void *stream, int64_t cap, int64_t *out, int *njobs_out);
+/* Debug mode of the reference (mmat.rg -d <dir>): the level loop of mmat.rg:1227-1355 LITERALLY -- one fused task
+ * at a time through the task-level entry points below, serialised -- printing the tasks' POTRF / TRSM / GEMM lines on stdout
+ * and, after every task, dumping the whole matrix as write_blocks does (mmat.rg:174-218): <dir>/<gen_filename>.mtx
+ * (write_matrix format) and .txt (block dump), with gen_filename's names (mmat.rg:149-172: potrf_lvlL_aXY,
+ * trsm_lvlL_aXY_bXY, gemm_lvlL_aXY_bXY_cXY, the block colours printed with %d%d as the reference does) and its
+ * "filename: ..." lines.  Slow by design; the factor it leaves in d_arena equals cholamd_factor's to rounding. */
+int cholamd_factor_debug(cholamd_device *d, double *d_arena, const char *dir, int full_precision, void *stream);
 /* LAPACK-style info after the stream has been synchronised: 0 ok; k > 0 = leading minor k of the
  * pivot of separator *sep_out is not positive definite (the reference ignores this, blas.rg:71);
  * < 0 = the factorisation itself failed (CHOLAMD_ERR_STALL, or a HIP error code of this call) and

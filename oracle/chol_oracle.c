@@ -248,6 +248,7 @@ typedef struct {
   /* op log of the last factorisation */
   OpRec *ops; int nops, cap_ops;
   int log_ops;
+  int quiet;   /* level-parallel runs: log_op keeps no statistics (shared counters) */
   double flops[4]; long calls[4];
   double level_flops[16][4]; long level_calls[16][4];
   int info;              /* first non-zero potrf info */
@@ -712,6 +713,7 @@ static void log_op(Orc *o, int op, int level, int m, int n, int k, const Filled 
     case 2: f = (double)n * (n + 1) * k; break;          /* SYRK n(n+1)k */
     case 3: f = 2.0 * m * n * k; break;                  /* GEMM 2mnk */
   }
+  if (o->quiet) return; /* level-parallel runs: no shared counters */
   o->flops[op] += f; o->calls[op]++;
   if (level < 16) { o->level_flops[level][op] += f; o->level_calls[level][op]++; }
   if (!o->log_ops) return;
@@ -838,6 +840,90 @@ static double now_s(void)
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+/* The same level loop with the task parallelism the reference runs with (`-ll:cpu N`, test_matrices.py:27: 3 workers; OpenBLAS
+ * one thread per call, mmat.rg:1057): inside a level the POTRF tasks of the separators are independent, so are the TRSM tasks,
+ * and the SYRK / GEMM tasks conflict only through their target block C = (gp, par) ("reads writes(rC)", blas.rg:364-367), where
+ * Legion serialises them in program order.  Restated with OpenMP: parallel loops over the separators for the first two sweeps
+ * and over the TARGET BLOCKS for the third, each block receiving its contributions in program order -- the same values as the
+ * sequential loop, bit for bit. */
+typedef struct { int sep, par, gp; } UpdTask;
+static void factor_levels_parallel(Orc *o, int workers)
+{
+  int interval = 0, interval_lbl = 0;
+  const int ns = o->nsep;
+  UpdTask *tk = malloc((size_t)(ns + 1) * 64 * sizeof(UpdTask));
+  int *order = malloc((size_t)(ns + 1) * 64 * sizeof(int));
+  for (int lvl = o->levels - 1; lvl >= 0; lvl--) {
+    const int lo = lvl_lo(lvl), hi = lvl_hi(lvl);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(workers)
+    for (int si = lo; si <= hi; si++) {
+      int sep = o->tree_node[si];
+      fused_dpotrf(o, &BLK(o, sep, sep), &SNAP(o, interval_lbl, sep, sep), lvl);
+    }
+    /* one TRSM task per (separator, ancestor): all independent */
+    int nt = 0;
+    for (int si = lo; si <= hi; si++) {
+      int pi = si;
+      for (int pl = lvl - 1; pl >= 0; pl--) { pi = pi / 2; tk[nt].sep = o->tree_node[si]; tk[nt].par = o->tree_node[pi]; tk[nt].gp = 0; nt++; }
+    }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(workers)
+    for (int t = 0; t < nt; t++)
+      fused_dtrsm(o, &BLK(o, tk[t].sep, tk[t].sep), &BLK(o, tk[t].par, tk[t].sep), &SNAP(o, interval_lbl, tk[t].sep, tk[t].sep),
+                  &SNAP(o, interval_lbl, tk[t].par, tk[t].sep), lvl);
+    /* update tasks in program order, then grouped by target block (stable): a group runs on one thread, in order */
+    nt = 0;
+    for (int si = lo; si <= hi; si++) {
+      int sep = o->tree_node[si], pi = si;
+      for (int pl = lvl - 1; pl >= 0; pl--) {
+        pi = pi / 2;
+        int par = o->tree_node[pi], gi = pi;
+        for (int gl = pl; gl >= 0; gl--) { tk[nt].sep = sep; tk[nt].par = par; tk[nt].gp = o->tree_node[gi]; nt++; gi = gi / 2; }
+      }
+    }
+    int ng = 0; /* order[] = task indices grouped by (gp, par); gstart via a second pass */
+    int *gstart = malloc((size_t)(nt + 1) * sizeof(int));
+    char *done = calloc((size_t)nt + 1, 1);
+    for (int t = 0; t < nt; t++) {
+      if (done[t]) continue;
+      gstart[ng++] = 0;
+      for (int u = t; u < nt; u++)
+        if (!done[u] && tk[u].gp == tk[t].gp && tk[u].par == tk[t].par) done[u] = 1;
+    }
+    /* fill order / gstart */
+    memset(done, 0, (size_t)nt + 1);
+    int pos = 0; ng = 0;
+    for (int t = 0; t < nt; t++) {
+      if (done[t]) continue;
+      gstart[ng++] = pos;
+      for (int u = t; u < nt; u++)
+        if (!done[u] && tk[u].gp == tk[t].gp && tk[u].par == tk[t].par) { done[u] = 1; order[pos++] = u; }
+    }
+    gstart[ng] = pos;
+    const int ccs_interval = interval;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(workers)
+    for (int g = 0; g < ng; g++)
+      for (int q = gstart[g]; q < gstart[g + 1]; q++) {
+        const UpdTask *u = &tk[order[q]];
+        fused_update(o, &BLK(o, u->gp, u->sep), &BLK(o, u->par, u->sep), &BLK(o, u->gp, u->par), &SNAP(o, interval_lbl, u->gp, u->sep),
+                     &SNAP(o, interval_lbl, u->par, u->sep), &SNAP(o, interval_lbl, u->gp, u->par), ntiles(o, u->par, ccs_interval), lvl, u->gp == u->par);
+      }
+    free(gstart); free(done);
+    interval_lbl++;
+    if (lvl <= o->levels - 2) interval++;
+  }
+  free(tk); free(order);
+}
+double orc_factor_parallel(Orc *o, int workers)
+{
+  o->log_ops = 0; o->nops = 0; o->info = 0; o->quiet = 1;
+  refill(o);
+  double t0 = now_s();
+  factor_levels_parallel(o, workers < 1 ? 1 : workers);
+  double dt = now_s() - t0;
+  o->quiet = 0;
+  return dt;
 }
 
 /* One reference "iteration" (mmat.rg:1212-1358): re-fill, then the level loop.  Returns the

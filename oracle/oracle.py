@@ -32,6 +32,8 @@ def lib():
     L.orc_free.argtypes = [C.c_void_p]
     L.orc_factor.restype = C.c_double
     L.orc_factor.argtypes = [C.c_void_p, C.c_int]
+    L.orc_factor_parallel.restype = C.c_double
+    L.orc_factor_parallel.argtypes = [C.c_void_p, C.c_int]
     L.orc_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_read_vector.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
     L.orc_use_openblas.argtypes = [C.c_char_p]
@@ -129,6 +131,11 @@ class Oracle:
         a = np.zeros(7 * n, dtype=np.int32)
         self.L.orc_snapshot(self.h, lbl, a.ctypes.data)
         return a.reshape(n, 7)
+
+    def factor_parallel(self, workers):
+        """The level loop with `workers` task-parallel threads (the reference's -ll:cpu N; BLAS one thread per call): the
+        same values as factor(), bit for bit.  Returns seconds in the level loop."""
+        return self.L.orc_factor_parallel(self.h, int(workers))
 
     def factor(self, log_ops=False):
         """One reference iteration (re-fill + level loop); returns seconds in the level loop."""

@@ -142,3 +142,14 @@ def test_mmio_reference_build_agrees():
         O = orc.Oracle(m, o, c)
         assert (O.N, O.NZ) == (N.value, NZ.value) and M.value == N.value
         assert tc.raw == b"MCRH"  # matrix coordinate real hermitian
+
+
+def test_level_parallel_oracle_is_bit_identical():
+    """The cpu_baseline's task-parallel variants (3 workers as the reference's tests run, all cores) compute the same factor, bit for bit."""
+    m, o, c, _ = case_paths("lapl_400x400")
+    O = orc.Oracle(m, o, c)
+    O.factor()
+    ref = O.dense().copy()
+    for workers in (1, 3, 8):
+        O.factor_parallel(workers)
+        assert np.array_equal(O.dense(), ref)
