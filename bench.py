@@ -42,13 +42,13 @@ PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = the fp32 vecto
 PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r2", "summary.json")  # scripts/profile_summary.py over the rocprofv3 passes of this command
 
 
-def profile_numbers(kernel, case, mixed):
+def profile_numbers(kernel, case, mixed, options=()):
     """Counter-derived numbers of `kernel` for this workload from the committed rocprofv3 passes (counters cannot be
     read live from inside the process): HBM bytes per launch, average launch duration, MFMA busy fraction."""
     try:
         with open(PROFILE_SUMMARY) as f:
             runs = json.load(f)["runs"]
-        key = case + (":mixed" if mixed else "")
+        key = case + (":mixed" if mixed else "") + ("".join(":" + o for o in sorted(options)) if options else "")
         k = runs[key]["kernels"][kernel]
         return {"hbm_bytes_per_launch": k.get("hbm_bytes_per_launch_corrected"), "avg_launch_us": k.get("avg_launch_us"),
                 "mfma_busy_frac": k.get("mfma_busy_frac"), "source": "profiles/r2/summary.json: " + runs[key].get("source", "")}
@@ -74,6 +74,12 @@ def cpu_baseline(files, flops, budget_s=12.0):
     from oracle import oracle as orc
     backend = "openblas" if orc.use_openblas() else "own-c-kernels"
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # the share of the host this job may use (cgroup quota), else the GPU box's documented share of 16 cores per GPU
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        share = max(1, int(int(quota) / int(period))) if quota != "max" else 16
+    except (OSError, ValueError):
+        share = 16
+    ncores = max(1, min(ncores, share))
     try:
         O = orc.Oracle(*files)
         O.factor()  # warm-up
@@ -127,6 +133,8 @@ def main():
                          "Laplacian with geometric nested dissection (e.g. gen:100:10, BASELINE config 5's matrix; no cpu_baseline)")
     ap.add_argument("--precision", default="fp64", choices=["fp64", "mixed"],
                     help="mixed = fp32 factor (the timed step) + fp64 iterative refinement of one solve (reported in config), BASELINE config 5")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="cholamd_device_set_option switch for this run (e.g. program=0: level-by-level launches), repeatable; recorded in config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.gpus < 1 or args.gpus & (args.gpus - 1):
@@ -168,6 +176,9 @@ def main():
         files = [os.path.join(g, f) for f in CASES[args.case]]
         plan = ca.Plan(*files)
     dev = ca.Device(plan, local_rank)
+    for kv in args.option:
+        k, v = kv.split("=")
+        dev.set_option(k, int(v))
     split = parallel.split_level(world)
     tail_off = parallel.tail_offset(plan, world)  # first panel of the shared top of the tree
     comm = None
@@ -309,7 +320,7 @@ def main():
             names = {"potrf": "k32_potrf", "trsm": "k32_trsm", "update": "k32_update_mt + k32_update"}
         else:
             names = {"potrf": "k_potrf_trsm" if fused else "k_potrf_rr", "trsm": "k_trsm_rr", "update": "k_update_mt + k_update" if generated else "k_update", "other": "k_program"}
-        prof = profile_numbers(names[dom].split(" + ")[0], args.case, mixed)
+        prof = profile_numbers(names[dom].split(" + ")[0], args.case, mixed, args.option)
         out = {
             "metric": "fp64 factorization GF/s (numeric level loop, F_ref flops) on 3-D Laplacian" if not mixed else
                       "fp32 factorization GF/s (numeric level loop, F_ref flops) on 3-D Laplacian; solution refined to fp64 accuracy",
@@ -321,7 +332,7 @@ def main():
                                     f"tests/{args.case} (reference fixture: 7-point Laplacian, nested-dissection ordering from the fixture files)"),
                        "n": plan.n, "levels": plan.levels, "separators": plan.nsep, "F_ref_flops": plan.flops,
                        "B_alg_bytes": plan.alg_bytes, "parallelism": f"subtree-sharded x{world}, one RCCL all-reduce of the arena tail (cholamd_factor_sharded)" if world > 1 else "single GPU",
-                       "precision": args.precision, "factor_info": list(info)},
+                       "precision": args.precision, "options": args.option, "factor_info": list(info)},
             "roofline": {"bound": "mfma", "kernel": names[dom], "achieved": None if achieved is None else round(achieved, 5),
                          "peak": peak, "unit": "TFLOP/s",
                          "frac": None if achieved is None else round(achieved / peak, 6),

@@ -8,11 +8,11 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 [ -z "$GRAFT_REPO_ROOT" ] && out=$(pwd)/gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-run() { # name, seconds, command...
+run() { # name, seconds, command...   (progress lines go to stderr: stdout may be redirected into a result file)
   local name=$1 secs=$2; shift 2
-  echo "== $name"; date +%T
+  echo "== $name $(date +%T)" >&2
   timeout -k 10 $secs "$@"; local rc=$?
-  echo "== $name rc=$rc"
+  echo "== $name rc=$rc" >&2
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping"; exit 1; fi
   return $rc
 }
@@ -37,6 +37,26 @@ prog)   run prog 180 python scripts/prog_check.py > $out/prog_check.txt 2>&1; ca
 proggen) run proggen 240 python scripts/prog_check.py gen:12,12,12,4,16 gen:20,20,20,5,64 gen:10,9,8,5,8 > $out/prog_gen.txt 2>&1; cat $out/prog_gen.txt ;;
 trace)  run trace 120 python scripts/prog_trace.py lapl_3375x3375 > $out/prog_trace.txt 2>&1; cat $out/prog_trace.txt
         run trace0 120 python scripts/prog_trace.py lapl_3375x3375 follow=0 > $out/prog_trace_nofollow.txt 2>&1; cat $out/prog_trace_nofollow.txt ;;
+profiles) # every rocprofv3 pass behind profiles/r2/summary.json: key | bench arguments | steps
+        SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU"
+        while IFS='|' read -r key bargs nsteps mops traffic; do
+          [ -z "$key" ] && continue
+          d=$out/$key; mkdir -p $d
+          (cd /tmp && run stats_$key 500 rocprofv3 --kernel-trace --stats --output-format csv -d $d/stats -o s -- python3 /root/repo/bench.py $bargs --steps $nsteps --warmup 2 --no-cpu-baseline > $d/bench_under_rocprof.json 2> $d/stats.err) || tail -3 $d/stats.err
+          (cd /tmp && run pmc_$key 500 rocprofv3 --kernel-trace --pmc $SQ $mops GRBM_GUI_ACTIVE --output-format csv -d $d/pmc_SQ -o p -- python3 /root/repo/bench.py $bargs --steps $nsteps --warmup 2 --no-cpu-baseline > $d/pmc_SQ.json 2> $d/pmc_SQ.err) || tail -3 $d/pmc_SQ.err
+          if [ "$traffic" = "1" ]; then for c in FETCH_SIZE WRITE_SIZE; do
+            (cd /tmp && run ${c}_$key 500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d/pmc_$c -o p -- python3 /root/repo/bench.py $bargs --steps $nsteps --warmup 2 --no-cpu-baseline > $d/pmc_$c.json 2> $d/pmc_$c.err) || tail -3 $d/pmc_$c.err
+          done; fi
+          rm -f $d/*/*_kernel_trace.csv $d/*/*agent_info.csv   # per-dispatch traces are large; the stats / counter CSVs are what is kept
+        done <<'LIST'
+lapl_3375|--case lapl_3375x3375|20|SQ_INSTS_VALU_MFMA_MOPS_F64|1
+lapl_3375_levels|--case lapl_3375x3375 --option program=0|20|SQ_INSTS_VALU_MFMA_MOPS_F64|1
+gen_40_6|--case gen:40:6|5|SQ_INSTS_VALU_MFMA_MOPS_F64|0
+gen_60_8|--case gen:60:8|3|SQ_INSTS_VALU_MFMA_MOPS_F64|1
+gen_60_8_mixed|--case gen:60:8 --precision mixed|3|SQ_INSTS_VALU_MFMA_MOPS_F32|0
+gen_100_10_mixed|--case gen:100:10 --precision mixed|2|SQ_INSTS_VALU_MFMA_MOPS_F32|0
+LIST
+        ;;
 *) echo "unknown step $s" ;;
 esac; done
 echo "batch done"

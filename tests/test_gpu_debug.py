@@ -62,6 +62,9 @@ def _replay(log, pmat, directory):
 
     last = None
     for d in ops:
+        # the dump of the last task of a (block, operation) run is compared BEFORE the next operation touches the matrix
+        if last is not None and (last["Block"] != d["Block"] or last["op"] != d["op"]):
+            check(last)
         if d["op"] == "POTRF":
             a = _region(d, "A")
             mat[a] = scipy.linalg.cholesky(mat[a], lower=True)
@@ -73,8 +76,6 @@ def _replay(log, pmat, directory):
             mat[c] = mat[c] - mat[a] @ mat[b].T
             if a == b:
                 mat[c] = np.tril(mat[c])
-        if last is not None and (last["Block"] != d["Block"] or last["op"] != d["op"]):
-            check(last)
         last = d
     check(last)
     return np.tril(mat), len(blocks), len(clusters), len(ops), checked
