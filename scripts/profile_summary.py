@@ -1,7 +1,7 @@
 """Build profiles/rN/summary.json -- every number bench.py's `roofline` object quotes from a profile -- out of the
 rocprofv3 passes of one gpu_batch.sh run (or several).
 
-    python scripts/profile_summary.py <out.json> <run-key>=<batch dir> [<run-key>=<batch dir> ...]
+    python scripts/profile_summary.py <out.json> '<run-key>|<batch dir>' ['<run-key>|<batch dir>' ...]
 
 run-key = the bench case (`lapl_3375x3375`, `gen:40:6`, `gen:100:10:mixed`, ...).  A batch dir holds (any subset of)
     stats*/   *_kernel_stats.csv                      rocprofv3 --kernel-trace --stats
@@ -10,7 +10,9 @@ run-key = the bench case (`lapl_3375x3375`, `gen:40:6`, `gen:100:10:mixed`, ...)
 Units and the gfx950 correction follow MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE / WRITE_SIZE are in KiB and
 FETCH_SIZE reports half of the bytes of wide coalesced reads, so hbm_bytes = (2 FETCH_SIZE + WRITE_SIZE) * 1024.
 MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs), the formula of rocprofiler-sdk's
-derived_counters.xml (gfx94x section: the guide notes ROCm 7.2 ships no gfx950 one), summed over the launches of the kernel;
+derived_counters.xml (gfx94x section: the guide notes ROCm 7.2 ships no gfx950 one), summed over the launches of the kernel,
+with GRBM_GUI_ACTIVE divided by 8: rocprofv3 reports it summed over the eight XCDs (checked against the executed flops of
+k_update_mt: 512 * MOPS / duration / 78.6 TF/s = 0.476 where the corrected busy fraction says 0.48);
 mfma_flops_per_launch = 512 * SQ_INSTS_VALU_MFMA_MOPS_F64 (the counter's unit) = flops EXECUTED on the matrix cores."""
 import csv
 import glob
@@ -25,6 +27,10 @@ def short(name):
 
 def counters(path):
     acc = {}
+    if path.endswith("_by_kernel.csv"):  # the per-kernel aggregates tracked under profiles/rN/ (Dispatches, Counter_Value_Sum)
+        for r in csv.DictReader(open(path)):
+            acc.setdefault(r["Kernel_Name"], {})[r["Counter_Name"]] = [int(r["Dispatches"]), float(r["Counter_Value_Sum"])]
+        return acc
     for r in csv.DictReader(open(path)):
         k = short(r["Kernel_Name"])
         c = acc.setdefault(k, {})
@@ -35,21 +41,24 @@ def counters(path):
 
 
 def one_run(d, suffix=""):
-    out = {"kernels": {}, "source": f"rocprofv3 passes under {os.path.basename(os.path.normpath(d))} (gpu_batch.sh)"}
+    out = {"kernels": {}, "source": f"{d}: kernel_stats.csv = rocprofv3 --kernel-trace --stats; pmc_*_by_kernel.csv = per-kernel sums of the rocprofv3 --pmc "
+                                    f"counter CSVs (one pass for the SQ/GRBM counters, FETCH_SIZE and WRITE_SIZE in passes of their own); the bench line "
+                                    f"printed under the profiler is bench_under_rocprof.json (scripts/gpu_batch.sh profiles)"}
     ks = out["kernels"]
-    for f in sorted(glob.glob(os.path.join(d, f"stats{suffix}", "*kernel_stats.csv"))):
+    for f in sorted(glob.glob(os.path.join(d, f"stats{suffix}", "*kernel_stats.csv")) + glob.glob(os.path.join(d, "kernel_stats.csv"))):
         for r in csv.DictReader(open(f)):
             k = ks.setdefault(short(r["Name"]), {})
             k["launches"] = int(r["Calls"])
             k["avg_launch_us"] = round(float(r["AverageNs"]) * 1e-3, 3)
             k["share_of_device_time_pct"] = float(r["Percentage"])
-    for f in sorted(glob.glob(os.path.join(d, f"pmc_SQ*{suffix}", "*counter_collection.csv"))):
+    for f in sorted(glob.glob(os.path.join(d, f"pmc_SQ*{suffix}", "*counter_collection.csv")) + glob.glob(os.path.join(d, "pmc_SQ*_by_kernel.csv"))):
         for kn, c in counters(f).items():
             k = ks.setdefault(kn, {})
             g = lambda n: c[n][1] if n in c else None  # noqa: E731
             gui, mfma = g("GRBM_GUI_ACTIVE"), g("SQ_VALU_MFMA_BUSY_CYCLES")
             if gui and mfma is not None:
-                k["mfma_busy_frac"] = round(mfma / (gui * 256 * 4), 5)
+                # rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (one GRBM each): the cycles of the launch are 1/8 of it
+                k["mfma_busy_frac"] = round(mfma / (gui / 8.0 * 256 * 4), 5)
             wave, wait, winst, act = g("SQ_WAVE_CYCLES"), g("SQ_WAIT_ANY"), g("SQ_WAIT_INST_ANY"), g("SQ_ACTIVE_INST_ANY")
             if wave:
                 k["wave_cycles_split"] = {"wait_any": round(wait / wave, 4) if wait is not None else None,
@@ -57,13 +66,13 @@ def one_run(d, suffix=""):
                                           "active_inst_any": round(act / wave, 4) if act is not None else None}
             if g("SQ_ACTIVE_INST_VALU") is not None and act:
                 k["valu_share_of_active"] = round(g("SQ_ACTIVE_INST_VALU") / act, 4)
-            mops = g("SQ_INSTS_VALU_MFMA_MOPS_F64")
-            if mops is not None:
-                n = c["SQ_INSTS_VALU_MFMA_MOPS_F64"][0]
-                k["mfma_flops_per_launch"] = round(512.0 * mops / n, 1)
+            for cn in c:
+                if cn.startswith("SQ_INSTS_VALU_MFMA_MOPS_"):
+                    k["mfma_flops_per_launch"] = round(512.0 * c[cn][1] / c[cn][0], 1)
+                    k["mfma_flops_counter"] = cn
             k["pmc_launches"] = max(v[0] for v in c.values())
-    fetch = glob.glob(os.path.join(d, f"pmc_FETCH_SIZE{suffix}", "*counter_collection.csv"))
-    write = glob.glob(os.path.join(d, f"pmc_WRITE_SIZE{suffix}", "*counter_collection.csv"))
+    fetch = glob.glob(os.path.join(d, f"pmc_FETCH_SIZE{suffix}", "*counter_collection.csv")) + glob.glob(os.path.join(d, "pmc_FETCH_SIZE_by_kernel.csv"))
+    write = glob.glob(os.path.join(d, f"pmc_WRITE_SIZE{suffix}", "*counter_collection.csv")) + glob.glob(os.path.join(d, "pmc_WRITE_SIZE_by_kernel.csv"))
     if fetch and write:
         fc, wc = counters(fetch[0]), counters(write[0])
         for kn in set(fc) & set(wc):
@@ -86,7 +95,7 @@ if __name__ == "__main__":
     if os.path.exists(dst):
         doc = json.load(open(dst))
     for spec in sys.argv[2:]:
-        key, d = spec.split("=", 1)
+        key, d = spec.split("|", 1) if "|" in spec else spec.split("=", 1)
         suffix = ""
         if "@" in d:
             d, suffix = d.split("@", 1)
