@@ -242,6 +242,7 @@ extern "C" int cholamd_device_set_option(cholamd_device *d, const char *name, in
   else if (n == "cells") d->opt.cells = value != 0;
   else if (n == "program") d->opt.program = value != 0;
   else if (n == "follow") d->opt.follow = value != 0;
+  else if (n == "super_blocks") d->opt.super_blocks = value;
   else if (n == "solve_reference_shape") { d->solve_reference_shape = value != 0; rebuild = false; }
   else { chol_set_error("unknown option '%s'", n.c_str()); return CHOLAMD_ERR_ARG; }
   return rebuild ? build_levels(d) : 0;

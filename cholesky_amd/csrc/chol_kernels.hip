@@ -239,13 +239,54 @@ __global__ __launch_bounds__(256) void k_update(double *__restrict__ base, const
 // 32x32 quadrants (4 accumulators each), so every staged operand feeds two MFMAs: 8x the arithmetic
 // intensity of k_update.  Same task / source lists, same program-order accumulation.
 // ------------------------------------------------------------------------------------------------
+// One LDS-DMA instruction (global_load_lds_dwordx4): lane l's 16 bytes at `g` land at lds + 16 l.  Written as asm so that the
+// compiler does not see a vector-memory operation: through the builtin it waits vmcnt(0) ahead of the next LDS read, which
+// serialises the ring; here the waits are the kernel's own counted s_waitcnt vmcnt(N) (cdna_hip_programming.md 5.7).  M0 (the LDS
+// base of the transfer) is saved and restored inside the statement.
+__device__ __forceinline__ void lds_dma16(const double *g, double *lds)
+{
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)lds);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
 #define MT 64
+#ifndef MKB
 #define MKB 16
+#endif
+#ifndef MT_STAGES
+#define MT_STAGES 2 /* measured (scripts/mt_bench.hip, 8192^2 SYRK, TF/s at K = 144 / 512): 16-deep chunks x 2 stages 38.2 / 49.0, x 3 34.3 / 46.2, x 4 27.3 / 40.5; 8-deep x 3 35.9 / 44.5, x 4 35.5 / 44.8, x 6 31.3 / 40.3: workgroups per CU (LDS) beat prefetch depth; register-staged double buffering (round 1) 35 / 44 */
+#endif
+/* MT_STAGES: LDS ring of the full-tile path: stages of one 16-deep chunk of both operands (16 KB each) */
+#define MT_SRC_BATCH 32 /* source descriptors held in LDS at a time */
+// one 16-deep chunk out of the LDS images sa / sb ([k][64 rows]) into the wave's 2x2 accumulators; the operands of k-step kk + 1 are
+// requested before the MFMAs of k-step kk are issued (the LDS round trip is off the MFMA chain)
+__device__ __forceinline__ void mt_chunk(d4 (&acc)[2][2], const double *sa, const double *sb, int g, int xo, int yo)
+{
+  double x0 = sa[g * MT + xo], x1 = sa[g * MT + xo + 16], y0 = sb[g * MT + yo], y1 = sb[g * MT + yo + 16];
+#pragma unroll
+  for (int kk = 0; kk < MKB / 4; ++kk) {
+    double nx0 = 0.0, nx1 = 0.0, ny0 = 0.0, ny1 = 0.0;
+    if (kk + 1 < MKB / 4) {
+      nx0 = sa[(4 * (kk + 1) + g) * MT + xo]; nx1 = sa[(4 * (kk + 1) + g) * MT + xo + 16];
+      ny0 = sb[(4 * (kk + 1) + g) * MT + yo]; ny1 = sb[(4 * (kk + 1) + g) * MT + yo + 16];
+    }
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, x0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, x0, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, x1, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, x1, acc[1][1], 0, 0, 0);
+    x0 = nx0; x1 = nx1; y0 = ny0; y1 = ny1;
+  }
+}
+// Full 64x64 tiles (the bulk of a large front) stage their operands by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
+// instruction = two k-columns of 64 rows, no registers) into a ring of MT_STAGES stages, MT_STAGES - 1 chunks in flight behind a
+// counted vmcnt: a chunk's memory round trip is hidden behind the MFMAs of the chunks before it, not behind one chunk's worth.
+// The chunk sequence runs across the sources of the task (the ring is not drained between sources).  Edge tiles and the last
+// partial chunk of a source (K not a multiple of 16) take the register-staged path (masked loads).
 __global__ __launch_bounds__(256) void k_update_mt(double *__restrict__ base, const chol_upd_task *__restrict__ tasks,
                                                    const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd)
 {
-  __shared__ double sA[2][MKB][MT];
-  __shared__ double sB[2][MKB][MT];
+  __shared__ double sA[MT_STAGES][MKB][MT];
+  __shared__ double sB[MT_STAGES][MKB][MT];
   const int tt = threadIdx.x, lane = tt & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tt >> 6);
   const int tid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -253,48 +294,88 @@ __global__ __launch_bounds__(256) void k_update_mt(double *__restrict__ base, co
   const chol_upd_task t = tasks[tid];
   const int r15 = lane & 15, g = lane >> 4;
   const int wr = wave & 1, wc = wave >> 1;
-  const int srow = tt & 63, skq = tt >> 6; // staging: this thread moves row `srow`, k = skq, skq+4, skq+8, skq+12
-  const bool sva = srow < t.mv, svb = srow < t.nv;
+  const int xo = 32 * wr + r15, yo = 32 * wc + r15;
   d4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (d4){ 0.0, 0.0, 0.0, 0.0 };
-  int buf = 0;
-  for (int s = t.src_begin; s < t.src_end; ++s) {
-    const chol_upd_src sd = srcs[s];
-    const double *A = base + sd.a_off + t.ar + srow;
-    const double *Bp = base + sd.b_off + t.br + srow;
-    const int K = sd.k;
-    double ra[4], rb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { // first chunk of this source
-      const int k = skq + 4 * i;
-      ra[i] = (sva && k < K) ? A[(int64_t)k * sd.lda] : 0.0;
-      rb[i] = (svb && k < K) ? Bp[(int64_t)k * sd.ldb] : 0.0;
+  const bool full = t.mv == MT && t.nv == MT;
+  if (full) {
+    // ---- LDS-DMA ring.  Chunk list = the full 16-deep chunks of every source, in order; (is, ik) = next chunk to issue.
+    // Wave w moves the k-pairs 2w, 2w+1 of both operands: lane l carries rows (2 (l & 31), +1) of k = k0 + 2 pair + (l >> 5).
+    // The source descriptors are copied to LDS in batches first: inside the ring nothing may be read through the vector-memory
+    // counter (a descriptor load and its vmcnt(0) would drain the ring every chunk).
+    __shared__ chol_upd_src sS[MT_SRC_BATCH];
+    const int lrow = 2 * (lane & 31), lk = lane >> 5;
+    for (int sb = t.src_begin; sb < t.src_end; sb += MT_SRC_BATCH) {
+      const int ns = min(MT_SRC_BATCH, t.src_end - sb);
+      __builtin_amdgcn_s_barrier(); // the previous batch is done with sS and with the ring
+      if (tt < ns) sS[tt] = srcs[sb + tt];
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      int total = 0;
+      for (int s = 0; s < ns; ++s) total += sS[s].k / MKB;
+      int is = 0, ik = 0, issued = 0; // issue cursor
+#define MT_ISSUE()                                                                                                    \
+      {                                                                                                               \
+        while (is < ns && ik + MKB > sS[is].k) { ++is; ik = 0; }                                                      \
+        const int64_t ao_ = sS[is].a_off, bo_ = sS[is].b_off;                                                         \
+        const int lda_ = sS[is].lda, ldb_ = sS[is].ldb;                                                               \
+        const int st_ = issued % MT_STAGES;                                                                           \
+        _Pragma("unroll") for (int pp = 0; pp < MKB / 8; ++pp) {                                                      \
+          const int pair = (MKB / 8) * wave + pp;                                                                     \
+          lds_dma16(base + ao_ + t.ar + lrow + (int64_t)(ik + 2 * pair + lk) * lda_, &sA[st_][2 * pair][0]);          \
+          lds_dma16(base + bo_ + t.br + lrow + (int64_t)(ik + 2 * pair + lk) * ldb_, &sB[st_][2 * pair][0]);          \
+        }                                                                                                             \
+        ++issued; ik += MKB;                                                                                          \
+      }
+      for (int i = 0; i < MT_STAGES - 1 && issued < total; ++i) MT_ISSUE();
+      for (int c = 0; c < total; ++c) {
+        // this wave's four DMA instructions of chunk c have landed when at most the later chunks' remain outstanding
+        if (issued - c - 1 >= MT_STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((MKB / 4) * (MT_STAGES - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier(); // every wave's part of chunk c is in LDS; every wave has left chunk c - 1
+        if (issued < total) MT_ISSUE(); // into the stage chunk c - 1 occupied
+        mt_chunk(acc, &sA[c % MT_STAGES][0][0], &sB[c % MT_STAGES][0][0], g, xo, yo);
+      }
+#undef MT_ISSUE
     }
-    for (int k0 = 0; k0 < K; k0 += MKB) {
+    __builtin_amdgcn_s_barrier(); // the tail path below re-uses stages 0 and 1
+  }
+  // ---- register-staged path: everything for edge tiles, the K tails (K mod 16 columns) of the sources for full tiles
+  {
+    const int srow = tt & 63, skq = tt >> 6; // this thread moves row `srow`, k = skq, skq+4, skq+8, skq+12
+    const bool sva = srow < t.mv, svb = srow < t.nv;
+    int buf = 0;
+    for (int s = t.src_begin; s < t.src_end; ++s) {
+      const chol_upd_src sd = srcs[s];
+      const int K = sd.k, kbeg = full ? (K / MKB) * MKB : 0;
+      if (kbeg >= K) continue;
+      const double *A = base + sd.a_off + t.ar + srow;
+      const double *Bp = base + sd.b_off + t.br + srow;
+      double ra[MKB / 4], rb[MKB / 4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { sA[buf][skq + 4 * i][srow] = ra[i]; sB[buf][skq + 4 * i][srow] = rb[i]; }
-      if (k0 + MKB < K) { // next chunk's loads fly during this chunk's MFMAs
+      for (int i = 0; i < MKB / 4; ++i) { // first chunk of this source
+        const int k = kbeg + skq + 4 * i;
+        ra[i] = (sva && k < K) ? A[(int64_t)k * sd.lda] : 0.0;
+        rb[i] = (svb && k < K) ? Bp[(int64_t)k * sd.ldb] : 0.0;
+      }
+      for (int k0 = kbeg; k0 < K; k0 += MKB) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int k = k0 + MKB + skq + 4 * i;
-          ra[i] = (sva && k < K) ? A[(int64_t)k * sd.lda] : 0.0;
-          rb[i] = (svb && k < K) ? Bp[(int64_t)k * sd.ldb] : 0.0;
+        for (int i = 0; i < MKB / 4; ++i) { sA[buf][skq + 4 * i][srow] = ra[i]; sB[buf][skq + 4 * i][srow] = rb[i]; }
+        if (k0 + MKB < K) { // next chunk's loads fly during this chunk's MFMAs
+#pragma unroll
+          for (int i = 0; i < MKB / 4; ++i) {
+            const int k = k0 + MKB + skq + 4 * i;
+            ra[i] = (sva && k < K) ? A[(int64_t)k * sd.lda] : 0.0;
+            rb[i] = (svb && k < K) ? Bp[(int64_t)k * sd.ldb] : 0.0;
+          }
         }
+        lds_barrier(); // chunk visible; the other buffer is free again (everyone is past its reads)
+        mt_chunk(acc, &sA[buf][0][0], &sB[buf][0][0], g, xo, yo);
+        buf ^= 1;
       }
-      lds_barrier(); // chunk visible; the other buffer is free again (everyone is past its reads)
-#pragma unroll
-      for (int kk = 0; kk < MKB / 4; ++kk) {
-        const double x0 = sA[buf][4 * kk + g][32 * wr + r15], x1 = sA[buf][4 * kk + g][32 * wr + 16 + r15];
-        const double y0 = sB[buf][4 * kk + g][32 * wc + r15], y1 = sB[buf][4 * kk + g][32 * wc + 16 + r15];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, x0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, x0, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, x1, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, x1, acc[1][1], 0, 0, 0);
-      }
-      buf ^= 1;
     }
   }
   // epilogue: all sixteen C values of the lane are requested before the first is used (clamped addresses, masked

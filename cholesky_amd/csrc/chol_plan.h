@@ -126,7 +126,10 @@ typedef struct {
   int cells;                /* extend-add of small phases by 16x16 grid cells of the target blocks */
   int program;              /* small problems: the whole factorisation as one launch (chol_build_program) */
   int follow;               /* ... in which pivot blocks follow their children's / predecessor's TRSM strips */
+  int super_blocks;         /* column blocks per super-block of a wide pivot: the trailing matrix beyond a super-block gets one update of
+                             * rank super_blocks * (block width) instead of one per block */
 } chol_sched_opts;
+#define CHOL_SUPER_BLOCKS 3
 void chol_sched_opts_default(chol_sched_opts *o);
 void chol_sched_opts_from_env(chol_sched_opts *o);
 

@@ -81,7 +81,7 @@ static int env_int(const char *name, int dflt) { const char *e = getenv(name); r
 void chol_sched_opts_default(chol_sched_opts *o)
 {
   o->split_min = CHOL_SPLIT_MIN; o->split_nb = CHOL_SPLIT_NB; o->fuse = 1; o->fuse_update_max = CHOL_FUSE_UPDATE_MAX;
-  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1; o->program = 1; o->follow = 1;
+  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS;
 }
 void chol_sched_opts_from_env(chol_sched_opts *o)
 {
@@ -94,6 +94,7 @@ void chol_sched_opts_from_env(chol_sched_opts *o)
   o->cells = !env_int("CHOLAMD_NO_CELLS", 0);
   o->program = !env_int("CHOLAMD_NO_PROGRAM", 0);
   o->follow = !env_int("CHOLAMD_NO_FOLLOW", 0);
+  o->super_blocks = env_int("CHOLAMD_SUPER_BLOCKS", o->super_blocks);
 }
 static int split_nb(const chol_sched_opts *o) { int v = o->split_nb; if (v > CHOL_RR_MAXN) v = CHOL_RR_MAXN; v = (v + 15) / 16 * 16; if (v < 16) v = 16; return v; }
 static int pivot_blocks(const chol_sched_opts *o, int n) { return n > o->split_min || n > CHOL_RR_MAXN ? (n + split_nb(o) - 1) / split_nb(o) : 1; }
@@ -375,15 +376,47 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
       for (int r = 0; r < nr; r++) push_trsm_run(B, diag, dinv, runs[r].off + colbase, nb, ld, runs[r].m, flag);
       if (fuse) pad_trsm_group(B, t0, 3, diag, dinv, diag, nb, ld, flag);
       else if (nb <= CHOL_TRSM_W_MAXN) pad_trsm_group(B, t0, 4, diag, dinv, diag, nb, ld, flag);
-      if (below > 0) { /* trailing columns [c0+nb, n): lower triangle of the pivot rows, everything of the ancestor rows */
-        const int64_t x_piv = p->panel_off[s] + (c0 + nb) + colbase;         /* X rows = solved pivot rows, k = nb */
-        chol_upd_src sp = { x_piv, x_piv, ld, ld, nb, 0 };
-        const int sidx = push_src(B, sp);
-        push_tasks(B, p->panel_off[s] + (c0 + nb) + (int64_t)(c0 + nb) * ld, ld, below, below, 1, sidx, sidx + 1);
-        for (int r = 0; r < nr; r++) {
-          chol_upd_src sa = { runs[r].off + colbase, x_piv, ld, ld, nb, 0 };
-          const int si = push_src(B, sa);
-          push_tasks(B, runs[r].off + (int64_t)(c0 + nb) * ld, ld, runs[r].m, below, 0, si, si + 1);
+      if (below > 0) {
+        /* Trailing update, in SUPER-BLOCKS of `super` column blocks: after a column block only the remaining columns of its
+         * own super-block receive its rank-nb update (they are factored next); the columns beyond wait for the end of the
+         * super-block and receive ONE update of rank (columns of the super-block) -- the same sums, but the bulk of the
+         * flops (the trailing matrix of a wide front) runs at K = super * nb instead of nb, where the macro-tile kernel is
+         * nearer its MFMA rate (35 TF/s at K = 144, 44 at K = 512, fp64).  Pivots of up to `super` blocks are unchanged. */
+        const int G = opts->super_blocks > 1 ? opts->super_blocks : 1;
+        const int sb0 = (st / G) * G;                                           /* first block of this super-block */
+        const int cs0 = sb0 * bw;                                               /* its first column */
+        const int cse = (sb0 + G) * bw < n ? (sb0 + G) * bw : n;                /* one past its last column */
+        const int last_in_sb = (st % G == G - 1) || c0 + nb >= n || c0 + nb >= cse;
+        /* (1) narrow: columns [c0+nb, cse) of the rows below, K = nb */
+        const int ncol = cse - (c0 + nb);
+        if (ncol > 0) {
+          const int64_t x_piv = p->panel_off[s] + (c0 + nb) + colbase;         /* solved pivot rows under the block, k = nb */
+          chol_upd_src sp = { x_piv, x_piv, ld, ld, nb, 0 };
+          const int sidx = push_src(B, sp);
+          push_tasks(B, p->panel_off[s] + (c0 + nb) + (int64_t)(c0 + nb) * ld, ld, ncol, ncol, 1, sidx, sidx + 1); /* rows inside the super-block: lower triangle */
+          if (below > ncol) { /* pivot rows beyond the super-block x its remaining columns */
+            chol_upd_src sq = { x_piv + ncol, x_piv, ld, ld, nb, 0 };
+            const int si = push_src(B, sq);
+            push_tasks(B, p->panel_off[s] + cse + (int64_t)(c0 + nb) * ld, ld, below - ncol, ncol, 0, si, si + 1);
+          }
+          for (int r = 0; r < nr; r++) {
+            chol_upd_src sa = { runs[r].off + colbase, x_piv, ld, ld, nb, 0 };
+            const int si = push_src(B, sa);
+            push_tasks(B, runs[r].off + (int64_t)(c0 + nb) * ld, ld, runs[r].m, ncol, 0, si, si + 1);
+          }
+        }
+        /* (2) wide, at the end of the super-block: columns [cse, n), K = cse - cs0 */
+        if (last_in_sb && cse < n) {
+          const int K = cse - cs0, rest = n - cse;
+          const int64_t x_sb = p->panel_off[s] + cse + (int64_t)cs0 * ld;      /* pivot rows beyond the super-block, its columns */
+          chol_upd_src sp = { x_sb, x_sb, ld, ld, K, 0 };
+          const int sidx = push_src(B, sp);
+          push_tasks(B, p->panel_off[s] + cse + (int64_t)cse * ld, ld, rest, rest, 1, sidx, sidx + 1);
+          for (int r = 0; r < nr; r++) {
+            chol_upd_src sa = { runs[r].off + (int64_t)cs0 * ld, x_sb, ld, ld, K, 0 };
+            const int si = push_src(B, sa);
+            push_tasks(B, runs[r].off + (int64_t)cse * ld, ld, runs[r].m, rest, 0, si, si + 1);
+          }
         }
       }
       free(runs);

@@ -57,6 +57,10 @@ gen_60_8_mixed|--case gen:60:8 --precision mixed|3|SQ_INSTS_VALU_MFMA_MOPS_F32|0
 gen_100_10_mixed|--case gen:100:10 --precision mixed|2|SQ_INSTS_VALU_MFMA_MOPS_F32|0
 LIST
         ;;
+super)  for sb in 1 2 3 4; do for c in gen:40:6 gen:60:8; do
+          run super_${sb}_$c 300 python bench.py --case $c --steps 3 --warmup 1 --option super_blocks=$sb 2> /dev/null | python3 -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('super_blocks=$sb', '$c', d['value'], 'GF/s', d['ms_per_step'], 'ms', d['roofline']['kernel_ms_per_step_events_raw'])"
+        done; done
+        for sb in 1 3; do run supermixed_$sb 400 python bench.py --case gen:100:10 --precision mixed --steps 2 --warmup 1 --option super_blocks=$sb 2> /dev/null | python3 -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('mixed super_blocks=$sb gen:100:10', d['value'], 'GF/s', d['ms_per_step'], 'ms', d['config']['refinement'])"; done ;;
 *) echo "unknown step $s" ;;
 esac; done
 echo "batch done"

@@ -75,3 +75,39 @@ def test_big_pivot_info_is_pivot_relative():
     dev.sync()
     info, sep = dev.info()
     assert sep == plan.nsep and info == col + 1
+
+
+@pytest.mark.parametrize("opts", [
+    {"split_min": 64, "split_nb": 64, "super_blocks": 2},   # root pivot 324 -> 6 column blocks, 3 super-blocks: narrow + wide trailing updates
+    {"split_min": 64, "split_nb": 64, "super_blocks": 4},
+    {"split_min": 64, "split_nb": 64, "super_blocks": 1},   # one update per column block (round 1's schedule)
+    {"split_min": 96, "split_nb": 96, "super_blocks": 3, "fuse": 0},
+], ids=lambda o: "+".join(f"{k}={v}" for k, v in o.items()))
+def test_super_block_trailing_updates_match_oracle(opts, tmp_path):
+    """Wide pivots are factored in column blocks; the trailing matrix beyond a SUPER-block of them gets one update of rank
+    (columns of the super-block) instead of one per block.  Same factor as the oracle for every grouping."""
+    import cholesky_amd as ca
+    orc.use_own_kernels()
+    prob = ca.Problem(18, 18, 18, 3, 48)
+    m, o, c, _ = prob.write(os.path.join(tmp_path, "gen"))
+    plan = prob.plan()
+    O = orc.Oracle(m, o, c)
+    O.factor()
+    dev = ca.Device(plan, 0)
+    for k, v in opts.items():
+        dev.set_option(k, v)
+    arena = dev.new_arena()
+    dev.fill(arena)
+    dev.factor(arena)
+    dev.sync()
+    assert dev.info() == (0, 0)
+    L = np.tril(plan.arena_to_dense(arena.cpu().numpy()))
+    Lo = np.tril(O.dense())
+    assert np.abs(L - Lo).max() <= 1e-11 * np.abs(Lo).max()
+    # the fp32 schedule (blocks of 128 columns) uses the same grouping
+    a32 = dev.new_arena_f32()
+    dev.fill_f32(a32)
+    dev.factor_f32(a32)
+    dev.sync()
+    L32 = np.tril(plan.arena_to_dense(a32.cpu().numpy().astype(np.float64)))
+    assert np.abs(L32 - Lo).max() <= 2e-5 * np.abs(Lo).max()
