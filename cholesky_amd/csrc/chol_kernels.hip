@@ -1557,6 +1557,16 @@ __global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ bas
     if (trace && tid == 0) { trace[4 * j] = __builtin_amdgcn_s_memrealtime(); trace[4 * j + 3] = blockIdx.x; }
     // ONE wave polls (hundreds of blocked workgroups are resident at a time: twelve polling waves each would sit on the L2 the
     // working jobs hand their data through); the others park at the barrier
+    // A job is usually drawn long before it may run: what does not depend on the wait is fetched ahead of it -- the first
+    // round's task descriptor and its source descriptors (immutable; scalar loads, kept warm in the scalar cache)
+    chol_upd_task tpre;
+    if (jb.kind == 2) {
+      const int tk = jb.first + min(jb.mode == 0 ? wave : grp, jb.n - 1);
+      tpre = tasks[tk];
+      int touch = 0;
+      for (int sx = tpre.src_begin; sx < tpre.src_end; ++sx) touch += srcs[sx].k;
+      asm volatile("" :: "s"(touch));
+    }
     if (jb.n_wait > 0) {
       if (wave == 0) wait_list(waits + jb.wait_first, jb.n_wait, ctr, ctr_total, epoch, lane, info);
       lds_barrier();
@@ -1576,7 +1586,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ bas
       if (jb.mode == 0) {
         for (int t0 = jb.first; t0 < jb.first + jb.n; t0 += RR_NW + 1) { // light tasks: one per wave
           const int tk = t0 + wave;
-          if (tk < jb.first + jb.n) update_task_wave<true>(base, tasks[tk], srcs, lane);
+          if (tk < jb.first + jb.n) update_task_wave<true>(base, t0 == jb.first ? tpre : tasks[tk], srcs, lane);
         }
       } else { // heavy tasks: three at a time, four waves each (K or the sources split, fixed-order LDS reduction)
         double (*sAcc)[3][3][4][64] = (double (*)[3][3][4][64])smem; // [parity of the round][group]
@@ -1584,7 +1594,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ bas
         for (int t0 = jb.first; t0 < jb.first + jb.n; t0 += 3, ++round) {
           const int tk = t0 + grp;
           const bool live = tk < jb.first + jb.n;
-          update_task_body<true>(base, tasks[live ? tk : t0], srcs, sAcc[round & 1][grp], wave & 3, lane, live, nullptr, 0, info);
+          update_task_body<true>(base, t0 == jb.first ? tpre : tasks[live ? tk : t0], srcs, sAcc[round & 1][grp], wave & 3, lane, live, nullptr, 0, info);
         }
       }
     }
