@@ -91,6 +91,7 @@ def load():
     L.cholamd_plan_arena_to_dense.argtypes = [vp, vp, vp]
     L.cholamd_plan_fill_host_part.argtypes = [vp, vp, ci, ci, C.POINTER(i64)]
     L.cholamd_plan_level_work_counts.argtypes = [vp, ci, ci, ci, vp]
+    L.cholamd_plan_level_work_volume.argtypes = [vp, ci, ci, ci, ci, vp]
     L.cholamd_plan_program_check.argtypes = [vp, ci, ci]
     L.cholamd_plan_program_counts.argtypes = [vp, ci, vp]
     L.cholamd_plan_program_jobs.argtypes = [vp, ci, i64, vp]
@@ -103,6 +104,9 @@ def load():
     L.cholamd_device_set_option.argtypes = [vp, C.c_char_p, ci]
     L.cholamd_comm_unique_id.argtypes = [vp]
     L.cholamd_comm_create.argtypes = [vp, ci, ci, vp, C.POINTER(vp)]
+    L.cholamd_comm_create_local.argtypes = [vp, ci, vp]
+    L.cholamd_factor_multi.argtypes = [vp, vp, vp, ci, vp]
+    L.cholamd_gather_factor.argtypes = [vp, vp, ci, vp]
     L.cholamd_comm_adopt.argtypes = [vp, ci, ci, C.POINTER(vp)]
     L.cholamd_comm_destroy.argtypes = [vp]
     L.cholamd_comm_destroy.restype = None

@@ -31,6 +31,7 @@ struct level_dev {
   chol_trsm_desc *trsm = nullptr;
   chol_upd_task *task = nullptr, *task_mt = nullptr;
   chol_upd_src *src = nullptr;
+  std::vector<chol_bcast> bcast;  // distributed top levels: the column blocks a phase of kind 6 broadcasts
 };
 struct solve_dev {
   int n_trsv = 0, n_grp = 0, n_fw = 0, n_bw = 0;
@@ -117,6 +118,7 @@ static int upload_level(level_dev &l, const chol_level_work &w)
 {
   l.n_potrf = w.n_potrf; l.n_trsm = w.n_trsm; l.n_task = w.n_task; l.n_src = w.n_src;
   l.phase.assign(w.phase, w.phase + w.n_phase);
+  l.bcast.assign(w.bcast, w.bcast + w.n_bcast);
   int rc = upload_vec(&l.potrf, w.potrf, (size_t)w.n_potrf);
   if (!rc) rc = upload_vec(&l.trsm, w.trsm, (size_t)w.n_trsm);
   if (!rc) rc = upload_vec(&l.task, w.task, (size_t)w.n_task);
@@ -243,6 +245,7 @@ extern "C" int cholamd_device_set_option(cholamd_device *d, const char *name, in
   else if (n == "program") d->opt.program = value != 0;
   else if (n == "follow") d->opt.follow = value != 0;
   else if (n == "super_blocks") d->opt.super_blocks = value;
+  else if (n == "dist_top") d->opt.dist_top = value;
   else if (n == "solve_reference_shape") { d->solve_reference_shape = value != 0; rebuild = false; }
   else { chol_set_error("unknown option '%s'", n.c_str()); return CHOLAMD_ERR_ARG; }
   return rebuild ? build_levels(d) : 0;
@@ -377,10 +380,12 @@ static int launch_phase(cholamd_device *d, const level_dev &l, const chol_phase 
   else if (ph.kind == 3) HIPCHK((hipError_t)chol_launch_update_mt(d_arena, l.task_mt + ph.first, l.src, ph.n, st));
   return 0;
 }
-extern "C" int cholamd_factor_levels(cholamd_device *d, double *d_arena, int level_hi, int level_lo, void *stream)
+struct cholamd_comm;
+static int bcast_rank(cholamd_device *d, const level_dev &l, const chol_phase &ph, double *d_arena, cholamd_comm *c, hipStream_t st);
+// levels [level_lo, level_hi] of one rank; a broadcast phase (kind 6: distributed top levels) goes through `c`
+static int factor_levels_comm(cholamd_device *d, double *d_arena, int level_hi, int level_lo, cholamd_comm *c, hipStream_t st)
 {
   HIPCHK(hipSetDevice(d->dev));
-  hipStream_t st = (hipStream_t)stream;
   const int L = d->plan->levels;
   if (level_hi >= L) level_hi = L - 1;
   if (level_lo < 0) level_lo = 0;
@@ -388,12 +393,21 @@ extern "C" int cholamd_factor_levels(cholamd_device *d, double *d_arena, int lev
   for (int lvl = level_hi; lvl >= level_lo; lvl--) { // mmat.rg:1227
     const level_dev &l = d->lv[lvl];
     for (const chol_phase &ph : l.phase) {
+      if (ph.kind == 6) {
+        int rc = bcast_rank(d, l, ph, d_arena, c, st);
+        if (rc) return rc;
+        continue;
+      }
       scoped_timer t(d, st, ph.kind == 3 ? 2 : ph.kind == 4 ? 1 : ph.kind == 5 ? 0 : ph.kind, ph.n > 0);
       int rc = launch_phase(d, l, ph, d_arena, st);
       if (rc) return rc;
     }
   }
   return 0;
+}
+extern "C" int cholamd_factor_levels(cholamd_device *d, double *d_arena, int level_hi, int level_lo, void *stream)
+{
+  return factor_levels_comm(d, d_arena, level_hi, level_lo, nullptr, (hipStream_t)stream);
 }
 extern "C" int cholamd_factor(cholamd_device *d, double *d_arena, void *stream)
 {
@@ -543,7 +557,7 @@ static int ensure_f32(cholamd_device *d)
   if (!d->lv32.empty()) return 0;
   const int L = d->plan->levels;
   chol_sched_opts o = d->opt;
-  o.split_min = CHOL32_MAXN; o.split_nb = CHOL32_MAXN; o.fuse = 0; o.fuse_update_max = 0; // pivot blocks the LDS-resident fp32 POTRF takes, one launch per phase
+  o.split_min = CHOL32_MAXN; o.split_nb = CHOL32_MAXN; o.fuse = 0; o.fuse_update_max = 0; o.dist_top = 0; // pivot blocks the LDS-resident fp32 POTRF takes, one launch per phase
   d->lv32.resize(L);
   for (int lvl = 0; lvl < L; lvl++) {
     chol_level_work w;
@@ -1224,10 +1238,20 @@ extern "C" void cholamd_cblas_dgemv(int layout, int trans, int m, int n, double 
 // arena tail (the top panels are the contiguous tail of the arena: chol_plan.h); one ncclAllReduce(sum) over
 // that tail is the exchange; the top levels follow on every rank.
 // ---------------------------------------------------------------------------------------------
+// A LOCAL communicator (cholamd_comm_create_local) joins rank objects of ONE process without RCCL: the exchange is a device-side
+// ordered sum of the tails and peer copies, events order the ranks' streams.  The ranks may share a device (how the one-GPU test
+// box runs world 2 ... 8); usable through cholamd_factor_multi only, which sees every rank's arena.
+#define CHOL_LOCAL_MAX 64
+struct local_group {
+  int n = 0, refs = 0;
+  std::vector<int> dev;
+  std::vector<hipEvent_t> ev; // [g]: rank g's stream has reached the exchange; [n + g]: rank g's part of the exchange is enqueued
+};
 struct cholamd_comm {
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
   bool owned = true;
+  local_group *local = nullptr;
 };
 #define NCCLCHK(call)                                                                                 \
   do {                                                                                                \
@@ -1271,6 +1295,25 @@ extern "C" int cholamd_comm_create_all(cholamd_device *const *devs, int n, chola
   for (int i = 0; i < n; i++) { out[i] = new cholamd_comm(); out[i]->comm = comms[i]; out[i]->world = n; out[i]->rank = i; }
   return 0;
 }
+extern "C" int cholamd_comm_create_local(cholamd_device *const *devs, int n, cholamd_comm **out)
+{ // one process, n rank objects, no RCCL: device-side sums and peer copies (the ranks may share a device)
+  if (n < 1 || n > CHOL_LOCAL_MAX) { chol_set_error("local communicator of %d ranks (1 .. %d)", n, CHOL_LOCAL_MAX); return CHOLAMD_ERR_ARG; }
+  local_group *G = new local_group();
+  G->n = n; G->refs = n; G->dev.resize(n); G->ev.resize(2 * n);
+  for (int i = 0; i < n; i++) G->dev[i] = devs[i]->dev;
+  for (int i = 0; i < n; i++) {
+    HIPCHK(hipSetDevice(G->dev[i]));
+    HIPCHK(hipEventCreateWithFlags(&G->ev[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&G->ev[n + i], hipEventDisableTiming));
+    for (int j = 0; j < n; j++) if (G->dev[j] != G->dev[i]) {
+      hipError_t e = hipDeviceEnablePeerAccess(G->dev[j], 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { chol_set_error("no peer access from device %d to device %d: %s", G->dev[i], G->dev[j], hipGetErrorString(e)); return CHOLAMD_ERR_COMM; }
+      (void)hipGetLastError();
+    }
+  }
+  for (int i = 0; i < n; i++) { out[i] = new cholamd_comm(); out[i]->world = n; out[i]->rank = i; out[i]->owned = false; out[i]->local = G; }
+  return 0;
+}
 extern "C" int cholamd_comm_adopt(void *nccl_comm, int world, int rank, cholamd_comm **out)
 { // an ncclComm_t the caller made (and keeps): e.g. the one a Legion mapper or torch's process group holds
   if (!nccl_comm) { chol_set_error("null ncclComm_t"); return CHOLAMD_ERR_ARG; }
@@ -1283,6 +1326,10 @@ extern "C" void cholamd_comm_destroy(cholamd_comm *c)
 {
   if (!c) return;
   if (c->owned && c->comm) (void)ncclCommDestroy(c->comm);
+  if (c->local && --c->local->refs == 0) {
+    for (size_t i = 0; i < c->local->ev.size(); i++) { (void)hipSetDevice(c->local->dev[i % c->local->n]); (void)hipEventDestroy(c->local->ev[i]); }
+    delete c->local;
+  }
   delete c;
 }
 static int tail_of(const cholamd_device *d, int64_t *tail, int64_t *count)
@@ -1300,18 +1347,40 @@ extern "C" int64_t cholamd_device_tail_offset(const cholamd_device *d)
 }
 extern "C" int cholamd_comm_allreduce(cholamd_comm *c, double *d_buf, int64_t count, void *stream)
 { // in-place fp64 sum over the communicator's ranks, asynchronous on `stream` (of the current device)
-  if (!c || !c->comm) { chol_set_error("null communicator"); return CHOLAMD_ERR_ARG; }
+  if (!c || !c->comm) { chol_set_error(c && c->local ? "a local communicator exchanges through cholamd_factor_multi only" : "null communicator"); return CHOLAMD_ERR_ARG; }
   if (count <= 0) return 0;
   NCCLCHK(ncclAllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, c->comm, (hipStream_t)stream));
   return 0;
 }
+static int comm_matches(const cholamd_device *d, const cholamd_comm *c)
+{
+  if (c && c->world == d->world && c->rank == d->rank) return 0;
+  chol_set_error("communicator (rank %d of %d) does not match the device partition (rank %d of %d)", c ? c->rank : -1, c ? c->world : -1, d->rank, d->world);
+  return CHOLAMD_ERR_ARG;
+}
 extern "C" int cholamd_exchange_tail(cholamd_device *d, double *d_arena, cholamd_comm *c, void *stream)
 {
   HIPCHK(hipSetDevice(d->dev));
-  if (!c || c->world != d->world || c->rank != d->rank) { chol_set_error("communicator (rank %d of %d) does not match the device partition (rank %d of %d)", c ? c->rank : -1, c ? c->world : -1, d->rank, d->world); return CHOLAMD_ERR_ARG; }
+  if (comm_matches(d, c)) return CHOLAMD_ERR_ARG;
   int64_t tail, count;
   tail_of(d, &tail, &count);
   return cholamd_comm_allreduce(c, d_arena + tail, count, stream);
+}
+// one rank's broadcasts of a phase of kind 6 (distributed top levels): every column block of the step travels from its owner to all
+// ranks, in place at the same arena offset; one RCCL group
+static int bcast_rank(cholamd_device *d, const level_dev &l, const chol_phase &ph, double *d_arena, cholamd_comm *c, hipStream_t st)
+{
+  if (!c) { chol_set_error("the distributed top levels (option dist_top) need a communicator: cholamd_factor_sharded / cholamd_factor_multi"); return CHOLAMD_ERR_ARG; }
+  if (comm_matches(d, c)) return CHOLAMD_ERR_ARG;
+  if (!c->comm) { chol_set_error("a local communicator exchanges through cholamd_factor_multi only"); return CHOLAMD_ERR_ARG; }
+  NCCLCHK(ncclGroupStart());
+  for (int i = ph.first; i < ph.first + ph.n; i++) {
+    const chol_bcast &b = l.bcast[i];
+    ncclResult_t r = ncclBroadcast(d_arena + b.off, d_arena + b.off, (size_t)b.count, ncclDouble, b.owner, c->comm, st);
+    if (r != ncclSuccess) { (void)ncclGroupEnd(); chol_set_error("ncclBroadcast failed: %s", ncclGetErrorString(r)); return CHOLAMD_ERR_COMM; }
+  }
+  NCCLCHK(ncclGroupEnd());
+  return 0;
 }
 extern "C" int cholamd_factor_sharded(cholamd_device *d, double *d_arena, cholamd_comm *c, void *stream)
 {
@@ -1319,28 +1388,120 @@ extern "C" int cholamd_factor_sharded(cholamd_device *d, double *d_arena, cholam
   if (d->world == 1) return cholamd_factor(d, d_arena, stream);
   int rc = cholamd_factor_levels(d, d_arena, L - 1, split, stream);
   if (!rc) rc = cholamd_exchange_tail(d, d_arena, c, stream);
-  if (!rc) rc = cholamd_factor_levels(d, d_arena, split - 1, 0, stream);
+  if (!rc) rc = factor_levels_comm(d, d_arena, split - 1, 0, c, (hipStream_t)stream);
   return rc;
 }
+
+// ---- one process driving n ranks ----
+struct ptr_pack { double *p[CHOL_LOCAL_MAX]; };
+__global__ void k_sum_tails(ptr_pack P, int n, int64_t count)
+{ // P.p[0][i] = sum over the ranks in rank order (a fixed order: run-to-run identical)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    double s = P.p[0][i];
+    for (int r = 1; r < n; r++) s += P.p[r][i];
+    P.p[0][i] = s;
+  }
+}
+static hipStream_t stream_of(void *const *streams, int g) { return streams ? (hipStream_t)streams[g] : nullptr; }
+static int local_allreduce_tails(cholamd_device *const *devs, double *const *arenas, local_group *G, int n, void *const *streams)
+{
+  int64_t tail, count;
+  tail_of(devs[0], &tail, &count);
+  if (count <= 0) return 0;
+  for (int g = 0; g < n; g++) { HIPCHK(hipSetDevice(devs[g]->dev)); HIPCHK(hipEventRecord(G->ev[g], stream_of(streams, g))); }
+  HIPCHK(hipSetDevice(devs[0]->dev));
+  ptr_pack P;
+  for (int g = 0; g < n; g++) { P.p[g] = arenas[g] + tail; if (g) HIPCHK(hipStreamWaitEvent(stream_of(streams, 0), G->ev[g], 0)); }
+  const int64_t blocks = (count + 255) / 256;
+  hipLaunchKernelGGL(k_sum_tails, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream_of(streams, 0), P, n, count);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(G->ev[n], stream_of(streams, 0)));
+  for (int g = 1; g < n; g++) {
+    HIPCHK(hipSetDevice(devs[g]->dev));
+    HIPCHK(hipStreamWaitEvent(stream_of(streams, g), G->ev[n], 0));
+    HIPCHK(hipMemcpyPeerAsync(arenas[g] + tail, devs[g]->dev, arenas[0] + tail, devs[0]->dev, (size_t)count * sizeof(double), stream_of(streams, g)));
+    HIPCHK(hipEventRecord(G->ev[n + g], stream_of(streams, g)));
+  }
+  HIPCHK(hipSetDevice(devs[0]->dev));
+  for (int g = 1; g < n; g++) HIPCHK(hipStreamWaitEvent(stream_of(streams, 0), G->ev[n + g], 0)); // rank 0 goes on writing its tail
+  return 0;
+}
+static int local_bcast(cholamd_device *const *devs, double *const *arenas, local_group *G, int n, void *const *streams, const level_dev &l, const chol_phase &ph)
+{
+  std::vector<char> owner_ready(n, 0);
+  for (int i = ph.first; i < ph.first + ph.n; i++) {
+    const int o = l.bcast[i].owner;
+    if (owner_ready[o]) continue;
+    owner_ready[o] = 1;
+    HIPCHK(hipSetDevice(devs[o]->dev));
+    HIPCHK(hipEventRecord(G->ev[o], stream_of(streams, o))); // the owner's POTRF + TRSM of the step are in its stream
+  }
+  for (int g = 0; g < n; g++) {
+    HIPCHK(hipSetDevice(devs[g]->dev));
+    for (int o = 0; o < n; o++) if (owner_ready[o] && o != g) HIPCHK(hipStreamWaitEvent(stream_of(streams, g), G->ev[o], 0));
+    for (int i = ph.first; i < ph.first + ph.n; i++) {
+      const chol_bcast &b = l.bcast[i];
+      if (b.owner == g) continue; // the owner does not touch the block again: the copies may read it while its stream goes on
+      HIPCHK(hipMemcpyPeerAsync(arenas[g] + b.off, devs[g]->dev, arenas[b.owner] + b.off, devs[b.owner]->dev, (size_t)b.count * sizeof(double), stream_of(streams, g)));
+    }
+  }
+  return 0;
+}
 extern "C" int cholamd_factor_multi(cholamd_device *const *devs, double *const *arenas, cholamd_comm *const *comms, int n, void *const *streams)
-{ // one process, n devices: everything is asynchronous on each device's stream
+{ // one process, n ranks: everything is asynchronous on each rank's stream
   if (n < 1) { chol_set_error("no devices"); return CHOLAMD_ERR_ARG; }
   if (n == 1) return cholamd_factor(devs[0], arenas[0], streams ? streams[0] : nullptr);
   const int L = devs[0]->plan->levels, split = chol_split_level(n);
+  local_group *G = comms[0] ? comms[0]->local : nullptr;
   for (int g = 0; g < n; g++) {
     if (devs[g]->world != n || devs[g]->rank != g) { chol_set_error("device %d is not partitioned as rank %d of %d", g, g, n); return CHOLAMD_ERR_ARG; }
-    int rc = cholamd_factor_levels(devs[g], arenas[g], L - 1, split, streams ? streams[g] : nullptr);
+    if (comm_matches(devs[g], comms[g])) return CHOLAMD_ERR_ARG;
+    if (comms[g]->local != G || (!G && !comms[g]->comm)) { chol_set_error("the %d communicators are not of one kind", n); return CHOLAMD_ERR_ARG; }
+    int rc = cholamd_factor_levels(devs[g], arenas[g], L - 1, split, stream_of(streams, g));
     if (rc) return rc;
   }
-  NCCLCHK(ncclGroupStart());
-  for (int g = 0; g < n; g++) {
-    int rc = cholamd_exchange_tail(devs[g], arenas[g], comms[g], streams ? streams[g] : nullptr);
-    if (rc) { (void)ncclGroupEnd(); return rc; }
+  if (G) { int rc = local_allreduce_tails(devs, arenas, G, n, streams); if (rc) return rc; }
+  else {
+    NCCLCHK(ncclGroupStart());
+    for (int g = 0; g < n; g++) {
+      int rc = cholamd_exchange_tail(devs[g], arenas[g], comms[g], stream_of(streams, g));
+      if (rc) { (void)ncclGroupEnd(); return rc; }
+    }
+    NCCLCHK(ncclGroupEnd());
   }
-  NCCLCHK(ncclGroupEnd());
-  for (int g = 0; g < n; g++) {
-    int rc = cholamd_factor_levels(devs[g], arenas[g], split - 1, 0, streams ? streams[g] : nullptr);
-    if (rc) return rc;
+  // top levels: every rank runs its phases up to its next broadcast phase; the broadcasts of all ranks form one group
+  for (int lvl = split - 1; lvl >= 0; lvl--) {
+    std::vector<size_t> cur(n, 0);
+    for (;;) {
+      int at_bcast = 0;
+      for (int g = 0; g < n; g++) {
+        const level_dev &l = devs[g]->lv[lvl];
+        HIPCHK(hipSetDevice(devs[g]->dev));
+        while (cur[g] < l.phase.size() && l.phase[cur[g]].kind != 6) {
+          int rc = launch_phase(devs[g], l, l.phase[cur[g]], arenas[g], stream_of(streams, g));
+          if (rc) return rc;
+          cur[g]++;
+        }
+        if (cur[g] < l.phase.size()) at_bcast++;
+      }
+      if (at_bcast == 0) break;
+      if (at_bcast != n) { chol_set_error("internal: the ranks disagree on the broadcast sequence of level %d", lvl); return CHOLAMD_ERR_ARG; }
+      if (G) { int rc = local_bcast(devs, arenas, G, n, streams, devs[0]->lv[lvl], devs[0]->lv[lvl].phase[cur[0]]); if (rc) return rc; }
+      else {
+        NCCLCHK(ncclGroupStart());
+        for (int g = 0; g < n; g++) {
+          const level_dev &l = devs[g]->lv[lvl];
+          const chol_phase &ph = l.phase[cur[g]];
+          for (int i = ph.first; i < ph.first + ph.n; i++) {
+            const chol_bcast &b = l.bcast[i];
+            ncclResult_t r = ncclBroadcast(arenas[g] + b.off, arenas[g] + b.off, (size_t)b.count, ncclDouble, b.owner, comms[g]->comm, stream_of(streams, g));
+            if (r != ncclSuccess) { (void)ncclGroupEnd(); chol_set_error("ncclBroadcast failed: %s", ncclGetErrorString(r)); return CHOLAMD_ERR_COMM; }
+          }
+        }
+        NCCLCHK(ncclGroupEnd());
+      }
+      for (int g = 0; g < n; g++) cur[g]++;
+    }
   }
   return 0;
 }

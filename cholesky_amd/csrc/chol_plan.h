@@ -115,8 +115,12 @@ typedef struct {
               * 5 fused potrf (first, n) + trsm (first2, n2) + 16x16 update tasks (first3, n3) */
   int first, n, first2, n2, first3, n3;
 } chol_phase;
+/* kind 6 (distributed top levels): broadcast of the column blocks [first, first + n) of the level's bcast list: every rank receives
+ * `count` doubles at arena offset `off` from rank `owner` */
+typedef struct { int64_t off, count; int owner, pad; } chol_bcast;
 
 /* schedule switches of one device object (chol_schedule.c): read from the environment once, at cholamd_device_create */
+#define CHOL_DIST_MIN 1024      /* dist_top = 2 (auto): the top levels are distributed when the root separator has this many columns */
 #define CHOL_MT_MIN_TILES 8192 /* a phase whose 16x16 sub-tile count reaches this goes to 64x64 macro tiles for its larger targets */
 typedef struct {
   int split_min, split_nb;  /* pivots wider than split_min are factored in column blocks of at most split_nb columns */
@@ -126,6 +130,8 @@ typedef struct {
   int cells;                /* extend-add of small phases by 16x16 grid cells of the target blocks */
   int program;              /* small problems: the whole factorisation as one launch (chol_build_program) */
   int follow;               /* ... in which pivot blocks follow their children's / predecessor's TRSM strips */
+  int dist_top;             /* 0 / 1 / 2 = auto (CHOL_DIST_MIN); world > 1: the levels above the cut are distributed over the ranks by column blocks (owner factors and
+                             * solves a block, broadcasts it, every rank updates the column blocks it owns) instead of replicated */
   int super_blocks;         /* column blocks per super-block of a wide pivot: the trailing matrix beyond a super-block gets one update of
                              * rank super_blocks * (block width) instead of one per block */
 } chol_sched_opts;
@@ -144,6 +150,7 @@ typedef struct {
   int n_task; chol_upd_task *task;         /* 16x16 sub-tile tasks (k_update) */
   int n_task_mt; chol_upd_task *task_mt;   /* 64x64 macro-tile tasks (k_update_mt): targets larger than 16x16 */
   int n_src; chol_upd_src *src;            /* task.src_begin/src_end index this array */
+  int n_bcast; chol_bcast *bcast;          /* distributed top levels: the column blocks exchanged after each step */
 } chol_level_work;
 
 /* solve-phase descriptors */

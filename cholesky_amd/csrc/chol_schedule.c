@@ -68,8 +68,11 @@ static void index_snapshot(const plan_t *p, int lbl, int64_t *first, int *count)
 }
 
 /* growable arrays of the level work */
-typedef struct { int64_t c_off; int ldc, m, n, syrk, src_begin, src_end, blk; } upd_target;
-typedef struct { chol_level_work *w; const chol_sched_opts *o; int force_fine; int cur_blk; const int *follow_lim; int cap_p, cap_t, cap_k, cap_km, cap_s, cap_ph; upd_target *pend; int n_pend, cap_pend; } builder;
+typedef struct { int64_t c_off; int ldc, m, n, syrk, src_begin, src_end, blk, ar0, br0; } upd_target;
+typedef struct { chol_level_work *w; const chol_sched_opts *o; int force_fine; int cur_blk; const int *follow_lim;
+  /* distributed top level: targets are cut at the column blocks of the target separator and kept only where this rank owns the block */
+  int dist_world, dist_rank; const struct cholamd_plan *dist_plan; int tgt_sep, tgt_col0; int cap_b;
+  int cap_p, cap_t, cap_k, cap_km, cap_s, cap_ph; upd_target *pend; int n_pend, cap_pend; } builder;
 /* Blocking of a pivot at the schedule level.  The POTRF kernel takes pivots up to CHOL_RR_MAXN whole, but one
  * workgroup's MFMA throughput bounds the early steps of a large one (the trailing update of step 0 of a
  * 17 x 17 tile grid is 120 tile updates on one CU); a pivot wider than CHOL_SPLIT_MIN is therefore factored
@@ -81,7 +84,7 @@ static int env_int(const char *name, int dflt) { const char *e = getenv(name); r
 void chol_sched_opts_default(chol_sched_opts *o)
 {
   o->split_min = CHOL_SPLIT_MIN; o->split_nb = CHOL_SPLIT_NB; o->fuse = 1; o->fuse_update_max = CHOL_FUSE_UPDATE_MAX;
-  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS;
+  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2;
 }
 void chol_sched_opts_from_env(chol_sched_opts *o)
 {
@@ -94,6 +97,7 @@ void chol_sched_opts_from_env(chol_sched_opts *o)
   o->cells = !env_int("CHOLAMD_NO_CELLS", 0);
   o->program = !env_int("CHOLAMD_NO_PROGRAM", 0);
   o->follow = !env_int("CHOLAMD_NO_FOLLOW", 0);
+  o->dist_top = env_int("CHOLAMD_DIST_TOP", o->dist_top);
   o->super_blocks = env_int("CHOLAMD_SUPER_BLOCKS", o->super_blocks);
 }
 static int split_nb(const chol_sched_opts *o) { int v = o->split_nb; if (v > CHOL_RR_MAXN) v = CHOL_RR_MAXN; v = (v + 15) / 16 * 16; if (v < 16) v = 16; return v; }
@@ -104,9 +108,14 @@ static int pivot_block_width(const chol_sched_opts *o, int n) { const int nb = p
  * below it the 16x16 split-K workgroups are what fills the 256 CUs, above it their 4x operand
  * re-reads are what costs */
 
-static void push_phase(builder *B, int kind, int first, int n)
+static void push_phase_f(builder *B, int kind, int first, int n, int force);
+static void push_phase(builder *B, int kind, int first, int n) { push_phase_f(B, kind, first, n, 0); }
+/* force: an empty launch keeps its place in the sequence (distributed top levels: every rank walks the same phase sequence,
+ * the broadcasts in it are collective) */
+static void push_phase_f(builder *B, int kind, int first, int n, int force)
 {
-  if (n <= 0) return;
+  if (n <= 0 && !force) return;
+  if (n < 0) n = 0;
   chol_level_work *w = B->w;
   if (w->n_phase == B->cap_ph) { B->cap_ph = B->cap_ph ? 2 * B->cap_ph : 16; w->phase = realloc(w->phase, B->cap_ph * sizeof(chol_phase)); }
   chol_phase ph = { kind, first, n, 0, 0, 0, 0 };
@@ -149,7 +158,7 @@ static int push_src(builder *B, chol_upd_src sd)
 }
 /* tasks of one m x n target whose sources are [src_begin, src_end): 16x16 sub-tiles for small targets
  * (k_update: the four waves split K), 64x64 macro tiles otherwise (k_update_mt: LDS-staged panels) */
-static void emit_tasks(builder *B, int macro, int64_t c_off, int ldc, int m, int n, int syrk, int src_begin, int src_end, int blk)
+static void emit_tasks(builder *B, int macro, int64_t c_off, int ldc, int m, int n, int syrk, int src_begin, int src_end, int blk, int ar0, int br0)
 {
   chol_level_work *w = B->w;
   const int ts = macro ? 64 : 16;
@@ -172,17 +181,40 @@ static void emit_tasks(builder *B, int macro, int64_t c_off, int ldc, int m, int
       t->nv = (short)(n - b * ts < ts ? n - b * ts : ts);
       t->lower = (syrk && a == b);
       t->src_begin = src_begin; t->src_end = src_end;
-      t->ar = a * ts; t->br = b * ts;
+      t->ar = ar0 + a * ts; t->br = br0 + b * ts;
       t->blk = blk;
     }
 }
 
 /* targets of the current update phase; flush_targets() chooses the tile shape once the phase is complete */
+static void push_target(builder *B, int64_t c_off, int ldc, int m, int n, int syrk, int src_begin, int src_end, int ar0, int br0)
+{
+  if (m <= 0 || n <= 0) return;
+  if (B->n_pend == B->cap_pend) { B->cap_pend = B->cap_pend ? 2 * B->cap_pend : 256; B->pend = realloc(B->pend, B->cap_pend * sizeof(upd_target)); }
+  upd_target t = { c_off, ldc, m, n, syrk, src_begin, src_end, B->cur_blk, ar0, br0 };
+  B->pend[B->n_pend++] = t;
+}
+static int pivot_block_width(const chol_sched_opts *o, int n);
+/* owner of column block `blk` of top separator `sep` among `world` ranks (cyclic, shifted by the separator's heap index) */
+static int dist_owner(const struct cholamd_plan *p, int sep, int blk, int world) { return (blk + p->heap_of[sep]) % world; }
 static void push_tasks(builder *B, int64_t c_off, int ldc, int m, int n, int syrk, int src_begin, int src_end)
 {
-  if (B->n_pend == B->cap_pend) { B->cap_pend = B->cap_pend ? 2 * B->cap_pend : 256; B->pend = realloc(B->pend, B->cap_pend * sizeof(upd_target)); }
-  upd_target t = { c_off, ldc, m, n, syrk, src_begin, src_end, B->cur_blk };
-  B->pend[B->n_pend++] = t;
+  if (B->dist_world <= 1) { push_target(B, c_off, ldc, m, n, syrk, src_begin, src_end, 0, 0); return; }
+  /* cut the target's columns at the column blocks of the target separator; keep the pieces this rank owns.  Columns j of the
+   * target are columns tgt_col0 + j of the separator's pivot; a piece of a SYRK target is its own triangle plus the rows below */
+  const int bw = pivot_block_width(B->o, B->dist_plan->sep_size[B->tgt_sep]);
+  for (int j0 = 0; j0 < n;) {
+    const int blk = (B->tgt_col0 + j0) / bw;
+    int j1 = (blk + 1) * bw - B->tgt_col0;
+    if (j1 > n) j1 = n;
+    if (dist_owner(B->dist_plan, B->tgt_sep, blk, B->dist_world) == B->dist_rank) {
+      if (syrk) {
+        push_target(B, c_off + j0 + (int64_t)j0 * ldc, ldc, j1 - j0, j1 - j0, 1, src_begin, src_end, j0, j0);
+        push_target(B, c_off + j1 + (int64_t)j0 * ldc, ldc, m - j1, j1 - j0, 0, src_begin, src_end, j1, j0);
+      } else push_target(B, c_off + (int64_t)j0 * ldc, ldc, m, j1 - j0, 0, src_begin, src_end, 0, j0);
+    }
+    j0 = j1;
+  }
 }
 static void flush_targets(builder *B)
 {
@@ -194,7 +226,7 @@ static void flush_targets(builder *B)
   const int big = fine >= B->o->mt_min_tiles && !B->force_fine;
   for (int i = 0; i < B->n_pend; i++) {
     const upd_target *t = &B->pend[i];
-    emit_tasks(B, big && (t->m > 16 || t->n > 16), t->c_off, t->ldc, t->m, t->n, t->syrk, t->src_begin, t->src_end, t->blk);
+    emit_tasks(B, big && (t->m > 16 || t->n > 16), t->c_off, t->ldc, t->m, t->n, t->syrk, t->src_begin, t->src_end, t->blk, t->ar0, t->br0);
   }
   B->n_pend = 0;
 }
@@ -228,6 +260,7 @@ static int emit_cell_tasks(builder *B, const plan_t *p, const upd_tuple *tu, int
         /* program launch with followers: the leading lim x lim part of a parent's diagonal block receives its children's
          * contributions inside the parent's POTRF job (follow_external), not from update tasks */
         if (B->follow_lim && B->follow_lim[u->bc] > 0 && 16 * I < B->follow_lim[u->bc] && 16 * J < B->follow_lim[u->bc]) continue;
+        if (B->dist_world > 1 && dist_owner(p, Bc->c, (16 * J) / pivot_block_width(B->o, p->sep_size[Bc->c]), B->dist_world) != B->dist_rank) continue; /* the cell's column block is another rank's */
         if (np == cap) { cap *= 2; pc = realloc(pc, (size_t)cap * sizeof(cell_piece)); }
         cell_piece *q = &pc[np++];
         const int r0 = (u->crow > 16 * I ? u->crow : 16 * I) - 16 * I, r1 = (u->crow + u->m < 16 * I + 16 ? u->crow + u->m : 16 * I + 16) - 16 * I;
@@ -350,6 +383,11 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
     if (pivot_blocks(opts, p->sep_size[s]) > steps) steps = pivot_blocks(opts, p->sep_size[s]);
   }
   if (steps == 0) steps = 1;
+  /* distributed top level (world > 1, option dist_top): column block `st` of separator s is factored and solved by its owner,
+   * broadcast, and every rank applies the updates into the column blocks IT owns (push_tasks / emit_cell_tasks cut and filter
+   * the targets); every rank walks the same phase sequence */
+  const int dist = world > 1 && level < d && (opts->dist_top == 1 || (opts->dist_top == 2 && p->sep_size[p->tree[1]] >= CHOL_DIST_MIN));
+  if (dist) { B->dist_world = world; B->dist_rank = rank; B->dist_plan = p; }
   int fused_last = -1; /* the level's last fused launch, if nothing was launched after it */
   int fuse = opts->fuse; /* POTRF + TRSM of a step in one launch, if every block fits its TRSM role */
   for (int q = 0; q < nh; q++) if (pivot_block_width(opts, p->sep_size[p->tree[hs[q]]]) > CHOL_FUSE_MAXN) fuse = 0;
@@ -357,7 +395,7 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
    * POTRF of the diagonal block, TRSM of every row below it (rows of the pivot and filled ancestor rows
    * alike), rank-nb update of the remaining columns of those rows */
   for (int st = 0; st < steps; st++) {
-    const int p0 = w->n_potrf, t0 = w->n_trsm, k0 = w->n_task, km0 = w->n_task_mt;
+    const int p0 = w->n_potrf, t0 = w->n_trsm, k0 = w->n_task, km0 = w->n_task_mt, b0 = w->n_bcast;
     for (int q = 0; q < nh; q++) {
       const int h = hs[q], s = p->tree[h], n = p->sep_size[s], ld = p->panel_ld[s];
       const int bw = pivot_block_width(opts, n);
@@ -366,16 +404,25 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
       const int nb = n - c0 < bw ? n - c0 : bw;
       const int64_t diag = p->panel_off[s] + c0 + (int64_t)c0 * ld;          /* element (c0, c0) of the pivot */
       const int64_t dinv = p->dinv_off[s] + (int64_t)(c0 / CHOL_NB) * CHOL_NB * CHOL_NB;
-      chol_potrf_desc pd = { diag, dinv, nb, ld, s, c0, 0, 0 };
-      push_potrf(B, pd);
       const int64_t colbase = (int64_t)c0 * ld;                              /* column c0 of the panel */
       const int below = n - c0 - nb;                                         /* pivot rows under the diagonal block */
-      const int flag = w->n_potrf - 1 - p0; /* this block's POTRF descriptor within the step */
-      if (below > 0) push_trsm_run(B, diag, dinv, p->panel_off[s] + (c0 + nb) + colbase, nb, ld, below, flag);
       row_run *runs; const int nr = ancestor_runs(p, h, snap, first, count, &runs);
-      for (int r = 0; r < nr; r++) push_trsm_run(B, diag, dinv, runs[r].off + colbase, nb, ld, runs[r].m, flag);
-      if (fuse) pad_trsm_group(B, t0, 3, diag, dinv, diag, nb, ld, flag);
-      else if (nb <= CHOL_TRSM_W_MAXN) pad_trsm_group(B, t0, 4, diag, dinv, diag, nb, ld, flag);
+      const int mine = !dist || dist_owner(p, s, st, world) == rank;
+      if (dist) { /* the column block travels from its owner to every rank once it is factored and solved */
+        if (w->n_bcast == B->cap_b) { B->cap_b = B->cap_b ? 2 * B->cap_b : 16; w->bcast = realloc(w->bcast, B->cap_b * sizeof(chol_bcast)); }
+        chol_bcast bc = { p->panel_off[s] + colbase, (int64_t)nb * ld, dist_owner(p, s, st, world), 0 };
+        w->bcast[w->n_bcast++] = bc;
+        B->tgt_sep = s;
+      }
+      if (mine) {
+        chol_potrf_desc pd = { diag, dinv, nb, ld, s, c0, 0, 0 };
+        push_potrf(B, pd);
+        const int flag = w->n_potrf - 1 - p0; /* this block's POTRF descriptor within the step */
+        if (below > 0) push_trsm_run(B, diag, dinv, p->panel_off[s] + (c0 + nb) + colbase, nb, ld, below, flag);
+        for (int r = 0; r < nr; r++) push_trsm_run(B, diag, dinv, runs[r].off + colbase, nb, ld, runs[r].m, flag);
+        if (fuse) pad_trsm_group(B, t0, 3, diag, dinv, diag, nb, ld, flag);
+        else if (nb <= CHOL_TRSM_W_MAXN) pad_trsm_group(B, t0, 4, diag, dinv, diag, nb, ld, flag);
+      }
       if (below > 0) {
         /* Trailing update, in SUPER-BLOCKS of `super` column blocks: after a column block only the remaining columns of its
          * own super-block receive its rank-nb update (they are factored next); the columns beyond wait for the end of the
@@ -389,6 +436,7 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
         const int last_in_sb = (st % G == G - 1) || c0 + nb >= n || c0 + nb >= cse;
         /* (1) narrow: columns [c0+nb, cse) of the rows below, K = nb */
         const int ncol = cse - (c0 + nb);
+        B->tgt_col0 = c0 + nb;
         if (ncol > 0) {
           const int64_t x_piv = p->panel_off[s] + (c0 + nb) + colbase;         /* solved pivot rows under the block, k = nb */
           chol_upd_src sp = { x_piv, x_piv, ld, ld, nb, 0 };
@@ -406,6 +454,7 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
           }
         }
         /* (2) wide, at the end of the super-block: columns [cse, n), K = cse - cs0 */
+        B->tgt_col0 = cse;
         if (last_in_sb && cse < n) {
           const int K = cse - cs0, rest = n - cse;
           const int64_t x_sb = p->panel_off[s] + cse + (int64_t)cs0 * ld;      /* pivot rows beyond the super-block, its columns */
@@ -422,6 +471,23 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
       free(runs);
     }
     flush_targets(B);
+    if (dist) { /* owner's POTRF + TRSM, the broadcast of the step's column blocks (collective: the same list on every rank),
+                 * then this rank's share of the trailing update */
+      if (fuse) {
+        if (w->n_phase == B->cap_ph) { B->cap_ph = B->cap_ph ? 2 * B->cap_ph : 16; w->phase = realloc(w->phase, B->cap_ph * sizeof(chol_phase)); }
+        chol_phase ph = { 5, p0, w->n_potrf - p0, t0, w->n_trsm - t0, k0, 0 };
+        if (ph.n > 0) w->phase[w->n_phase++] = ph;
+      } else {
+        push_phase(B, 0, p0, w->n_potrf - p0);
+        int wide = 0;
+        for (int i = t0; i < w->n_trsm; i++) if (w->trsm[i].n > CHOL_TRSM_W_MAXN) wide = 1;
+        push_phase(B, wide ? 1 : 4, t0, w->n_trsm - t0);
+      }
+      push_phase_f(B, 6, b0, w->n_bcast - b0, 1);
+      push_phase(B, 2, k0, w->n_task - k0);
+      push_phase(B, 3, km0, w->n_task_mt - km0);
+      continue;
+    }
     if (fuse) { /* one launch: the strips follow their pivot's POTRF column by column, the 16x16 update tasks of the
                  * step (trailing columns of a split pivot) wait for the strips inside the same launch */
       if (w->n_phase == B->cap_ph) { B->cap_ph = B->cap_ph ? 2 * B->cap_ph : 16; w->phase = realloc(w->phase, B->cap_ph * sizeof(chol_phase)); }
@@ -490,10 +556,12 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
         chol_upd_src sd = { tu[q].a_off, tu[q].b_off, tu[q].lda, tu[q].ldb, tu[q].k, 0 };
         push_src(B, sd);
       }
+      if (dist) { B->tgt_sep = p->blk[tu[i].bc].c; B->tgt_col0 = tu[i].ccol; }
       push_tasks(B, tu[i].c_off, tu[i].ldc, tu[i].m, tu[i].n, tu[i].syrk, sb, w->n_src);
       i = e;
     }
     flush_targets(B);
+    if (dist) push_phase(B, 2, k0, w->n_task - k0); else
     /* the 16x16 tasks of the extend-add ride in the level's last fused launch when that one carries no tasks of
      * its own and nothing was launched after it */
     if (fused_last >= 0 && fused_last == w->n_phase - 1 && w->phase[fused_last].n3 == 0 && w->n_task - k0 <= opts->fuse_update_max) {
@@ -1110,9 +1178,46 @@ int cholamd_plan_program_counts(const cholamd_plan *p, int follow, int out[6])
   return 0;
 }
 
+/* volumes of one level's lists for (rank, world) under dist_top = 0 / 1 / 2 (auto): what the CPU tests sum over the ranks.
+ * out: POTRF columns, TRSM elements (rows x columns), update volume (target elements x source depth), broadcast entries,
+ * broadcast doubles, a checksum of the broadcast list (identical on every rank: the sequence is collective) */
+int cholamd_plan_level_work_volume(const cholamd_plan *p, int level, int rank, int world, int dist_top, int64_t out[6])
+{
+  chol_sched_opts o;
+  chol_sched_opts_default(&o);
+  o.dist_top = dist_top;
+  chol_level_work w;
+  int rc = chol_build_level_work(p, &o, level, rank, world, &w);
+  if (rc) return rc;
+  memset(out, 0, 6 * sizeof(int64_t));
+  for (int i = 0; i < w.n_potrf; i++) out[0] += w.potrf[i].n;
+  for (int i = 0; i < w.n_trsm; i++) out[1] += (int64_t)w.trsm[i].m * w.trsm[i].n;
+  for (int pass = 0; pass < 2; pass++) {
+    const chol_upd_task *T = pass ? w.task_mt : w.task;
+    const int nt = pass ? w.n_task_mt : w.n_task;
+    for (int i = 0; i < nt; i++) {
+      const chol_upd_task *t = &T[i];
+      int64_t full = 0;
+      for (int c = 0; c < t->nv; c++) full += t->lower ? (t->mv - c > 0 ? t->mv - c : 0) : t->mv;
+      for (int q = t->src_begin; q < t->src_end; q++) {
+        const chol_upd_src *sd = &w.src[q];
+        const int r0 = sd->range & 255, r1 = (sd->range >> 8) & 255, c0 = (sd->range >> 16) & 255, c1 = (sd->range >> 24) & 255;
+        out[2] += (sd->range ? (int64_t)(r1 - r0) * (c1 - c0) : full) * sd->k;
+      }
+    }
+  }
+  out[3] = w.n_bcast;
+  for (int i = 0; i < w.n_bcast; i++) { out[4] += w.bcast[i].count; out[5] = out[5] * 1000003 + w.bcast[i].off * 31 + w.bcast[i].owner + 7 * w.bcast[i].count; }
+  int nb6 = 0;
+  for (int i = 0; i < w.n_phase; i++) if (w.phase[i].kind == 6) nb6 += w.phase[i].n;
+  if (nb6 != w.n_bcast) { chol_set_error("internal: %d broadcast entries, %d in phases", w.n_bcast, nb6); rc = CHOLAMD_ERR_ARG; }
+  chol_level_work_free(&w);
+  return rc;
+}
+
 void chol_level_work_free(chol_level_work *w)
 {
-  free(w->potrf); free(w->trsm); free(w->task); free(w->task_mt); free(w->src); free(w->phase);
+  free(w->potrf); free(w->trsm); free(w->task); free(w->task_mt); free(w->src); free(w->phase); free(w->bcast);
   memset(w, 0, sizeof *w);
 }
 

@@ -186,3 +186,22 @@ class Comm:
                 self.h = None
         except Exception:
             pass
+
+
+def factor_multi(devs, arenas, local=True, streams=None):
+    """One process driving the n rank objects `devs` (devs[g] partitioned as rank g of n): cholamd_factor_multi with a LOCAL
+    communicator (device-side sums and peer copies: the ranks may share a GPU) or an RCCL one (ncclCommInitAll, one GPU per rank)."""
+    L = load()
+    n = len(devs)
+    hd = (C.c_void_p * n)(*[d.h for d in devs])
+    ha = (C.c_void_p * n)(*[C.c_void_p(a.data_ptr()) for a in arenas])
+    hc = (C.c_void_p * n)()
+    hs = (C.c_void_p * n)(*[_stream_ptr(s) for s in streams]) if streams is not None else None
+    check((L.cholamd_comm_create_local if local else L.cholamd_comm_create_all)(hd, n, hc), "cholamd_comm_create")
+    try:
+        check(L.cholamd_factor_multi(hd, ha, hc, n, hs), "cholamd_factor_multi")
+        for d in devs:
+            d.sync()
+    finally:
+        for c in hc:
+            L.cholamd_comm_destroy(c)

@@ -132,6 +132,13 @@ class Plan:
         check(self.L.cholamd_plan_level_work_counts(self.h, level, rank, world, out.ctypes.data), "cholamd_plan_level_work_counts")
         return tuple(int(v) for v in out)
 
+    def level_work_volume(self, level, rank=0, world=1, dist_top=2):
+        """(POTRF columns, TRSM elements, update volume, broadcast entries, broadcast doubles, broadcast checksum) of one level's
+        lists for (rank, world) with the top levels replicated (dist_top=0), distributed by column blocks (1) or automatic (2)."""
+        out = np.zeros(6, dtype=np.int64)
+        check(self.L.cholamd_plan_level_work_volume(self.h, level, rank, world, dist_top, out.ctypes.data), "cholamd_plan_level_work_volume")
+        return tuple(int(v) for v in out)
+
     def program_check(self, follow=True, workers=64):
         """Host-side self-check of the one-launch program (raises CholamdError on a dead-lock or a mismatch)."""
         check(self.L.cholamd_plan_program_check(self.h, int(follow), int(workers)), "cholamd_plan_program_check")

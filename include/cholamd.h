@@ -175,6 +175,10 @@ int cholamd_plan_fill_host_part(const cholamd_plan *p, double *arena, int rank, 
 /* sizes of the device work lists of one tree level for (rank, world): potrf descriptors, trsm
  * strips, update tasks, update sources */
 int cholamd_plan_level_work_counts(const cholamd_plan *p, int level, int rank, int world, int out[4]);
+/* volumes of the same lists with the top levels replicated (dist_top = 0) or distributed by column blocks (1; 2 = automatic):
+ * POTRF columns, TRSM elements, update volume (target elements x source depth), broadcast entries, broadcast doubles, checksum
+ * of the broadcast list (the same on every rank) */
+int cholamd_plan_level_work_volume(const cholamd_plan *p, int level, int rank, int world, int dist_top, int64_t out[6]);
 /* host-side self-check of the one-launch program cholamd_factor() runs for small problems on one GPU (chol_build_program):
  * simulated with `workers` resident workgroups and every counter raised only on job completion, no job may starve; counters
  * total up; pivot blocks and TRSM rows equal those of the per-level lists.  0 = consistent, otherwise cholamd_last_error()
@@ -276,7 +280,8 @@ int cholamd_factor_info(cholamd_device *d, int *sep_out);
  * CHOLAMD_MT_MIN_TILES, CHOLAMD_NO_CELLS, CHOLAMD_SOLVE_REFERENCE_SHAPE: read once, there); names: "split_min",
  * "split_nb", "fuse", "fuse_update_max", "mt_min_tiles", "cells", "solve_reference_shape", "program" (the whole factorisation
  * of a small problem as one launch; CHOLAMD_NO_PROGRAM), "follow" (its pivot blocks follow their children's TRSM strips;
- * CHOLAMD_NO_FOLLOW).  Rebuilds the work lists. */
+ * CHOLAMD_NO_FOLLOW), "super_blocks", "dist_top" (0 / 1 / 2 = automatic: top levels of a partitioned run distributed by column
+ * blocks, see Multi-GPU below; CHOLAMD_DIST_TOP).  Rebuilds the work lists. */
 int cholamd_device_set_option(cholamd_device *d, const char *name, int value);
 /* Solve phase, mmat.rg:1364-1495: b and x in ORIGINAL dof order (device pointers, n doubles).
  * The off-diagonal blocks accumulate into the vector with hardware fp64 atomics, so x agrees from run to run to
@@ -312,7 +317,12 @@ int cholamd_device_event_overhead(cholamd_device *d, void *stream, float *ms_out
 /* the subtrees under its level-d separator (cholamd_device_set_partition), its contributions to  */
 /* the shared top of the tree accumulate in its own copy of the arena TAIL (the top panels are    */
 /* contiguous: offset cholamd_device_tail_offset), ONE RCCL all-reduce (sum, fp64) over that tail  */
-/* is the extend-add exchange, then every rank factors the top levels.  libcholamd links RCCL;     */
+/* is the extend-add exchange, then the top levels: REPLICATED on every rank (small roots: they   */
+/* are a latency chain) or, option "dist_top" (automatic from a root separator of 1024 columns),  */
+/* DISTRIBUTED by column blocks: block b of a top separator belongs to rank (b + heap index) mod  */
+/* world; its owner factors it and solves the rows below it, ncclBroadcast carries the block to    */
+/* every rank, every rank applies the trailing update and the extend-add to the column blocks IT    */
+/* owns (one owner per element, sources in program order: deterministic).  libcholamd links RCCL;   */
 /* the communicator is an ncclComm_t made here or adopted from the caller.                         */
 /* ----------------------------------------------------------------------------------------- */
 typedef struct cholamd_comm cholamd_comm;
@@ -320,6 +330,9 @@ typedef struct cholamd_comm cholamd_comm;
 int cholamd_comm_unique_id(char id[CHOLAMD_UNIQUE_ID_BYTES]);   /* ncclGetUniqueId: rank 0 calls it and hands the bytes to every rank */
 int cholamd_comm_create(cholamd_device *d, int world, int rank, const char id[CHOLAMD_UNIQUE_ID_BYTES], cholamd_comm **out); /* ncclCommInitRank on d's GPU (collective) */
 int cholamd_comm_create_all(cholamd_device *const *devs, int n, cholamd_comm **out /* n handles */); /* one process, n GPUs: ncclCommInitAll */
+/* one process, n rank objects, NO RCCL: device-side ordered sum of the tails + peer copies, events between the ranks' streams.
+ * The ranks may share a device (the one-GPU test box runs world 2 ... 8 this way).  For cholamd_factor_multi only. */
+int cholamd_comm_create_local(cholamd_device *const *devs, int n, cholamd_comm **out /* n handles */);
 int cholamd_comm_adopt(void *nccl_comm /* ncclComm_t */, int world, int rank, cholamd_comm **out);  /* the caller keeps ownership of the ncclComm_t */
 void cholamd_comm_destroy(cholamd_comm *c);
 int cholamd_comm_allreduce(cholamd_comm *c, double *d_buf, int64_t count, void *stream); /* in-place fp64 sum (ncclAllReduce), asynchronous on `stream` */

@@ -47,8 +47,18 @@ def _cpu_worker(rank, world, port, case, q):
     ok_lists = bool(torch.equal(below[d:, :2], whole[d:, :2])) and bool(torch.equal(counts[:d], whole[:d]))
     # update sources below the cut are partitioned by source separator: their counts add up too
     ok_src = bool(torch.equal(below[d:, 3], whole[d:, 3]))
+    # top levels distributed by column blocks (dist_top = 1): pivot columns, solved elements and update volume of the ranks add up
+    # to the undivided lists'; every rank holds the same broadcast sequence
+    vol = torch.tensor([plan.level_work_volume(l, rank, world, 1) for l in range(d)], dtype=torch.int64).reshape(d, 6)
+    tot = vol[:, :3].clone()
+    dist.all_reduce(tot)
+    lo, hi = vol[:, 3:].clone(), vol[:, 3:].clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    one = torch.tensor([plan.level_work_volume(l, 0, 1, 0)[:3] for l in range(d)], dtype=torch.int64).reshape(d, 3)
+    ok_dist = bool(torch.equal(tot, one)) and bool(torch.equal(lo, hi)) and bool((vol[:, 3] > 0).all())
     if rank == 0:
-        q.put((ok_tail, ok_lists, ok_src, tail))
+        q.put((ok_tail, ok_lists, ok_src and ok_dist, tail))
     dist.destroy_process_group()
 
 
@@ -65,6 +75,33 @@ def test_partition_logic_gloo(case, world):
         assert p.exitcode == 0
     ok_tail, ok_lists, ok_src, tail = q.get()
     assert ok_tail and ok_lists and ok_src and tail > 0
+
+
+@pytest.mark.parametrize("dims,world", [((20, 20, 20, 4, 32), 2), ((20, 20, 20, 4, 32), 4), ((30, 30, 10, 5, 32), 8)])
+def test_distributed_top_lists_tile_the_schedule(dims, world):
+    """Generated problems with top separators of several column blocks: under dist_top the ranks' POTRF blocks, TRSM strips and
+    update targets of the top levels partition the undivided lists (volumes add up), each rank's broadcast list is the same,
+    and what is broadcast is every column block of every top panel exactly once."""
+    import cholesky_amd as ca
+    plan = ca.Problem(*dims).plan()
+    d = world.bit_length() - 1
+    sizes, tree = plan.sep_sizes, plan.tree
+    for lvl in range(d):
+        vols = np.array([plan.level_work_volume(lvl, r, world, 1) for r in range(world)], dtype=np.int64)
+        one = np.array(plan.level_work_volume(lvl, 0, 1, 0), dtype=np.int64)
+        assert np.array_equal(vols[:, :3].sum(axis=0), one[:3])
+        assert (vols[:, 3:] == vols[0, 3:]).all()
+        assert one[3] == 0
+        rep = np.array(plan.level_work_volume(lvl, world - 1, world, 0), dtype=np.int64)
+        assert np.array_equal(rep[:3], one[:3]) and rep[3] == 0  # replicated top: every rank does all of it
+        # the owners really differ: no rank holds all the pivot columns of a level with more than one column block
+        if vols[0, 3] > 1:
+            assert vols[:, 0].max() < one[0]
+    # below the cut nothing changes
+    for lvl in range(d, plan.levels):
+        for r in range(world):
+            assert plan.level_work_volume(lvl, r, world, 1) == plan.level_work_volume(lvl, r, world, 0)
+    assert sizes[tree[1]] > 144  # the root really has several column blocks
 
 
 def _gpu_worker(rank, world, port, case, q):
@@ -190,6 +227,48 @@ def test_sharded_world8_in_one_process():
     assert np.abs(_assemble(plan, parts, world, ref) - ref).max() <= 1e-12
     for r in range(1, world):
         assert np.array_equal(parts[r][tail:], parts[0][tail:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,world,dist_top", [("lapl_3375x3375", 2, 1), ("lapl_3375x3375", 8, 1), ("lapl_3375x3375", 4, 0),
+                                                 ((20, 20, 20, 4, 32), 4, 1), ((24, 24, 24, 5, 32), 8, 1), ((36, 36, 30, 3, 64), 2, 2)])
+def test_factor_multi_distributed_top(case, world, dist_top):
+    """cholamd_factor_multi over a LOCAL communicator (the rank objects share the one GPU): subtree levels, ordered device-side sum
+    of the tails, then the top levels distributed by column blocks (owner POTRF + TRSM, broadcast, owned updates) -- or
+    replicated (dist_top 0) -- against the single-GPU factor; every rank ends with the same complete top."""
+    import cholesky_amd as ca
+    from cholesky_amd import parallel
+    from cholesky_amd.device import factor_multi
+    plan = ca.Plan(*case_paths(case)[:3]) if isinstance(case, str) else ca.Problem(*case).plan()
+    one = ca.Device(plan, 0)
+    ref_t = one.new_arena()
+    one.fill(ref_t)
+    one.factor(ref_t)
+    one.sync()
+    assert one.info() == (0, 0)
+    ref = ref_t.cpu().numpy()
+    del ref_t
+    tail = parallel.tail_offset(plan, world)
+    devs, arenas = [], []
+    for r in range(world):
+        dev = ca.Device(plan, 0)
+        dev.set_option("dist_top", dist_top)
+        dev.set_partition(r, world)
+        a = dev.new_arena()
+        dev.fill(a)
+        devs.append(dev)
+        arenas.append(a)
+    if dist_top == 2:
+        assert plan.level_work_volume(0, 0, world, 2)[3] > 0  # root >= 1024 columns: distributed automatically
+    factor_multi(devs, arenas, local=True)
+    for dev in devs:
+        assert dev.info() == (0, 0)
+    scale = max(1.0, np.abs(ref).max())
+    top0 = arenas[0][tail:].cpu().numpy()
+    for r in range(1, world):
+        assert np.array_equal(arenas[r][tail:].cpu().numpy(), top0)
+    parts = [a.cpu().numpy() for a in arenas]
+    assert np.abs(_assemble(plan, parts, world, ref) - ref).max() <= 1e-12 * scale
 
 
 @pytest.mark.gpu
