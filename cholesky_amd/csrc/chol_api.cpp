@@ -245,6 +245,7 @@ extern "C" int cholamd_device_set_option(cholamd_device *d, const char *name, in
   else if (n == "program") d->opt.program = value != 0;
   else if (n == "follow") d->opt.follow = value != 0;
   else if (n == "super_blocks") d->opt.super_blocks = value;
+  else if (n == "follow_tail") d->opt.follow_tail = value;
   else if (n == "dist_top") d->opt.dist_top = value;
   else if (n == "solve_reference_shape") { d->solve_reference_shape = value != 0; rebuild = false; }
   else { chol_set_error("unknown option '%s'", n.c_str()); return CHOLAMD_ERR_ARG; }
@@ -434,10 +435,11 @@ extern "C" int cholamd_device_program_trace(cholamd_device *d, double *d_arena, 
   if (!d->prog_ready) { chol_set_error("no program launch for this problem / these options"); return CHOLAMD_ERR_ARG; }
   *njobs_out = d->n_job;
   if (cap < (int64_t)5 * d->n_job) return 0;
-  HIPCHK(hipMalloc((void **)&d->trace, (size_t)4 * d->n_job * sizeof(unsigned long long)));
-  HIPCHK(hipMemset(d->trace, 0, (size_t)4 * d->n_job * sizeof(unsigned long long)));
+  // 4 stamps per job, then 48 per job for the followers (own tiles in, items, the time each item's round began)
+  HIPCHK(hipMalloc((void **)&d->trace, (size_t)52 * d->n_job * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(d->trace, 0, (size_t)52 * d->n_job * sizeof(unsigned long long)));
   int rc = cholamd_factor(d, d_arena, stream);
-  std::vector<unsigned long long> h((size_t)4 * d->n_job);
+  std::vector<unsigned long long> h((size_t)52 * d->n_job);
   if (!rc) {
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     HIPCHK(hipMemcpy(h.data(), d->trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -451,6 +453,18 @@ extern "C" int cholamd_device_program_trace(cholamd_device *d, double *d_arena, 
     out[5 * j] = d->jobs_host[j].kind + (d->jobs_host[j].kind == 0 && d->jobs_host[j].n_ext > 0 ? 10 : 0);
     for (int q = 0; q < 3; q++) out[5 * j + 1 + q] = (int64_t)(h[4 * j + q] - t0);
     out[5 * j + 4] = (int64_t)h[4 * j + 3];
+  }
+  if (const char *path = getenv("CHOLAMD_TRACE_FOLLOW")) { // diagnostic: the followers' per-item stamps as text (us since the first job was drawn)
+    if (FILE *fp = fopen(path, "w")) {
+      for (int j = 0; j < d->n_job; j++) {
+        const unsigned long long *x = &h[(size_t)4 * d->n_job + (size_t)48 * j];
+        if (d->jobs_host[j].kind != 0 || x[1] == 0) continue;
+        fprintf(fp, "job %d items %llu own-tiles-wait-over %.1f rounds:", j, x[1], x[0] ? (double)(x[0] - t0) * 0.01 : -1.0);
+        for (unsigned long long i = 0; i < x[1] && i < 44; i++) if (x[2 + i]) fprintf(fp, " %llu:%.1f", i, (double)(x[2 + i] - t0) * 0.01);
+        fprintf(fp, "\n");
+      }
+      fclose(fp);
+    }
   }
   return 0;
 }

@@ -483,15 +483,15 @@ __device__ __forceinline__ double rsqrt_nr(double d)
 // myinv = 1 / L(row, row).  Returns the first non-positive pivot (1-based) or 0.
 __device__ __forceinline__ int chol16_rows(double (&a)[TS], double &myinv, int r15)
 {
-  int bad = 0;
   myinv = 0.0;
+  double dd[TS]; // the pivots (wave uniform: SGPRs)
 #pragma unroll
   for (int j = 0; j < TS; ++j) {
     const double d = readlane_f64(a[j], j);
+    dd[j] = d;
     double akj[TS];
 #pragma unroll
     for (int k = j + 1; k < TS; ++k) akj[k] = readlane_f64(a[j], k); // unscaled column j, overlaps the rsqrt chain
-    if (!(d > 0.0) && bad == 0) bad = j + 1;
     const double rv = rsqrt_nr(d);
     const double r = readlane_f64(rv, 0); // wave uniform: keep it in SGPRs
     myinv = (r15 == j) ? rv : myinv;
@@ -500,6 +500,15 @@ __device__ __forceinline__ int chol16_rows(double (&a)[TS], double &myinv, int r
 #pragma unroll
     for (int k = j + 1; k < TS; ++k) a[k] = fma(-t, akj[k], a[k]);
     __builtin_amdgcn_sched_barrier(0); // bound the live range of the broadcast scalars to one column
+  }
+  // A pivot that is not positive (or NaN) turns its column, and through the rank-1 update every later column of every row, into
+  // NaN: the LAST pivot tells whether any failed, and only then is the first one looked for (sixteen compare / select rounds
+  // on the scalar unit otherwise sit on the pivot chain of every step)
+  int bad = 0;
+  if (!(dd[TS - 1] > 0.0)) {
+#pragma unroll
+    for (int j = 0; j < TS; ++j)
+      if (!(dd[j] > 0.0) && bad == 0) bad = j + 1;
   }
   return bad;
 }
@@ -586,8 +595,12 @@ __device__ __forceinline__ void own_block_row(const double (&a)[TS], int r15, do
 // indices 3 and 7, "light") get 3 tiles for every 5 of the nine others: tiles are dealt in rounds of
 // 11, 9, 11, 9, 11 (= 51 per cycle; 153 tiles = 3 cycles -> 15 per heavy wave, 9 per light wave).
 // Slots grow with idx for every wave, so a wave's active tiles (column > k) are a suffix of its slots.
-__device__ __forceinline__ void rr_owner(int idx, int &w, int &slot)
+#ifndef RR_HEAVY_ONLY
+#define RR_HEAVY_ONLY 36 /* pivot blocks with at most this many register tiles (T <= 10) leave the factor wave's SIMD to the factor wave */
+#endif
+__device__ __forceinline__ void rr_owner(int idx, int ntl2, int &w, int &slot)
 {
+  if (ntl2 <= RR_HEAVY_ONLY) { const int off = idx % RR_NHEAVY; w = off + off / 3; slot = idx / RR_NHEAVY; return; }
   const int cyc = idx / 51, pos = idx % 51;
   const int round = pos < 11 ? 0 : pos < 20 ? 1 : pos < 31 ? 2 : pos < 40 ? 3 : 4;
   const int off = pos - (round == 0 ? 0 : round == 1 ? 11 : round == 2 ? 20 : round == 3 ? 31 : 40);
@@ -603,8 +616,9 @@ __device__ __forceinline__ void rr_owner(int idx, int &w, int &slot)
 __device__ __forceinline__ int rr_heavy_index(int w) { return (w & 3) == 3 ? -1 : w - (w >> 2); }
 // number of indices in [0, cnt) that rr_owner() gives to tile wave w (hw = rr_heavy_index(w)): the wave's
 // slots [0, rr_count) hold exactly those tiles
-__device__ __forceinline__ int rr_count(int cnt, int w, int hw)
+__device__ __forceinline__ int rr_count(int cnt, int ntl2, int w, int hw)
 {
+  if (ntl2 <= RR_HEAVY_ONLY) return hw >= 0 ? cnt / RR_NHEAVY + (cnt % RR_NHEAVY > hw) : 0;
   const int cyc = cnt / 51, rem = cnt % 51;
   if (hw >= 0) return cyc * 5 + (rem > hw) + (rem > 11 + hw) + (rem > 20 + hw) + (rem > 31 + hw) + (rem > 40 + hw);
   const int o = w == 3 ? 9 : 10;
@@ -758,86 +772,155 @@ template <bool PUB> __device__ __forceinline__ d4 load_tile(const double *A, int
 // the slots [0, FOLLOW_SLOTS) of rr_owner's deal, an external panel is FOLLOW_LOADS doubles per thread.
 #define FOLLOW_SLOTS 4
 #define FOLLOW_LOADS ((CHOL_FOLLOW_MAXT * TS * TS + RR_THREADS - 1) / RR_THREADS)
-struct follow_args { const chol_ext *ext; int n_ext; const int *ctr; const int *ctr_total; int epoch; };
-// leading column tiles of `x` whose strips have all published (every lane polls one counter: one round trip for all of them)
-__device__ __forceinline__ int ext_ready(const chol_ext &x, int nct, const int *ctr, const int *ctr_total, int epoch, int lane)
+__device__ __forceinline__ void wait_list(const chol_wait *__restrict__ wl, int n, const int *ctr, const int *__restrict__ ctr_total, int epoch, int lane, int *info)
+{
+  for (int b0 = 0; b0 < n; b0 += 64) {
+    int c = 0, need = 0;
+    const bool mine = b0 + lane < n;
+    if (mine) { const chol_wait wt = wl[b0 + lane]; c = wt.ctr; need = wt.value + epoch * ctr_total[wt.ctr]; }
+    for (int it = 0;; ++it) {
+      const bool ok = !mine || __hip_atomic_load(&ctr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+      if (!__ballot(!ok)) break;
+      if (it >= (1 << 15)) { if (lane == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); break; }
+      __builtin_amdgcn_s_sleep(32); // ~1 us between polls: a blocked job is not on anybody's critical path by less than that
+    }
+  }
+}
+// one look at a wait list: true if every entry holds (n <= 64)
+__device__ __forceinline__ bool wait_list_holds(const chol_wait *__restrict__ wl, int n, const int *ctr, const int *__restrict__ ctr_total, int epoch, int lane)
 {
   bool ok = true;
-  if (lane < nct) {
-    const int c = x.chan + lane;
-    ok = __hip_atomic_load(&ctr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch * ctr_total[c] >= x.nstrip;
+  for (int b0 = 0; b0 < n; b0 += 64)
+    if (b0 + lane < n) { const chol_wait wt = wl[b0 + lane]; ok = ok && __hip_atomic_load(&ctr[wt.ctr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wt.value + epoch * ctr_total[wt.ctr]; }
+  return !__ballot(!ok);
+}
+struct follow_args { const chol_ext *ext; int n_ext; const int *ctr; const int *ctr_total; int epoch; const chol_wait *wl; int n_wl; unsigned long long *stamp, *xstamp; };
+// followed column tiles from item `from` on whose strips have all published: every lane polls one item's counter (one round trip)
+__device__ __forceinline__ int ext_ready(const follow_args &f, int from, int lane)
+{
+  bool ok = true;
+  if (from + lane < f.n_ext) {
+    const int c = f.ext[from + lane].ctr;
+    ok = __hip_atomic_load(&f.ctr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - f.epoch * f.ctr_total[c] >= f.ext[from + lane].need;
   }
   const unsigned long long notok = __ballot(!ok);
-  return notok ? __builtin_ctzll(notok) : nct;
+  const int lead = notok ? __builtin_ctzll(notok) : 64;
+  return min(from + lead, f.n_ext);
 }
-template <bool UPD>
+template <bool UPD, bool PUB>
 __device__ __forceinline__ void follow_external(const double *__restrict__ base, const follow_args f, int T, int n, double *sE, d4 (&tile)[11], d4 (&stage)[3],
-                                                const int (&ijp)[12], int w, int lane, int tid, int *info)
+                                                const int (&ijp)[12], int w, int lane, int tid, int *info, const double *A, int lda, int r15, int g)
 {
   const int lp = lane; // accumulator layout: register q of lane l at q * 64 + l
   int buf = 0;
-  for (int xi = 0; xi < f.n_ext; ++xi) {
-    const chol_ext x = f.ext[xi];
-    const int nct = (x.k + TS - 1) / TS;
-    const double *src = base + x.off;
-    // Column tiles are consumed in order.  `ready` = leading column tiles known to be published; the poll for more is issued
-    // before the barrier and update of the tile at hand and read after them (its round trip is off the step), and the loads of
-    // tile ee + 1 are issued before the update with tile ee whenever it is known to be ready.
-    int ready = 0, loaded = -1;
-    double va[FOLLOW_LOADS];
-#define EXT_LOAD(E_)                                                                                                 \
-  _Pragma("unroll") for (int it = 0; it < FOLLOW_LOADS; ++it) {                                                      \
-    const int idx = tid + it * RR_THREADS;                                                                           \
-    const int row = (idx >> 8) * TS + (idx & 15), col = (E_) * TS + ((idx >> 4) & 15);                               \
-    va[it] = (idx < T * TS * TS && row < n && col < x.k) ? gload<true>(&src[row + (int64_t)col * x.ld]) : 0.0;       \
+  // Column tiles are consumed in the order of the list, TWO per round where two fit an LDS buffer (T <= 8) -- a column tile of a wide
+  // follower is 16 KB handed over by other workgroups, and one memory round trip per tile is what bounds a follower that has fallen
+  // behind its sources -- except the last two, which go one by one (the follower's start hangs on them).  The grouping is a function
+  // of the list alone: every wave takes the same rounds (they poll for themselves), and a pair is the same sequence of MFMAs on the
+  // same accumulators as two single rounds.  `ready` = leading items known to be published; the poll for more is issued before the
+  // barrier and update of the round at hand and read after them, and the loads of the next round are issued before the update
+  // whenever all of it is known to be ready.
+  int ready = 0, ng = 0; // ng: items of the round starting at i whose loads are in flight (0 = not issued)
+  double va[FOLLOW_LOADS], vb[FOLLOW_LOADS];
+  const int pair_lim = 2 * T <= RR_MAXT ? f.n_ext - 2 : 0; // items [i, i + 1] form a round while i + 1 < pair_lim
+#define EXT_ROUND(I_) ((I_) + 1 < pair_lim ? 2 : 1)
+#define EXT_LOAD(I_, V_)                                                                                             \
+  {                                                                                                                  \
+    const chol_ext xl_ = f.ext[I_];                                                                                  \
+    const double *src_ = base + xl_.off;                                                                             \
+    _Pragma("unroll") for (int it = 0; it < FOLLOW_LOADS; ++it) {                                                    \
+      const int idx = tid + it * RR_THREADS;                                                                         \
+      const int row = (idx >> 8) * TS + (idx & 15), col = (idx >> 4) & 15;                                           \
+      V_[it] = (idx < T * TS * TS && row < n && col < xl_.ncol) ? gload<true>(&src_[row + (int64_t)col * xl_.ld]) : 0.0; \
+    }                                                                                                                \
   }
-    for (int ee = 0; ee < nct; ++ee) {
-      if (ready <= ee) {
-        ready = ext_ready(x, nct, f.ctr, f.ctr_total, f.epoch, lane);
-        for (int it = 0; ready <= ee; ++it) { // bounded like wait_progress: a stall fails the factorisation through info
-          if (it >= (1 << 16)) { if (lane == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); ready = nct; break; }
-          __builtin_amdgcn_s_sleep(4);
-          ready = ext_ready(x, nct, f.ctr, f.ctr_total, f.epoch, lane);
-        }
-      }
-      if (loaded != ee) { EXT_LOAD(ee); }
-      double *sB = sE + buf * (RR_MAXT * TS * TS);
-#pragma unroll
-      for (int it = 0; it < FOLLOW_LOADS; ++it) {
-        const int idx = tid + it * RR_THREADS;
-        if (idx < T * TS * TS) sB[idx] = va[it];
-      }
-      int pv = 0, pneed = 0;
-      bool polled = false;
-      if (ee + 1 < ready) { EXT_LOAD(ee + 1); loaded = ee + 1; }
-      else if (ee + 1 < nct) { // ask now, look after the update
-        polled = true;
-        if (lane < nct) { const int c = x.chan + lane; pv = __hip_atomic_load(&f.ctr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pneed = f.epoch * f.ctr_total[c] + x.nstrip; }
-      }
+#define EXT_LOAD_ROUND(I_)                                                                                           \
+  {                                                                                                                  \
+    EXT_LOAD(I_, va);                                                                                                \
+    ng = EXT_ROUND(I_);                                                                                              \
+    if (ng == 2) { EXT_LOAD((I_) + 1, vb); }                                                                         \
+  }
+#define EXT_UPDATE(acc_, ti_, tj_)                                                                                   \
+  {                                                                                                                  \
+    _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                                 \
+      acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(sB[(tj_) * (TS * TS) + st * 64 + lp], -sB[(ti_) * (TS * TS) + st * 64 + lp], acc_, 0, 0, 0); \
+    if (G == 2) {                                                                                                    \
+      _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                               \
+        acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(sB2[(tj_) * (TS * TS) + st * 64 + lp], -sB2[(ti_) * (TS * TS) + st * 64 + lp], acc_, 0, 0, 0); \
+    }                                                                                                                \
+  }
+  for (int i = 0; i < f.n_ext;) {
+    if (f.n_wl > 0 && i == f.n_ext - 1) { // the follower's own tiles, before the last followed column tile
+      if (!UPD) wait_list(f.wl, f.n_wl, f.ctr, f.ctr_total, f.epoch, lane, info); // the factor wave polls
+      if (!UPD && f.xstamp && lane == 0) f.xstamp[0] = __builtin_amdgcn_s_memrealtime();
       lds_barrier();
       if (UPD) {
-#define EXT_UPDATE(acc_, ti_, tj_)                                                                                   \
-  _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                                   \
-    acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(sB[(tj_) * (TS * TS) + st * 64 + lp], -sB[(ti_) * (TS * TS) + st * 64 + lp], acc_, 0, 0, 0);
+        int rx = r15, gx = g; // opaque here: the addresses of these loads are invariant in the loop around them, and hoisting them spills
+        asm volatile("" : "+v"(rx), "+v"(gx));
 #pragma unroll
-        for (int it = 0; it < 3; ++it) { // the tiles of columns 0 and 1 (parked in LDS by the prologue later on)
-          const int u = w + it * RR_NW;
-          if (u < 2 * T - 1) { const int tj = u < T ? 0 : 1, ti = u < T ? u : u - T + 1; EXT_UPDATE(stage[it], ti, tj); }
+        for (int it = 0; it < 3; ++it) {
+          const int u = min(w + it * RR_NW, 2 * T - 2);
+          stage[it] += load_tile<PUB>(A, lda, n, u < T ? u : u - T + 1, u < T ? 0 : 1, rx, gx);
         }
+        __builtin_amdgcn_sched_barrier(0); // two batches of loads: all 28 values and their addresses at once do not fit the registers
 #pragma unroll
         for (int s = 0; s < FOLLOW_SLOTS; ++s)
-          if (ijp[s] != 0xffff) { const int ti = ijp[s] & 0xff, tj = ijp[s] >> 8; EXT_UPDATE(tile[s], ti, tj); }
-#undef EXT_UPDATE
-      }
-      buf ^= 1;
-      if (polled) {
-        const unsigned long long notok = __ballot(lane < nct && pv < pneed);
-        const int r2 = notok ? __builtin_ctzll(notok) : nct;
-        ready = r2 > ready ? r2 : ready;
+          if (ijp[s] != 0xffff) tile[s] += load_tile<PUB>(A, lda, n, ijp[s] & 0xff, ijp[s] >> 8, rx, gx);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-#undef EXT_LOAD
+    if (ng == 0) {
+      const int need = i + EXT_ROUND(i);
+      if (ready < need) {
+        ready = ext_ready(f, i, lane);
+        for (int it = 0; ready < need; ++it) { // bounded like wait_progress: a stall fails the factorisation through info
+          if (it >= (1 << 16)) { if (lane == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); ready = f.n_ext; break; }
+          __builtin_amdgcn_s_sleep(4);
+          ready = ext_ready(f, i, lane);
+        }
+      }
+      EXT_LOAD_ROUND(i);
+    }
+    const int G = ng;
+    if (!UPD && f.xstamp && lane == 0 && i < 44) { f.xstamp[1] = f.n_ext; f.xstamp[2 + i] = __builtin_amdgcn_s_memrealtime(); }
+    double *sB = sE + buf * (RR_MAXT * TS * TS), *sB2 = sB + T * TS * TS;
+#pragma unroll
+    for (int it = 0; it < FOLLOW_LOADS; ++it) {
+      const int idx = tid + it * RR_THREADS;
+      if (idx < T * TS * TS) { sB[idx] = va[it]; if (G == 2) sB2[idx] = vb[it]; }
+    }
+    const int j = i + G; // first item of the next round
+    ng = 0;
+    int pv = 0, pneed = 0;
+    bool polled = false;
+    if (j < f.n_ext && j + EXT_ROUND(j) <= ready) { EXT_LOAD_ROUND(j); }
+    else if (j < f.n_ext) { // ask now, look after the update
+      polled = true;
+      if (j + lane < f.n_ext) { const int c = f.ext[j + lane].ctr; pv = __hip_atomic_load(&f.ctr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pneed = f.epoch * f.ctr_total[c] + f.ext[j + lane].need; }
+    }
+    lds_barrier();
+    if (UPD) {
+#pragma unroll
+      for (int it = 0; it < 3; ++it) { // the tiles of columns 0 and 1 (parked in LDS by the prologue later on)
+        const int u = w + it * RR_NW;
+        if (u < 2 * T - 1) { const int tj = u < T ? 0 : 1, ti = u < T ? u : u - T + 1; EXT_UPDATE(stage[it], ti, tj); }
+      }
+#pragma unroll
+      for (int s = 0; s < FOLLOW_SLOTS; ++s)
+        if (ijp[s] != 0xffff) { const int ti = ijp[s] & 0xff, tj = ijp[s] >> 8; EXT_UPDATE(tile[s], ti, tj); }
+    }
+    buf ^= 1;
+    if (polled) {
+      const unsigned long long notok = __ballot(j + lane < f.n_ext && pv < pneed);
+      const int r2 = min(j + (notok ? __builtin_ctzll(notok) : 64), f.n_ext);
+      ready = r2 > ready ? r2 : ready;
+    }
+    i = j;
   }
+#undef EXT_LOAD_ROUND
+#undef EXT_ROUND
+#undef EXT_UPDATE
+#undef EXT_LOAD
 }
 
 template <bool PUB, bool FOLLOW = false>
@@ -884,7 +967,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
   for (int t = tid + 2 * T - 1; t < ntl; t += RR_THREADS) {
     int ti, tj, ow, os;
     tile_of_index(t, T, ti, tj);
-    rr_owner(ntl - 1 - t, ow, os);
+    rr_owner(ntl - 1 - t, ntl2, ow, os);
     sIJ[os * RR_NW + ow] = (unsigned short)(ti | (tj << 8));
   }
   __syncthreads();
@@ -894,8 +977,9 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
     if (FOLLOW && fa.n_ext > 0) { // loads and barriers of the external panel steps (it owns no tile)
       d4 tdummy[RR_RSLOTS], sdummy[3];
       int idummy[RR_SLOTS];
-      follow_external<false>(base, fa, T, n, smem + RR_OFF_SOL, tdummy, sdummy, idummy, 0, lane, tid, info);
+      follow_external<false, PUB>(base, fa, T, n, smem + RR_OFF_SOL, tdummy, sdummy, idummy, 0, lane, tid, info, A, lda, r15, g);
       lds_barrier(); // the last panel has been read: the prologue may park column 1 in its place
+      if (fa.stamp && lane == 0) *fa.stamp = __builtin_amdgcn_s_memrealtime(); // diagnostic runs: the followed columns are in
     }
     __builtin_amdgcn_s_setprio(3);
     lds_wait_ge(cUpd, RR_NW); // prologue of the tile waves done: (0,0), (1,1) are in sDg, column 0 in sRaw
@@ -931,16 +1015,24 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       lds_set(fL, k + 1, lane);
       STAMPK(3);
       if (k + 1 >= T) break;
-      // ---- b. the two look-ahead tiles of step k-1's trailing update are in LDS (their owners do them first)
-      lds_wait_both_ge(fA, k + 1); // fA and fD in one 64-bit poll
-      STAMPK(4);
+      // ---- b. the two look-ahead tiles of step k-1's trailing update are in LDS (their owners do them first; by now they
+      //         have been for a while): the flag pair is read ahead of the tiles in the same batch of LDS reads (LDS executes a
+      //         wave's accesses in order), and only a flag that was not up yet costs a poll and a second read of the tiles
+      const long long fl = __hip_atomic_load((long long *)fA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // fA and fD: one 64-bit word
+      asm volatile("" ::: "memory");
+      d4 raw, dn;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { raw[q] = sRaw[k + 1][q * 64 + lp0]; dn[q] = sDg[(k + 1) & 1][q * 64 + lp0]; }
       // ---- c. solve (k+1, k) and publish it
       double wv[4];
 #pragma unroll
       for (int st = 0; st < 4; ++st) wv[st] = sLW[par][TS + 4 * st + g][r15];
-      d4 raw, dn;
+      if (__builtin_amdgcn_readfirstlane((int)fl) < k + 1 || __builtin_amdgcn_readfirstlane((int)(fl >> 32)) < k + 1) {
+        lds_wait_both_ge(fA, k + 1);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { raw[q] = sRaw[k + 1][q * 64 + lp0]; dn[q] = sDg[(k + 1) & 1][q * 64 + lp0]; }
+        for (int q = 0; q < 4; ++q) { raw[q] = sRaw[k + 1][q * 64 + lp0]; dn[q] = sDg[(k + 1) & 1][q * 64 + lp0]; }
+      }
+      STAMPK(4);
       const d4 p = solve16(raw, wv);
 #pragma unroll
       for (int q = 0; q < 4; ++q) sSol[par][k + 1][q * 64 + lp0] = p[q];
@@ -966,20 +1058,30 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
     //      Every load of the prologue is issued before the first wait: three tiles of columns 0 / 1 per wave at
     //      most (2 T - 1 <= 33 tiles over 11 waves), then the register tiles.
     d4 stage[3];
-    if (FOLLOW && fa.n_ext > 0) { // the block's own tiles first (their memory round trip overlaps the wait for the first followed
-                                  // column), the followed contributions on top
+    if (FOLLOW && fa.n_ext > 0) {
+      // A follower without waits of its own (no update job of an earlier phase writes its diagonal block: the parents of the
+      // leaves) loads its own tiles first -- their round trip overlaps the wait for the first followed column -- and puts the
+      // followed contributions on top.  One with waits starts from ZERO accumulators, consumes its children's columns as they
+      // arrive, and adds its own tiles just before the LAST followed column tile (follow_external: there its waits must hold;
+      // the load hides behind the wait for that column): it does not sit idle until its grandchildren's extend-add is through.
+      // Which of the two is fixed by the schedule, not by timing: the summation order is the same in every run.
+      const bool early = fa.n_wl == 0;
+      const d4 zero4 = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
       for (int it = 0; it < 3; ++it) {
         const int u = min(w + it * RR_NW, 2 * T - 2);
-        stage[it] = load_tile<PUB>(A, lda, n, u < T ? u : u - T + 1, u < T ? 0 : 1, r15, g);
+        stage[it] = zero4;
+        if (early) stage[it] = load_tile<PUB>(A, lda, n, u < T ? u : u - T + 1, u < T ? 0 : 1, r15, g);
       }
 #pragma unroll
-      for (int s = 0; s < RR_RSLOTS; ++s) {
-        d4 v = { 0.0, 0.0, 0.0, 0.0 };
-        if (ijp[s] != 0xffff) v = load_tile<PUB>(A, lda, n, ijp[s] & 0xff, ijp[s] >> 8, r15, g);
+      for (int s = 0; s < FOLLOW_SLOTS; ++s) { // a follower's block has at most CHOL_FOLLOW_MAXT column tiles: FOLLOW_SLOTS register tiles per wave
+        d4 v = zero4;
+        if (early && ijp[s] != 0xffff) v = load_tile<PUB>(A, lda, n, ijp[s] & 0xff, ijp[s] >> 8, r15, g);
         tile[s] = v;
       }
-      follow_external<true>(base, fa, T, n, smem + RR_OFF_SOL, tile, stage, ijp, w, lane, tid, info);
+      follow_external<true, PUB>(base, fa, T, n, smem + RR_OFF_SOL, tile, stage, ijp, w, lane, tid, info, A, lda, r15, g);
+#pragma unroll
+      for (int s = FOLLOW_SLOTS; s < RR_RSLOTS; ++s) tile[s] = zero4; // not live across the followed columns
       lds_barrier();
     } else {
 #pragma unroll
@@ -1086,7 +1188,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
         }
       }
       const int live = (T - k - 1) * (T - k) / 2;
-      const int top = rr_count(live < ntl2 ? live : ntl2, w, hw) - 1;
+      const int top = rr_count(live < ntl2 ? live : ntl2, ntl2, w, hw) - 1;
       // one tile: acc -= P(ti) P(tj)^T, then park it if this was its last update; true if it was parked
 #define RR_UPDATE(acc_, ti_, tj_)                                                                                  \
   {                                                                                                                \
@@ -1518,20 +1620,6 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_trsm(double *__restrict__ 
 // are ahead of it in the queue or for the strips of a source that the queue places within reach of the resident
 // workgroups (checked on the host: chol_program_check); every spin is bounded and fails the factorisation through info.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wait_list(const chol_wait *__restrict__ wl, int n, const int *ctr, const int *__restrict__ ctr_total, int epoch, int lane, int *info)
-{
-  for (int b0 = 0; b0 < n; b0 += 64) {
-    int c = 0, need = 0;
-    const bool mine = b0 + lane < n;
-    if (mine) { const chol_wait wt = wl[b0 + lane]; c = wt.ctr; need = wt.value + epoch * ctr_total[wt.ctr]; }
-    for (int it = 0;; ++it) {
-      const bool ok = !mine || __hip_atomic_load(&ctr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
-      if (!__ballot(!ok)) break;
-      if (it >= (1 << 15)) { if (lane == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); break; }
-      __builtin_amdgcn_s_sleep(32); // ~1 us between polls: a blocked job is not on anybody's critical path by less than that
-    }
-  }
-}
 __global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ base, double *__restrict__ ws, const chol_job *__restrict__ jobs, int njobs,
                                                         const chol_wait *__restrict__ waits, const chol_potrf_desc *__restrict__ pdescs,
                                                         const chol_trsm_desc *__restrict__ tdescs, const chol_upd_task *__restrict__ tasks,
@@ -1567,15 +1655,15 @@ __global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ bas
       for (int sx = tpre.src_begin; sx < tpre.src_end; ++sx) touch += srcs[sx].k;
       asm volatile("" :: "s"(touch));
     }
-    if (jb.n_wait > 0) {
+    if (jb.n_wait > 0 && !(jb.kind == 0 && jb.n_ext > 0)) { // a follower looks at its waits itself (potrf_rr_body)
       if (wave == 0) wait_list(waits + jb.wait_first, jb.n_wait, ctr, ctr_total, epoch, lane, info);
       lds_barrier();
     }
-    if (trace && tid == 0) trace[4 * j + 1] = __builtin_amdgcn_s_memrealtime();
+    if (trace && tid == 0) trace[4 * j + 1] = __builtin_amdgcn_s_memrealtime(); // a follower overwrites it when its followed columns are in
     if (jb.kind == 0) {
       const chol_potrf_desc pd = pdescs[jb.first];
       follow_args fa;
-      fa.ext = exts + jb.ext_first; fa.n_ext = jb.n_ext; fa.ctr = ctr; fa.ctr_total = ctr_total; fa.epoch = epoch;
+      fa.ext = exts + jb.ext_first; fa.n_ext = jb.n_ext; fa.ctr = ctr; fa.ctr_total = ctr_total; fa.epoch = epoch; fa.wl = waits + jb.wait_first; fa.n_wl = jb.n_wait; fa.stamp = trace ? &trace[4 * j + 1] : nullptr; fa.xstamp = trace ? &trace[4 * njobs + 48 * j] : nullptr;
       potrf_rr_body<true, true>(base, ws, pd, info, ctr + pd.ctr, epoch * ctr_total[pd.ctr], smem, fa, tid);
     } else if (jb.kind == 1) {
       double (*sX)[3][TS * TS] = (double (*)[3][TS * TS])smem;

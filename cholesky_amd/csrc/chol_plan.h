@@ -21,6 +21,8 @@ extern "C" {
 
 #define CHOL_NB 16        /* diagonal-block width of the POTRF/TRSM kernels = one fp64 MFMA tile */
 #define CHOL_RR_MAXN 272  /* largest pivot the register-resident kernels take (17 tiles) */
+#define CHOL_FOLLOW_ALL_MAXT 4 /* followers of at most this many column tiles take every column of their sources themselves */
+#define CHOL_FOLLOW_TAIL 4     /* default of option follow_tail */
 #define CHOL_FOLLOW_MAXT 10 /* most column tiles of a pivot block that follows its sources inside the program launch (chol_kernels.hip, follow_external) */
 #define CHOL32_MAXN 128   /* widest pivot block of the fp32 path: its lower triangle is factored out of LDS (chol_kernels_f32.hip) */
 
@@ -96,10 +98,12 @@ typedef struct {
   int mode, pad;       /* update: 0 = one wave per task (light tasks, twelve at a time), 1 = four waves per task splitting K / the sources
                         * (heavy tasks, three at a time) */
 } chol_job;
-typedef struct {       /* one followed source: (rows of the follower's block) x (columns of a source pivot block) */
-  int64_t off;         /* first of those rows in the first column of the source block */
-  int ld, k;           /* leading dimension of the source panel, columns of the source block */
-  int chan, nstrip;    /* counter chan + e is raised by every one of the nstrip strips covering the rows once it has stored column tile e */
+typedef struct {       /* one followed column tile: (rows of the follower's block) x (16 columns of a source pivot block).  A follower's items are
+                        * queued in the order their columns are EXPECTED to arrive (position of the column in its source's pivot chain: the
+                        * columns of two children that run side by side alternate) -- a fixed order: the sums are the same in every run */
+  int64_t off;         /* first of the follower's rows in the first column of the tile */
+  int ld, ncol;        /* leading dimension of the source panel, columns of the tile (<= 16) */
+  int ctr, need;       /* counter raised by every one of the `need` strips covering the rows once it has stored this column tile */
 } chol_ext;
 typedef struct {
   int n_job; chol_job *job;
@@ -132,6 +136,8 @@ typedef struct {
   int follow;               /* ... in which pivot blocks follow their children's / predecessor's TRSM strips */
   int dist_top;             /* 0 / 1 / 2 = auto (CHOL_DIST_MIN); world > 1: the levels above the cut are distributed over the ranks by column blocks (owner factors and
                              * solves a block, broadcasts it, every rank updates the column blocks it owns) instead of replicated */
+  int follow_tail;          /* a follower wider than CHOL_FOLLOW_ALL_MAXT column tiles takes only the LAST follow_tail column tiles of each source
+                             * itself; the columns before them reach its diagonal block through update jobs on other CUs (0: follows everything) */
   int super_blocks;         /* column blocks per super-block of a wide pivot: the trailing matrix beyond a super-block gets one update of
                              * rank super_blocks * (block width) instead of one per block */
 } chol_sched_opts;

@@ -84,7 +84,7 @@ static int env_int(const char *name, int dflt) { const char *e = getenv(name); r
 void chol_sched_opts_default(chol_sched_opts *o)
 {
   o->split_min = CHOL_SPLIT_MIN; o->split_nb = CHOL_SPLIT_NB; o->fuse = 1; o->fuse_update_max = CHOL_FUSE_UPDATE_MAX;
-  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2;
+  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL;
 }
 void chol_sched_opts_from_env(chol_sched_opts *o)
 {
@@ -99,6 +99,7 @@ void chol_sched_opts_from_env(chol_sched_opts *o)
   o->follow = !env_int("CHOLAMD_NO_FOLLOW", 0);
   o->dist_top = env_int("CHOLAMD_DIST_TOP", o->dist_top);
   o->super_blocks = env_int("CHOLAMD_SUPER_BLOCKS", o->super_blocks);
+  o->follow_tail = env_int("CHOLAMD_FOLLOW_TAIL", o->follow_tail);
 }
 static int split_nb(const chol_sched_opts *o) { int v = o->split_nb; if (v > CHOL_RR_MAXN) v = CHOL_RR_MAXN; v = (v + 15) / 16 * 16; if (v < 16) v = 16; return v; }
 static int pivot_blocks(const chol_sched_opts *o, int n) { return n > o->split_min || n > CHOL_RR_MAXN ? (n + split_nb(o) - 1) / split_nb(o) : 1; }
@@ -621,6 +622,25 @@ static int add_ext(pbuild *P, chol_ext e)
   g->ext[g->n_ext] = e;
   return g->n_ext++;
 }
+/* the column tiles of one followed source block (k columns from `off`, counters chan + e) with the expected arrival position key0 + e */
+typedef struct { chol_ext x; int key, seq; } ext_item;
+static int cmp_ext_item(const void *a, const void *b)
+{
+  const ext_item *x = a, *y = b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->seq < y->seq ? -1 : (x->seq > y->seq);
+}
+static void push_ext_items(ext_item **items, int *n, int *cap, int64_t off, int ld, int k, int chan, int nstrip, int key0, int e_from)
+{
+  for (int e = e_from; e * CHOL_NB < k; e++) {
+    if (*n == *cap) { *cap = *cap ? 2 * *cap : 64; *items = realloc(*items, *cap * sizeof(ext_item)); }
+    ext_item *it = &(*items)[(*n)];
+    it->x.off = off + (int64_t)e * CHOL_NB * ld; it->x.ld = ld; it->x.ncol = k - e * CHOL_NB < CHOL_NB ? k - e * CHOL_NB : CHOL_NB;
+    it->x.ctr = chan + e; it->x.need = nstrip;
+    it->key = key0 + e; it->seq = *n;
+    (*n)++;
+  }
+}
 /* a job whose waits are the entries added since wait_first */
 static chol_job *add_job(pbuild *P, int kind, int first, int n, int wait_first)
 {
@@ -709,6 +729,43 @@ static void emit_update_jobs(pbuild *P, builder *B, const plan_t *p, int k0, con
   }
 }
 
+/* Early part of a wide follower's sources: dense 16x16 cell tasks  C(I, J) -= sum over the sources of E_I E_J^T  over the lower
+ * triangle of the lim x lim target block at c_off, E = rows of the target in a source panel (off = row 0 in the first of k
+ * columns).  They become ordinary update jobs on other CUs that wait for the sources' channel counters (the strips publish their
+ * column tiles in order: the last column needed stands for all) and for the earlier update jobs into the panel; the follower
+ * itself takes only the last column tiles of each source (follow_external) and sees these through its own tiles. */
+typedef struct { int64_t off; int ld, k, ctr, need; } early_src;
+static void emit_early_cells(pbuild *P, builder *B, const plan_t *p, int64_t c_off, int ldc, int lim, int blk, const early_src *es, int nes,
+                             const int *c_upd, const int *c_updd, int *snap_upd, int *cnt_upd, int *cnt_updd)
+{
+  chol_level_work *w = B->w;
+  int nsrc = 0;
+  for (int q = 0; q < nes; q++) nsrc += es[q].k > 0;
+  if (nsrc == 0) return;
+  const int k0 = w->n_task, Tl = (lim + CHOL_NB - 1) / CHOL_NB;
+  for (int I = 0; I < Tl; I++)
+    for (int J = 0; J <= I; J++) {
+      const int sb = w->n_src;
+      for (int q = 0; q < nes; q++)
+        if (es[q].k > 0) { chol_upd_src sd = { es[q].off + CHOL_NB * I, es[q].off + CHOL_NB * J, es[q].ld, es[q].ld, es[q].k, 0 }; push_src(B, sd); }
+      if (w->n_task == B->cap_k) { B->cap_k = B->cap_k ? 2 * B->cap_k : 256; w->task = realloc(w->task, B->cap_k * sizeof(chol_upd_task)); }
+      chol_upd_task *t = &w->task[w->n_task++];
+      memset(t, 0, sizeof *t);
+      t->c_off = c_off + CHOL_NB * I + (int64_t)(CHOL_NB * J) * ldc; t->ldc = ldc;
+      t->mv = (short)(lim - CHOL_NB * I < CHOL_NB ? lim - CHOL_NB * I : CHOL_NB);
+      t->nv = (short)(lim - CHOL_NB * J < CHOL_NB ? lim - CHOL_NB * J : CHOL_NB);
+      t->lower = I == J;
+      t->src_begin = sb; t->src_end = w->n_src;
+      t->blk = blk;
+    }
+  int *sc = malloc(nes * sizeof(int)), *sn = malloc(nes * sizeof(int)), ns = 0;
+  for (int q = 0; q < nes; q++) if (es[q].k > 0) { sc[ns] = es[q].ctr; sn[ns] = es[q].need; ns++; }
+  const int col_sep = p->blk[blk].c;
+  snap_upd[col_sep] = cnt_upd[col_sep];
+  emit_update_jobs(P, B, p, k0, c_upd, c_updd, snap_upd, cnt_upd, cnt_updd, sc, sn, ns, NULL);
+  free(sc); free(sn);
+}
+
 int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_work *w, chol_program *pg)
 {
   memset(w, 0, sizeof *w);
@@ -763,6 +820,18 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
       b->c_prog = new_ctr(P, (b->nb + CHOL_NB - 1) / CHOL_NB);
       b->c_strips = new_ctr(P, 0);
     }
+  }
+  /* expected position (in 16-column steps) at which a separator's pivot chain starts: the longest chain below it; leaves start at 0.
+   * A follower consumes its children's column tiles in the order of these positions */
+  int *est_start = calloc(ns + 1, sizeof(int));
+  for (int h = ns; h >= 1; h--) {
+    int st0 = 0;
+    for (int c = 2 * h; c <= 2 * h + 1 && c <= ns; c++) {
+      const int k = p->tree[c];
+      const int end = est_start[k] + (p->sep_size[k] + CHOL_NB - 1) / CHOL_NB;
+      if (end > st0) st0 = end;
+    }
+    est_start[p->tree[h]] = st0;
   }
   /* POTRF job of block st of separator s; exts were added just before (ext_first .. n_ext) */
   #define EMIT_POTRF(s_, st_, ext_first_)                                                                        \
@@ -853,9 +922,19 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
         if (st + 1 >= nblk_of[s] || pb[s][st].ch_below < 0) continue;
         const pblock *b = &pb[s][st];
         const int ld = p->panel_ld[s];
+        ext_item *items = NULL; int nit = 0, capit = 0;
+        const int64_t e_off = p->panel_off[s] + (b->c0 + b->nb) + (int64_t)b->c0 * ld;
+        const int nb1 = pb[s][st + 1].nb, nt = (b->nb + CHOL_NB - 1) / CHOL_NB;
+        int bt = 0; /* column tiles of this block that reach the next block's diagonal block through early update jobs */
+        if (opts->follow_tail > 0 && (nb1 + CHOL_NB - 1) / CHOL_NB > CHOL_FOLLOW_ALL_MAXT && nt > opts->follow_tail) bt = nt - opts->follow_tail;
+        if (bt > 0) {
+          const early_src es = { e_off, ld, bt * CHOL_NB, b->ch_below + bt - 1, b->ns_below };
+          emit_early_cells(P, B, p, p->panel_off[s] + (b->c0 + b->nb) + (int64_t)(b->c0 + b->nb) * ld, ld, nb1, BIDX(p, s, s), &es, 1, c_upd, c_updd, snap_upd, cnt_upd, cnt_updd);
+        }
         const int ef = pg->n_ext;
-        chol_ext e = { p->panel_off[s] + (b->c0 + b->nb) + (int64_t)b->c0 * ld, ld, b->nb, b->ch_below, b->ns_below };
-        add_ext(P, e);
+        push_ext_items(&items, &nit, &capit, e_off, ld, b->nb, b->ch_below, b->ns_below, 0, bt);
+        for (int i = 0; i < nit; i++) add_ext(P, items[i].x);
+        free(items);
         EMIT_POTRF(s, st + 1, ef);
       }
       /* (D) trailing update of the step: columns right of the block in the pivot rows below it (lower triangle) and in the
@@ -924,13 +1003,32 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
           for (int st = 0; st < nblk_of[kids[c]]; st++)
             if (count[BIDX(p, par, kids[c])] > 0 && pb[kids[c]][st].ch_par < 0) all = 0;
         if (!all) continue;
-        for (int c = 0; c < 2; c++)
+        ext_item *items = NULL; int nit = 0, capit = 0;
+        const int lim = pb[par][0].nb, wide = opts->follow_tail > 0 && (lim + CHOL_NB - 1) / CHOL_NB > CHOL_FOLLOW_ALL_MAXT;
+        early_src es[2 * 32]; int nes = 0;
+        for (int c = 0; c < 2; c++) {
+          int total = 0;
+          for (int st = 0; st < nblk_of[kids[c]]; st++) total += (pb[kids[c]][st].nb + CHOL_NB - 1) / CHOL_NB;
+          const int bt = wide && total > opts->follow_tail ? total - opts->follow_tail : 0; /* the child's leading column tiles that go the early way */
+          int before = 0; /* column tiles of the child's earlier blocks */
           for (int st = 0; st < nblk_of[kids[c]]; st++) {
             const pblock *b = &pb[kids[c]][st];
-            if (b->ch_par < 0) continue;
-            chol_ext e = { b->par_off, p->panel_ld[kids[c]], b->nb, b->ch_par, b->ns_par };
-            add_ext(P, e);
+            const int nt = (b->nb + CHOL_NB - 1) / CHOL_NB;
+            const int et = bt - before < 0 ? 0 : bt - before > nt ? nt : bt - before; /* early column tiles of this block */
+            if (b->ch_par >= 0) {
+              if (et > 0 && nes < 64) { const early_src e1 = { b->par_off, p->panel_ld[kids[c]], et * CHOL_NB < b->nb ? et * CHOL_NB : b->nb, b->ch_par + et - 1, b->ns_par }; es[nes++] = e1; }
+              push_ext_items(&items, &nit, &capit, b->par_off, p->panel_ld[kids[c]], b->nb, b->ch_par, b->ns_par, est_start[kids[c]] + before, et);
+            }
+            before += nt;
           }
+        }
+        if (nes > 0) {
+          const chol_block *Bp = &p->blk[BIDX(p, par, par)];
+          emit_early_cells(P, B, p, Bp->off, Bp->ld, lim, BIDX(p, par, par), es, nes, c_upd, c_updd, snap_upd, cnt_upd, cnt_updd);
+        }
+        qsort(items, nit, sizeof(ext_item), cmp_ext_item);
+        for (int i = 0; i < nit; i++) add_ext(P, items[i].x);
+        free(items);
         if (pg->n_ext == ef) continue;
         follow_lim[BIDX(p, par, par)] = pb[par][0].nb;
         EMIT_POTRF(par, 0, ef);
@@ -1042,7 +1140,7 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
   if (!rc && w->n_task > PROG_MAX_TASKS) { chol_set_error("program launch: %d update tasks", w->n_task); rc = CHOLAMD_ERR_ARG; }
   for (int s = 1; s <= ns; s++) { pg->ctr_total[c_upd[s]] = cnt_upd[s]; pg->ctr_total[c_updd[s]] = cnt_updd[s]; }
   for (int s = 1; s <= ns; s++) free(pb[s]);
-  free(pb); free(nblk_of); free(first); free(count); free(c_upd); free(c_updd); free(cnt_upd); free(cnt_updd); free(snap_upd); free(follow_lim);
+  free(est_start); free(pb); free(nblk_of); free(first); free(count); free(c_upd); free(c_updd); free(cnt_upd); free(cnt_updd); free(snap_upd); free(follow_lim);
   free(B->pend);
   if (rc) { chol_level_work_free(w); chol_program_free(pg); }
   return rc;
@@ -1080,7 +1178,7 @@ int chol_program_check(const plan_t *p, const chol_sched_opts *opts, int workers
       if (ok && jb->kind == 0)
         for (int x = 0; x < jb->n_ext && ok; x++) {
           const chol_ext *e = &g.ext[jb->ext_first + x];
-          for (int t = 0; t < (e->k + CHOL_NB - 1) / CHOL_NB; t++) if (val[e->chan + t] < e->nstrip) ok = 0;
+          if (val[e->ctr] < e->need) ok = 0;
         }
       if (ok && jb->kind == 1 && val[w.trsm[jb->first].flag] < g.ctr_total[w.trsm[jb->first].flag]) ok = 0; /* its pivot block is factored */
       if (!ok) continue;

@@ -16,7 +16,7 @@ int main(int argc, char **argv)
   for (int rep = 0; rep < 3; rep++) {
     hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
     hipMemset(dinfo, 0, 8);
-    hipLaunchKernelGGL(k_potrf_rr, dim3(1), dim3(RR_THREADS), 0, 0, dA, (double *const *)nullptr, dW, dd, dinfo);
+    hipLaunchKernelGGL(k_potrf_rr, dim3(1), dim3(RR_THREADS), 0, 0, dA, dW, dd, dinfo);
     hipDeviceSynchronize();
   }
   unsigned long long st[16];
