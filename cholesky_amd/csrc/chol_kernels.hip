@@ -256,58 +256,76 @@ __device__ __forceinline__ void lds_dma16(const double *g, double *lds)
 #ifndef MT_STAGES
 #define MT_STAGES 2 /* measured (scripts/mt_bench.hip, 8192^2 SYRK, TF/s at K = 144 / 512): 16-deep chunks x 2 stages 38.2 / 49.0, x 3 34.3 / 46.2, x 4 27.3 / 40.5; 8-deep x 3 35.9 / 44.5, x 4 35.5 / 44.8, x 6 31.3 / 40.3: workgroups per CU (LDS) beat prefetch depth; register-staged double buffering (round 1) 35 / 44 */
 #endif
-/* MT_STAGES: LDS ring of the full-tile path: stages of one 16-deep chunk of both operands (16 KB each) */
+/* MT_STAGES: LDS ring of the full-tile path: stages of one 16-deep chunk of both operands */
 #define MT_SRC_BATCH 32 /* source descriptors held in LDS at a time */
-// one 16-deep chunk out of the LDS images sa / sb ([k][64 rows]) into the wave's 2x2 accumulators; the operands of k-step kk + 1 are
-// requested before the MFMAs of k-step kk are issued (the LDS round trip is off the MFMA chain)
-__device__ __forceinline__ void mt_chunk(d4 (&acc)[2][2], const double *sa, const double *sb, int g, int xo, int yo)
+// One macro tile of TM x TN per workgroup of WR x WC waves, each wave a (TM / WR) x (TN / WC) block of 16x16 accumulators.
+//   64 x 64, 2 x 2 waves (k_update_mt): 2 x 2 accumulators per wave, 8 flop per byte staged into LDS.
+//   Measured against it (scripts/mt_bench.hip 8192^2 SYRK, TF/s at K = 144 / 432 / 512): 128 x 128 tiles, 4 x 2 waves of
+//   2 x 4 accumulators, 16 flop per byte: 27 / 41 / 42 against 38 / 49 / 49 -- two workgroups of eight waves per CU (64 KB of LDS each)
+//   hide less than four or five of four; at K = 144 either shape is bound by the read-modify-write of C, not by the MFMAs
+// one 16-deep chunk out of the LDS images sa ([k][TM rows]) / sb ([k][TN rows]) into the wave's accumulators; the operands of k-step
+// kk + 1 are requested before the MFMAs of k-step kk are issued (the LDS round trip is off the MFMA chain)
+template <int TM, int TN, int RM, int RN>
+__device__ __forceinline__ void mt_chunk(d4 (&acc)[RM][RN], const double *sa, const double *sb, int g, int xo, int yo)
 {
-  double x0 = sa[g * MT + xo], x1 = sa[g * MT + xo + 16], y0 = sb[g * MT + yo], y1 = sb[g * MT + yo + 16];
+  double x[RM], y[RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i) x[i] = sa[g * TM + xo + 16 * i];
+#pragma unroll
+  for (int j = 0; j < RN; ++j) y[j] = sb[g * TN + yo + 16 * j];
 #pragma unroll
   for (int kk = 0; kk < MKB / 4; ++kk) {
-    double nx0 = 0.0, nx1 = 0.0, ny0 = 0.0, ny1 = 0.0;
+    double nx[RM], ny[RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i) nx[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < RN; ++j) ny[j] = 0.0;
     if (kk + 1 < MKB / 4) {
-      nx0 = sa[(4 * (kk + 1) + g) * MT + xo]; nx1 = sa[(4 * (kk + 1) + g) * MT + xo + 16];
-      ny0 = sb[(4 * (kk + 1) + g) * MT + yo]; ny1 = sb[(4 * (kk + 1) + g) * MT + yo + 16];
+#pragma unroll
+      for (int i = 0; i < RM; ++i) nx[i] = sa[(4 * (kk + 1) + g) * TM + xo + 16 * i];
+#pragma unroll
+      for (int j = 0; j < RN; ++j) ny[j] = sb[(4 * (kk + 1) + g) * TN + yo + 16 * j];
     }
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, x0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, x0, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, x1, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, x1, acc[1][1], 0, 0, 0);
-    x0 = nx0; x1 = nx1; y0 = ny0; y1 = ny1;
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+      for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(y[j], x[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < RM; ++i) x[i] = nx[i];
+#pragma unroll
+    for (int j = 0; j < RN; ++j) y[j] = ny[j];
   }
 }
-// Full 64x64 tiles (the bulk of a large front) stage their operands by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
-// instruction = two k-columns of 64 rows, no registers) into a ring of MT_STAGES stages, MT_STAGES - 1 chunks in flight behind a
-// counted vmcnt: a chunk's memory round trip is hidden behind the MFMAs of the chunks before it, not behind one chunk's worth.
+// Full tiles (the bulk of a large front) stage their operands by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
+// instruction = 128 consecutive doubles of the [k][rows] image, no registers) into a ring of MT_STAGES stages, MT_STAGES - 1 chunks in
+// flight behind a counted vmcnt: a chunk's memory round trip is hidden behind the MFMAs of the chunks before it.
 // The chunk sequence runs across the sources of the task (the ring is not drained between sources).  Edge tiles and the last
 // partial chunk of a source (K not a multiple of 16) take the register-staged path (masked loads).
-__global__ __launch_bounds__(256) void k_update_mt(double *__restrict__ base, const chol_upd_task *__restrict__ tasks,
-                                                   const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd)
+template <int TM, int TN, int WR, int WC>
+__device__ __forceinline__ void update_mt_body(double *__restrict__ base, const chol_upd_task t, const chol_upd_src *__restrict__ srcs)
 {
-  __shared__ double sA[MT_STAGES][MKB][MT];
-  __shared__ double sB[MT_STAGES][MKB][MT];
+  constexpr int NW = WR * WC, NT = 64 * NW, RM = TM / WR / 16, RN = TN / WC / 16;
+  constexpr int QA = MKB * TM / 128 / NW, QB = MKB * TN / 128 / NW; // LDS-DMA instructions per wave, chunk and operand
+  static_assert(QA * NW * 128 == MKB * TM && QB * NW * 128 == MKB * TN && NT % TM == 0 && NT % TN == 0, "tile shape");
+  __shared__ double sA[MT_STAGES][MKB][TM];
+  __shared__ double sB[MT_STAGES][MKB][TN];
   const int tt = threadIdx.x, lane = tt & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tt >> 6);
-  const int tid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if ((blockIdx.x >> 3) >= per_xcd || tid >= ntask) return;
-  const chol_upd_task t = tasks[tid];
   const int r15 = lane & 15, g = lane >> 4;
-  const int wr = wave & 1, wc = wave >> 1;
-  const int xo = 32 * wr + r15, yo = 32 * wc + r15;
-  d4 acc[2][2];
+  const int wr = wave % WR, wc = wave / WR;
+  const int xo = (TM / WR) * wr + r15, yo = (TN / WC) * wc + r15;
+  d4 acc[RM][RN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (d4){ 0.0, 0.0, 0.0, 0.0 };
-  const bool full = t.mv == MT && t.nv == MT;
+    for (int j = 0; j < RN; ++j) acc[i][j] = (d4){ 0.0, 0.0, 0.0, 0.0 };
+  const bool full = t.mv == TM && t.nv == TN;
   if (full) {
     // ---- LDS-DMA ring.  Chunk list = the full 16-deep chunks of every source, in order; (is, ik) = next chunk to issue.
-    // Wave w moves the k-pairs 2w, 2w+1 of both operands: lane l carries rows (2 (l & 31), +1) of k = k0 + 2 pair + (l >> 5).
+    // Instruction q of an operand's chunk moves the doubles [128 q, 128 q + 128) of the [k][rows] image: lane l the pair at 128 q + 2 l.
     // The source descriptors are copied to LDS in batches first: inside the ring nothing may be read through the vector-memory
     // counter (a descriptor load and its vmcnt(0) would drain the ring every chunk).
     __shared__ chol_upd_src sS[MT_SRC_BATCH];
-    const int lrow = 2 * (lane & 31), lk = lane >> 5;
     for (int sb = t.src_begin; sb < t.src_end; sb += MT_SRC_BATCH) {
       const int ns = min(MT_SRC_BATCH, t.src_end - sb);
       __builtin_amdgcn_s_barrier(); // the previous batch is done with sS and with the ring
@@ -323,21 +341,24 @@ __global__ __launch_bounds__(256) void k_update_mt(double *__restrict__ base, co
         const int64_t ao_ = sS[is].a_off, bo_ = sS[is].b_off;                                                         \
         const int lda_ = sS[is].lda, ldb_ = sS[is].ldb;                                                               \
         const int st_ = issued % MT_STAGES;                                                                           \
-        _Pragma("unroll") for (int pp = 0; pp < MKB / 8; ++pp) {                                                      \
-          const int pair = (MKB / 8) * wave + pp;                                                                     \
-          lds_dma16(base + ao_ + t.ar + lrow + (int64_t)(ik + 2 * pair + lk) * lda_, &sA[st_][2 * pair][0]);          \
-          lds_dma16(base + bo_ + t.br + lrow + (int64_t)(ik + 2 * pair + lk) * ldb_, &sB[st_][2 * pair][0]);          \
+        _Pragma("unroll") for (int pp = 0; pp < QA; ++pp) {                                                           \
+          const int e_ = 128 * (QA * wave + pp) + 2 * lane;                                                           \
+          lds_dma16(base + ao_ + t.ar + e_ % TM + (int64_t)(ik + e_ / TM) * lda_, &sA[st_][0][0] + 128 * (QA * wave + pp)); \
+        }                                                                                                             \
+        _Pragma("unroll") for (int pp = 0; pp < QB; ++pp) {                                                           \
+          const int e_ = 128 * (QB * wave + pp) + 2 * lane;                                                           \
+          lds_dma16(base + bo_ + t.br + e_ % TN + (int64_t)(ik + e_ / TN) * ldb_, &sB[st_][0][0] + 128 * (QB * wave + pp)); \
         }                                                                                                             \
         ++issued; ik += MKB;                                                                                          \
       }
       for (int i = 0; i < MT_STAGES - 1 && issued < total; ++i) MT_ISSUE();
       for (int c = 0; c < total; ++c) {
-        // this wave's four DMA instructions of chunk c have landed when at most the later chunks' remain outstanding
-        if (issued - c - 1 >= MT_STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((MKB / 4) * (MT_STAGES - 2)) : "memory");
+        // this wave's DMA instructions of chunk c have landed when at most the later chunks' remain outstanding
+        if (issued - c - 1 >= MT_STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((QA + QB) * (MT_STAGES - 2)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier(); // every wave's part of chunk c is in LDS; every wave has left chunk c - 1
         if (issued < total) MT_ISSUE(); // into the stage chunk c - 1 occupied
-        mt_chunk(acc, &sA[c % MT_STAGES][0][0], &sB[c % MT_STAGES][0][0], g, xo, yo);
+        mt_chunk<TM, TN, RM, RN>(acc, &sA[c % MT_STAGES][0][0], &sB[c % MT_STAGES][0][0], g, xo, yo);
       }
 #undef MT_ISSUE
     }
@@ -345,63 +366,69 @@ __global__ __launch_bounds__(256) void k_update_mt(double *__restrict__ base, co
   }
   // ---- register-staged path: everything for edge tiles, the K tails (K mod 16 columns) of the sources for full tiles
   {
-    const int srow = tt & 63, skq = tt >> 6; // this thread moves row `srow`, k = skq, skq+4, skq+8, skq+12
-    const bool sva = srow < t.mv, svb = srow < t.nv;
+    constexpr int KA = NT / TM, KB = NT / TN; // k-columns the threads cover per pass of the A / B image
+    const int arow = tt % TM, akq = tt / TM, brow = tt % TN, bkq = tt / TN;
+    const bool sva = arow < t.mv, svb = brow < t.nv;
     int buf = 0;
     for (int s = t.src_begin; s < t.src_end; ++s) {
       const chol_upd_src sd = srcs[s];
       const int K = sd.k, kbeg = full ? (K / MKB) * MKB : 0;
       if (kbeg >= K) continue;
-      const double *A = base + sd.a_off + t.ar + srow;
-      const double *Bp = base + sd.b_off + t.br + srow;
-      double ra[MKB / 4], rb[MKB / 4];
+      const double *A = base + sd.a_off + t.ar + arow;
+      const double *Bp = base + sd.b_off + t.br + brow;
+      double ra[MKB / KA], rb[MKB / KB];
 #pragma unroll
-      for (int i = 0; i < MKB / 4; ++i) { // first chunk of this source
-        const int k = kbeg + skq + 4 * i;
-        ra[i] = (sva && k < K) ? A[(int64_t)k * sd.lda] : 0.0;
-        rb[i] = (svb && k < K) ? Bp[(int64_t)k * sd.ldb] : 0.0;
-      }
+      for (int i = 0; i < MKB / KA; ++i) { const int k = kbeg + akq + KA * i; ra[i] = (sva && k < K) ? A[(int64_t)k * sd.lda] : 0.0; } // first chunk of this source
+#pragma unroll
+      for (int i = 0; i < MKB / KB; ++i) { const int k = kbeg + bkq + KB * i; rb[i] = (svb && k < K) ? Bp[(int64_t)k * sd.ldb] : 0.0; }
       for (int k0 = kbeg; k0 < K; k0 += MKB) {
 #pragma unroll
-        for (int i = 0; i < MKB / 4; ++i) { sA[buf][skq + 4 * i][srow] = ra[i]; sB[buf][skq + 4 * i][srow] = rb[i]; }
+        for (int i = 0; i < MKB / KA; ++i) sA[buf][akq + KA * i][arow] = ra[i];
+#pragma unroll
+        for (int i = 0; i < MKB / KB; ++i) sB[buf][bkq + KB * i][brow] = rb[i];
         if (k0 + MKB < K) { // next chunk's loads fly during this chunk's MFMAs
 #pragma unroll
-          for (int i = 0; i < MKB / 4; ++i) {
-            const int k = k0 + MKB + skq + 4 * i;
-            ra[i] = (sva && k < K) ? A[(int64_t)k * sd.lda] : 0.0;
-            rb[i] = (svb && k < K) ? Bp[(int64_t)k * sd.ldb] : 0.0;
-          }
+          for (int i = 0; i < MKB / KA; ++i) { const int k = k0 + MKB + akq + KA * i; ra[i] = (sva && k < K) ? A[(int64_t)k * sd.lda] : 0.0; }
+#pragma unroll
+          for (int i = 0; i < MKB / KB; ++i) { const int k = k0 + MKB + bkq + KB * i; rb[i] = (svb && k < K) ? Bp[(int64_t)k * sd.ldb] : 0.0; }
         }
         lds_barrier(); // chunk visible; the other buffer is free again (everyone is past its reads)
-        mt_chunk(acc, &sA[buf][0][0], &sB[buf][0][0], g, xo, yo);
+        mt_chunk<TM, TN, RM, RN>(acc, &sA[buf][0][0], &sB[buf][0][0], g, xo, yo);
         buf ^= 1;
       }
     }
   }
-  // epilogue: all sixteen C values of the lane are requested before the first is used (clamped addresses, masked
+  // epilogue: all C values of the lane are requested before the first is used (clamped addresses, masked
   // stores); as read-modify-writes in a row each one would wait for its own memory round trip
-  double cv[2][2][4];
+  double cv[RM][RN][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < RN; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int r = min(32 * wr + 16 * i + r15, t.mv - 1), c = min(32 * wc + 16 * j + g + 4 * q, t.nv - 1);
+        const int r = min((TM / WR) * wr + 16 * i + r15, t.mv - 1), c = min((TN / WC) * wc + 16 * j + g + 4 * q, t.nv - 1);
         cv[i][j][q] = *(const volatile double *)(base + t.c_off + r + (int64_t)c * t.ldc);
       }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int r = 32 * wr + 16 * i + r15;
+    for (int j = 0; j < RN; ++j) {
+      const int r = (TM / WR) * wr + 16 * i + r15;
       double *C = base + t.c_off + r;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int c = 32 * wc + 16 * j + g + 4 * q;
+        const int c = (TN / WC) * wc + 16 * j + g + 4 * q;
         if (r < t.mv && c < t.nv && (!t.lower || r >= c)) C[(int64_t)c * t.ldc] = cv[i][j][q] - acc[i][j][q];
       }
     }
+}
+__global__ __launch_bounds__(256) void k_update_mt(double *__restrict__ base, const chol_upd_task *__restrict__ tasks,
+                                                   const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd)
+{
+  const int tid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per_xcd || tid >= ntask) return;
+  update_mt_body<MT, MT, 2, 2>(base, tasks[tid], srcs);
 }
 
 // ================================================================================================
@@ -782,7 +809,10 @@ __device__ __forceinline__ void wait_list(const chol_wait *__restrict__ wl, int 
       const bool ok = !mine || __hip_atomic_load(&ctr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
       if (!__ballot(!ok)) break;
       if (it >= (1 << 15)) { if (lane == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); break; }
-      __builtin_amdgcn_s_sleep(32); // ~1 us between polls: a blocked job is not on anybody's critical path by less than that
+#ifndef WAIT_SLEEP
+#define WAIT_SLEEP 32
+#endif
+      __builtin_amdgcn_s_sleep(WAIT_SLEEP); // ~1 us between polls: a blocked job is not on anybody's critical path by less than that
     }
   }
 }

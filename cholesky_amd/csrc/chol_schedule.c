@@ -595,8 +595,12 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
 /* self-check (chol_program_check) simulates the queue with a bounded number of resident          */
 /* workgroups to show that this cannot dead-lock.                                                 */
 /* ---------------------------------------------------------------------------------------- */
+#ifndef PROG_JOB_TASKS
 #define PROG_JOB_TASKS 12    /* light 16x16 update tasks per update job (one per wave) */
+#endif
+#ifndef PROG_HEAVY_STEPS
 #define PROG_HEAVY_STEPS 48   /* MFMA k-steps (of 4 columns) from which a task is split over four waves */
+#endif
 #define PROG_MAX_TASKS 24000 /* beyond this the per-level launches (macro tiles) are the better schedule */
 typedef struct { int potrf, c_prog, c_strips, n_groups, c0, nb, emitted; int ch_below, ns_below; int ch_par, ns_par; int64_t par_off; } pblock;
 typedef struct { chol_program *pg; int cap_j, cap_w, cap_e, cap_c; } pbuild;

@@ -1,10 +1,25 @@
 // Development aid: the macro-tile update kernel on one large SYRK target (n x n lower, one source of depth k), TF/s
 //   hipcc --offload-arch=gfx950 -O3 -Iinclude -Icholesky_amd/csrc scripts/mt_bench.hip -o scripts/mt_bench
 #include "../cholesky_amd/csrc/chol_kernels.hip"
+// the 128 x 128 / 8-wave instance of the macro-tile body: measured here only (slower than the product's 64 x 64: chol_kernels.hip)
+__global__ __launch_bounds__(512) void k_update_mt128(double *__restrict__ base, const chol_upd_task *__restrict__ tasks,
+                                                      const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd)
+{
+  const int tid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per_xcd || tid >= ntask) return;
+  update_mt_body<128, 128, 4, 2>(base, tasks[tid], srcs);
+}
+static int chol_launch_update_mt128(double *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st)
+{
+  const int per_xcd = (ntask + 7) / 8;
+  hipLaunchKernelGGL(k_update_mt128, dim3(per_xcd * 8), dim3(512), 0, st, base, tasks, srcs, ntask, per_xcd);
+  return (int)hipGetLastError();
+}
 #include <cstdio>
 #include <vector>
 #include <cstring>
 #include <algorithm>
+#include <cmath>
 int main(int argc, char **argv)
 {
   const int n = argc > 1 ? atoi(argv[1]) : 8192, k = argc > 2 ? atoi(argv[2]) : 144;
@@ -15,7 +30,8 @@ int main(int argc, char **argv)
   for (size_t i = 0; i < X.size(); i++) X[i] = 1e-3 * (double)(i % 977);
   hipMemcpy(dX, X.data(), X.size() * 8, hipMemcpyHostToDevice);
   std::vector<chol_upd_task> tasks;
-  const int nt = (n + 63) / 64;
+  const int TSZ = argc > 4 ? atoi(argv[4]) : 64; // macro tile: 64 (k_update_mt) or 128 (k_update_mt128)
+  const int nt = (n + TSZ - 1) / TSZ;
   const int BL = argc > 3 ? atoi(argv[3]) : 1; // tasks enumerated in BL x BL blocks of tiles
   for (int A0 = 0; A0 < nt; A0 += BL)
    for (int B0 = 0; B0 <= A0; B0 += BL)
@@ -23,9 +39,9 @@ int main(int argc, char **argv)
     for (int b = B0; b < std::min(B0 + BL, nt); b++) {
       if (b > a) continue;
       chol_upd_task t = {};
-      t.c_off = (int64_t)((uintptr_t)dC / 8) + a * 64 + (int64_t)b * 64 * n; t.ldc = n;
-      t.mv = (short)std::min(64, n - a * 64); t.nv = (short)std::min(64, n - b * 64);
-      t.lower = a == b; t.src_begin = 0; t.src_end = 1; t.ar = a * 64; t.br = b * 64;
+      t.c_off = (int64_t)((uintptr_t)dC / 8) + a * TSZ + (int64_t)b * TSZ * n; t.ldc = n;
+      t.mv = (short)std::min(TSZ, n - a * TSZ); t.nv = (short)std::min(TSZ, n - b * TSZ);
+      t.lower = a == b; t.src_begin = 0; t.src_end = 1; t.ar = a * TSZ; t.br = b * TSZ;
       tasks.push_back(t);
     }
   chol_upd_src src = { (int64_t)((uintptr_t)dX / 8), (int64_t)((uintptr_t)dX / 8), n, n, k, 0 };
@@ -37,13 +53,15 @@ int main(int argc, char **argv)
   float best = 1e9f;
   for (int rep = 0; rep < 5; rep++) {
     hipEventRecord(e0);
-    chol_launch_update_mt(nullptr, dt, ds, (int)tasks.size(), 0);
+    if (TSZ == 128) chol_launch_update_mt128(nullptr, dt, ds, (int)tasks.size(), 0); else chol_launch_update_mt(nullptr, dt, ds, (int)tasks.size(), 0);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (ms < best) best = ms;
   }
-  const double flops = (double)tasks.size() * 64.0 * 64.0 * 2.0 * k;
-  printf("BL=%d n=%d k=%d: %zu macro tiles, %.3f ms, %.1f TF/s executed\n", BL, n, k, tasks.size(), best, flops / best * 1e-9);
+  const double flops = (double)tasks.size() * TSZ * TSZ * 2.0 * k;
+  // a few entries against the host (row sums of X X^T)
+  { std::vector<double> C((size_t)n * 4); hipMemcpy(C.data(), dC, C.size() * 8, hipMemcpyDeviceToHost); double err = 0; for (int c = 0; c < 4; c++) for (int r = c; r < n; r += 997) { double sum = 0; for (int q = 0; q < k; q++) sum += X[r + (size_t)q * n] * X[c + (size_t)q * n]; err = std::max(err, fabs(C[r + (size_t)c * n] + 5.0 * sum) / (1.0 + fabs(sum))); } printf("check (5 launches accumulate): rel err %.2e\n", err); }
+  printf("TS=%d BL=%d n=%d k=%d: %zu macro tiles, %.3f ms, %.1f TF/s executed\n", TSZ, BL, n, k, tasks.size(), best, flops / best * 1e-9);
   return 0;
 }
