@@ -853,6 +853,7 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
   int ready = 0, ng = 0; // ng: items of the round starting at i whose loads are in flight (0 = not issued)
   double va[FOLLOW_LOADS], vb[FOLLOW_LOADS];
   const int pair_lim = 2 * T <= RR_MAXT ? f.n_ext - 2 : 0; // items [i, i + 1] form a round while i + 1 < pair_lim
+  const int own_at = f.n_ext >= 2 ? f.n_ext - 2 : f.n_ext - 1; // never the second item of a pair
 #define EXT_ROUND(I_) ((I_) + 1 < pair_lim ? 2 : 1)
 #define EXT_LOAD(I_, V_)                                                                                             \
   {                                                                                                                  \
@@ -880,7 +881,7 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
     }                                                                                                                \
   }
   for (int i = 0; i < f.n_ext;) {
-    if (f.n_wl > 0 && i == f.n_ext - 1) { // the follower's own tiles, before the last followed column tile
+    if (f.n_wl > 0 && i == own_at) { // the follower's own tiles, before the last two followed column tiles (their round trip hides behind the wait for those)
       if (!UPD) wait_list(f.wl, f.n_wl, f.ctr, f.ctr_total, f.epoch, lane, info); // the factor wave polls
       if (!UPD && f.xstamp && lane == 0) f.xstamp[0] = __builtin_amdgcn_s_memrealtime();
       lds_barrier();
@@ -1092,7 +1093,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       // A follower without waits of its own (no update job of an earlier phase writes its diagonal block: the parents of the
       // leaves) loads its own tiles first -- their round trip overlaps the wait for the first followed column -- and puts the
       // followed contributions on top.  One with waits starts from ZERO accumulators, consumes its children's columns as they
-      // arrive, and adds its own tiles just before the LAST followed column tile (follow_external: there its waits must hold;
+      // arrive, and adds its own tiles just before the last TWO followed column tiles (follow_external: there its waits must hold;
       // the load hides behind the wait for that column): it does not sit idle until its grandchildren's extend-add is through.
       // Which of the two is fixed by the schedule, not by timing: the summation order is the same in every run.
       const bool early = fa.n_wl == 0;

@@ -30,6 +30,10 @@ names = {0: "POTRF", 10: "POTRF*", 1: "TRSM", 2: "UPD"}
 for j in range(len(tr)):
     if kind[j] in (0, 10):
         print(f"  job {j:4d} {names[int(kind[j])]:6s} wg {tr[j, 4]:3d}  drawn {us[j, 0]:7.1f}  start {us[j, 1]:7.1f}  end {us[j, 2]:7.1f}  (busy {us[j, 2] - us[j, 1]:6.1f})")
+if os.environ.get("TRACE_JOBS"):  # TRACE_JOBS=lo:hi -- every job of the range
+    lo, hi = (int(v) for v in os.environ["TRACE_JOBS"].split(":"))
+    for j in range(lo, min(hi, len(tr))):
+        print(f"  job {j:4d} kind {int(kind[j]):2d} wg {tr[j, 4]:3d}  drawn {us[j, 0]:7.1f}  start {us[j, 1]:7.1f}  end {us[j, 2]:7.1f}")
 for k in (1, 2):
     sel = kind == k
     if sel.any():
