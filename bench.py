@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="cholamd_device_set_option switch for this run (e.g. program=0: level-by-level launches), repeatable; recorded in config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=2, help="extra figure (not the metric): independent factorisations kept this many at a time on device objects / streams of their own; 0 or 1 = skip")
     args = ap.parse_args()
     if args.gpus < 1 or args.gpus & (args.gpus - 1):
         sys.exit("bench.py: --gpus must be a power of two (the separator tree is cut at level log2(gpus))")
@@ -274,6 +275,36 @@ def main():
         it, rel = dev.solve_refine(arenas[(done + K - 1) % n_arenas] if K <= n_arenas else arenas[(K - 1) % n_arenas], bvec, xvec, 30, 1e-11, stream)
         torch.cuda.synchronize()
         refine = {"corrections": it, "relres": rel, "ms": round((time.perf_counter() - t0) * 1e3, 3), "tol": 1e-11}
+    # not the metric -- reported beside it: independent factorisations (a batch of matrices, a parameter sweep) kept TWO in
+    # (--in-flight) in flight, each on a device object and stream of its own.  A factorisation of this size ends in a dependency chain that keeps a
+    # handful of the 256 CUs busy; the next one's leaves fill the rest.  `value` above stays the one-after-the-other rate.
+    concurrent = None
+    NF = args.in_flight
+    if world == 1 and not mixed and not generated and K <= n_arenas and K >= 2 * NF and NF >= 2:
+        devs, streams = [dev], [stream]
+        for q in range(1, NF):
+            dq = ca.Device(plan, local_rank)
+            for kv in args.option:
+                k, v = kv.split("=")
+                dq.set_option(k, int(v))
+            devs.append(dq)
+            streams.append(torch.cuda.Stream())
+        refill()
+        for i in range(2 * NF):  # warm-up of the other objects (descriptor upload, counters)
+            devs[i % NF].factor(arenas[i], streams[i % NF])
+        torch.cuda.synchronize()
+        refill()
+        t0 = time.perf_counter()
+        for i in range(K):
+            devs[i % NF].factor(arenas[i], streams[i % NF])
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        if all(d.info()[0] == 0 for d in devs):
+            same = all(bool(torch.equal(arenas[0], arenas[q])) for q in range(1, NF))  # factors of the same matrix by the different objects
+            concurrent = {"in_flight": NF, "value": round(plan.flops * K / dt2 * 1e-9, 3), "unit": "GF/s", "ms_per_step": round(dt2 / K * 1e3, 5), "steps": K,
+                          "factors_identical": same,
+                          "note": f"K independent factorisations, {NF} at a time ({NF} device objects, {NF} HIP streams); throughput of a batch, not the latency of one factorisation"}
+        del devs[1:]
     refill()
     dev.set_timing(1)
     reps = min(n_arenas, 20)
@@ -352,6 +383,8 @@ def main():
         }
         if refine is not None:
             out["config"]["refinement"] = refine
+        if concurrent is not None:
+            out["concurrent"] = concurrent
         if world == 1 and not args.no_cpu_baseline and not generated:
             out["cpu_baseline"] = cpu_baseline(files, plan.flops)
         print(json.dumps(out))

@@ -93,6 +93,7 @@ def load():
     L.cholamd_plan_level_work_counts.argtypes = [vp, ci, ci, ci, vp]
     L.cholamd_plan_level_work_volume.argtypes = [vp, ci, ci, ci, ci, vp]
     L.cholamd_plan_program_check.argtypes = [vp, ci, ci]
+    L.cholamd_plan_program_check_opts.argtypes = [vp, ci, ci, ci, ci]
     L.cholamd_plan_program_counts.argtypes = [vp, ci, vp]
     L.cholamd_plan_program_jobs.argtypes = [vp, ci, i64, vp]
     L.cholamd_plan_program_jobs.restype = i64

@@ -1238,6 +1238,15 @@ int cholamd_plan_program_check(const cholamd_plan *p, int follow, int workers)
   o.follow = follow;
   return chol_program_check(p, &o, workers);
 }
+int cholamd_plan_program_check_opts(const cholamd_plan *p, int follow_tail, int split_min, int split_nb, int workers)
+{ /* the same for other follower tails / pivot splits (negative: the default) */
+  chol_sched_opts o;
+  chol_sched_opts_default(&o);
+  if (follow_tail >= 0) o.follow_tail = follow_tail;
+  if (split_min >= 0) o.split_min = split_min;
+  if (split_nb >= 0) o.split_nb = split_nb;
+  return chol_program_check(p, &o, workers);
+}
 int64_t cholamd_plan_program_jobs(const cholamd_plan *p, int follow, int64_t cap, int *out)
 { /* diagnostic: per job 8 ints: kind, separator (POTRF / TRSM: the pivot's label; update: target block's column label), target
    * block's row label (update) or column offset of the pivot block, first, n, sig0, sig1, n_wait; then the wait list as

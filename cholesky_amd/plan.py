@@ -143,6 +143,10 @@ class Plan:
         """Host-side self-check of the one-launch program (raises CholamdError on a dead-lock or a mismatch)."""
         check(self.L.cholamd_plan_program_check(self.h, int(follow), int(workers)), "cholamd_plan_program_check")
 
+    def program_check_opts(self, follow_tail=-1, split_min=-1, split_nb=-1, workers=64):
+        """program_check under other follower tails / pivot splits (negative: the default)."""
+        check(self.L.cholamd_plan_program_check_opts(self.h, follow_tail, split_min, split_nb, int(workers)), "cholamd_plan_program_check_opts")
+
     def program_counts(self, follow=True):
         out = np.zeros(6, dtype=np.int32)
         check(self.L.cholamd_plan_program_counts(self.h, int(follow), out.ctypes.data), "cholamd_plan_program_counts")

@@ -184,6 +184,8 @@ int cholamd_plan_level_work_volume(const cholamd_plan *p, int level, int rank, i
  * total up; pivot blocks and TRSM rows equal those of the per-level lists.  0 = consistent, otherwise cholamd_last_error()
  * says what is wrong (also when the problem does not qualify for the program launch).  follow: with / without followers. */
 int cholamd_plan_program_check(const cholamd_plan *p, int follow, int workers);
+/* the same with followers under other values of the options "follow_tail", "split_min", "split_nb" (negative: the default) */
+int cholamd_plan_program_check_opts(const cholamd_plan *p, int follow_tail, int split_min, int split_nb, int workers);
 int cholamd_plan_program_counts(const cholamd_plan *p, int follow, int out[6]);
 int64_t cholamd_plan_program_jobs(const cholamd_plan *p, int follow, int64_t cap, int *out); /* diagnostic dump of the job queue (scripts/prog_trace.py) */ /* jobs, following POTRF jobs, update tasks, strips, counters, followed panels */
 /* dense N x N col-major image of an arena (zeros outside allocated blocks) and back */

@@ -211,6 +211,10 @@ def _ntiles_table(case):
 
 @pytest.mark.parametrize("opts", [
     {"follow": 0},                                     # the one-launch program without followers (update jobs carry every contribution)
+    {"follow_tail": 0},                                # followers take every column tile of their sources themselves (no early update jobs)
+    {"follow_tail": 2},                                # ... only the last two (most of the contribution through early jobs)
+    {"follow_tail": 7},
+    {"split_min": 96, "split_nb": 96, "follow_tail": 1}, # three / four column blocks per leaf: chains of followers with early jobs
     {"program": 0},                                    # level by level: fused POTRF+TRSM launches + update launches
     {"program": 0, "fuse": 0},                         # separate POTRF / TRSM launches (k_potrf_rr, k_trsm_rr, k_trsm_w)
     {"program": 0, "fuse_update_max": 100000},         # update tasks inside the fused launch

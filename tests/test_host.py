@@ -246,6 +246,23 @@ def test_program_launch_is_live_and_covers_the_level_lists(case, follow):
     assert cnt["jobs"] > 0 and (cnt["followers"] > 0) == bool(follow)
 
 
+def test_program_launch_is_live_under_follower_tails_and_splits():
+    """The followers' early update jobs (option follow_tail) and the item lists of every pivot split keep the queue live: tails
+    0 (followers take everything) ... 6, pivots in 64-column blocks (chains of followers) and in 192-column blocks."""
+    import cholesky_amd as ca
+    m, o, c, _ = case_paths("lapl_3375x3375")
+    P = ca.Plan(m, o, c)
+    for tail in (0, 1, 2, 4, 6):
+        for workers in (256, 8):
+            P.program_check_opts(follow_tail=tail, workers=workers)
+    P.program_check_opts(follow_tail=1, split_min=64, split_nb=64, workers=16)
+    P.program_check_opts(follow_tail=3, split_min=96, split_nb=96, workers=16)
+    P.program_check_opts(split_min=192, split_nb=192, workers=16)
+    G = ca.Problem(14, 14, 14, 4, 16).plan()
+    for tail in (0, 2, 4):
+        G.program_check_opts(follow_tail=tail, workers=16)
+
+
 def test_program_launch_on_generated_problems():
     import cholesky_amd as ca
     for dims in [(7, 5, 3, 3, 4), (12, 12, 12, 4, 16), (10, 9, 8, 5, 8)]:
