@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="cholamd_device_set_option switch for this run (e.g. program=0: level-by-level launches), repeatable; recorded in config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2, help="extra figure (not the metric): independent factorisations kept this many at a time on device objects / streams of their own; 0 or 1 = skip")
+    ap.add_argument("--in-flight", type=int, default=4, help="extra figure (not the metric): independent factorisations kept this many at a time on device objects / streams of their own; 0 or 1 = skip")
     args = ap.parse_args()
     if args.gpus < 1 or args.gpus & (args.gpus - 1):
         sys.exit("bench.py: --gpus must be a power of two (the separator tree is cut at level log2(gpus))")
