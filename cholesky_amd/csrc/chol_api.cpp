@@ -246,6 +246,7 @@ extern "C" int cholamd_device_set_option(cholamd_device *d, const char *name, in
   else if (n == "follow") d->opt.follow = value != 0;
   else if (n == "super_blocks") d->opt.super_blocks = value;
   else if (n == "follow_tail") d->opt.follow_tail = value;
+  else if (n == "staged") d->opt.staged = value != 0;
   else if (n == "dist_top") d->opt.dist_top = value;
   else if (n == "solve_reference_shape") { d->solve_reference_shape = value != 0; rebuild = false; }
   else { chol_set_error("unknown option '%s'", n.c_str()); return CHOLAMD_ERR_ARG; }
@@ -918,7 +919,7 @@ static int fused_update(const cholamd_region *rA, const cholamd_region *rB, cons
                a.sep_x, a.sep_y, a.cluster, a.lo_x, a.lo_y, a.hi_x, a.hi_y, sAx, sAy, b.sep_x, b.sep_y, b.cluster, b.lo_x, b.lo_y, b.hi_x, b.hi_y, sBx, b.hi_y - b.lo_y + 1,
                c->sep_x, c->sep_y, c->cluster, c->lo_x, c->lo_y, c->hi_x, c->hi_y, sCx, sCy, c->sep_x, c->sep_y, level, interval);
       const bool syrk = is_syrk && col == row;
-      chol_upd_src s = { poff(tile_ptr(rA, &a)), poff(tile_ptr(rB, &b)), rA->ld, rB->ld, sAy, 0 };
+      chol_upd_src s = { poff(tile_ptr(rA, &a)), poff(tile_ptr(rB, &b)), rA->ld, rB->ld, sAy, 0, 0, 0 };
       srcs.push_back(s);
       // distinct (a, b) pairs address distinct C tiles inside one fused task, so one source per task group
       add_update_tasks(tasks, (int)srcs.size() - 1, (int)srcs.size(), tile_ptr(rC, c), rC->ld, syrk ? sCx : sAx, syrk ? sCx : sBx, syrk);

@@ -131,6 +131,33 @@ __global__ void k_scatter(double *__restrict__ arena, const int64_t *__restrict_
   for (; i < nnz; i += stride) arena[dst[i]] = val[i];
 }
 
+// Staged waits of an extend-add job of the program launch (chol_upd_src.stage): the job's sources become readable one source pivot
+// block after the other; a wave looks at the remaining waits in ONE poll (every lane one entry) and polls again only in front of a
+// source whose stage does not hold yet.  The wave that polled reads the source with sc1 loads afterwards (the hand-off form of
+// wait_list / the job-level waits).
+struct stage_waits { const chol_wait *w; int n; const int *ctr; const int *ctr_total; int epoch; int *info; };
+__device__ __forceinline__ int stages_holding(const stage_waits &sw, int lane)
+{ // leading waits that hold
+  int lead = 0;
+  for (int b0 = 0; b0 < sw.n; b0 += 64) {
+    bool ok = true;
+    if (b0 + lane < sw.n) { const chol_wait wt = sw.w[b0 + lane]; ok = __hip_atomic_load(&sw.ctr[wt.ctr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wt.value + sw.epoch * sw.ctr_total[wt.ctr]; }
+    const unsigned long long notok = __ballot(!ok);
+    if (notok) return lead + __builtin_ctzll(notok);
+    lead = min(b0 + 64, sw.n);
+  }
+  return lead;
+}
+__device__ __forceinline__ int wait_stage(const stage_waits &sw, int need, int lane)
+{
+  int have = stages_holding(sw, lane);
+  for (int it = 0; have < need; ++it) {
+    if (it >= (1 << 15)) { if (lane == 0) atomicCAS(&sw.info[0], 0, CHOLAMD_ERR_STALL); return sw.n; }
+    __builtin_amdgcn_s_sleep(16);
+    have = stages_holding(sw, lane);
+  }
+  return have;
+}
 // ------------------------------------------------------------------------------------------------
 // UPDATE: one workgroup (4 waves) per 16x16 output sub-tile of a target C tile.  The tile's sources
 // are walked in the reference's program order; the four waves split every source's K range, or -- from
@@ -148,7 +175,7 @@ __global__ void k_scatter(double *__restrict__ arena, const int64_t *__restrict_
 // descriptor and the C sub-tile are requested before that wait.
 template <bool PUB>
 __device__ __forceinline__ void update_task_body(double *__restrict__ base, const chol_upd_task t, const chol_upd_src *__restrict__ srcs, double (*sAcc)[4][64],
-                                                 int wave, int lane, bool live, const int *wait, int wait_target, int *info)
+                                                 int wave, int lane, bool live, const int *wait, int wait_target, int *info, const stage_waits sw = stage_waits())
 {
   // the C sub-tile is requested first (wave 0; clamped addresses, masked at the store): read at the end, each of
   // its four columns would be a memory round trip of its own on the tail of every task
@@ -165,17 +192,20 @@ __device__ __forceinline__ void update_task_body(double *__restrict__ base, cons
   if (PUB && wait) (void)wait_progress(wait, wait_target, 0, info);
   d4 acc = { 0.0, 0.0, 0.0, 0.0 };
   const int nsrc = live ? t.src_end - t.src_begin : 0;
+  int st_done = (PUB && sw.n > 0 && nsrc > 0) ? stages_holding(sw, lane) : 0;
   if (nsrc >= 4) {
     // many sources (a target high in the tree collects one per descendant): the waves take whole sources
     // round-robin, so four descriptor -> operand load chains are in flight instead of one
     for (int s = t.src_begin + wave; s < t.src_end; s += 4) {
       const chol_upd_src sd = srcs[s];
+      if (PUB && sd.stage > st_done) st_done = wait_stage(sw, sd.stage, lane);
       const int r0 = sd.range & 255, r1 = sd.range ? (sd.range >> 8) & 255 : t.mv, c0 = (sd.range >> 16) & 255, c1 = sd.range ? (sd.range >> 24) & 255 : t.nv;
       acc = rank_k_16x16<PUB>(acc, base + sd.a_off + t.ar, sd.lda, r1, base + sd.b_off + t.br, sd.ldb, c1, sd.k, lane, r0, c0);
     }
   } else {
     for (int s = t.src_begin; s < t.src_end; ++s) {
       const chol_upd_src sd = srcs[s];
+      if (PUB && live && sd.stage > st_done) st_done = wait_stage(sw, sd.stage, lane);
       const int kc = ((((sd.k + 3) >> 2) + 3) >> 2) << 2; // K per wave, a multiple of 4
       const int k_lo = wave * kc;
       if (k_lo < sd.k) {
@@ -203,7 +233,7 @@ __device__ __forceinline__ void update_task_body(double *__restrict__ base, cons
 // the same task by ONE wave (program launch: twelve tasks of a job at a time, one per wave -- no K split, no LDS reduction,
 // no barrier; sources in program order, K in order: deterministic)
 template <bool PUB>
-__device__ __forceinline__ void update_task_wave(double *__restrict__ base, const chol_upd_task t, const chol_upd_src *__restrict__ srcs, int lane)
+__device__ __forceinline__ void update_task_wave(double *__restrict__ base, const chol_upd_task t, const chol_upd_src *__restrict__ srcs, int lane, const stage_waits sw = stage_waits())
 {
   const int r = lane & 15, g = lane >> 4;
   double cv[4];
@@ -211,8 +241,10 @@ __device__ __forceinline__ void update_task_wave(double *__restrict__ base, cons
 #pragma unroll
   for (int q = 0; q < 4; ++q) cv[q] = gload<PUB>(C + min(r, t.mv - 1) + (int64_t)min(g + 4 * q, t.nv - 1) * t.ldc);
   d4 acc = { 0.0, 0.0, 0.0, 0.0 };
+  int st_done = (PUB && sw.n > 0) ? stages_holding(sw, lane) : 0;
   for (int s = t.src_begin; s < t.src_end; ++s) {
     const chol_upd_src sd = srcs[s];
+    if (PUB && sd.stage > st_done) st_done = wait_stage(sw, sd.stage, lane);
     const int r0 = sd.range & 255, r1 = sd.range ? (sd.range >> 8) & 255 : t.mv, c0 = (sd.range >> 16) & 255, c1 = sd.range ? (sd.range >> 24) & 255 : t.nv;
     acc = rank_k_16x16<PUB>(acc, base + sd.a_off + t.ar, sd.lda, r1, base + sd.b_off + t.br, sd.ldb, c1, sd.k, lane, r0, c0);
   }
@@ -1686,8 +1718,8 @@ __global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ bas
       for (int sx = tpre.src_begin; sx < tpre.src_end; ++sx) touch += srcs[sx].k;
       asm volatile("" :: "s"(touch));
     }
-    if (jb.n_wait > 0 && !(jb.kind == 0 && jb.n_ext > 0)) { // a follower looks at its waits itself (potrf_rr_body)
-      if (wave == 0) wait_list(waits + jb.wait_first, jb.n_wait, ctr, ctr_total, epoch, lane, info);
+    if (jb.n_pre > 0 && !(jb.kind == 0 && jb.n_ext > 0)) { // a follower looks at its waits itself (potrf_rr_body); an extend-add job's staged waits are its tasks' business
+      if (wave == 0) wait_list(waits + jb.wait_first, jb.n_pre, ctr, ctr_total, epoch, lane, info);
       lds_barrier();
     }
     if (trace && tid == 0) trace[4 * j + 1] = __builtin_amdgcn_s_memrealtime(); // a follower overwrites it when its followed columns are in
@@ -1702,10 +1734,12 @@ __global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ bas
       if (grp >= jb.n) d.m = 0; // every group runs the same number of barriers: the strips of a job share one pivot block
       trsm_rr_body<true, FUSED_SLOTS>(base, ws, d, sX[grp], wave & 3, lane, ctr + d.flag, epoch * ctr_total[d.flag], info, d.chan >= 0 ? ctr + d.chan : nullptr);
     } else {
+      stage_waits sw;
+      sw.w = waits + jb.wait_first + jb.n_pre; sw.n = jb.n_wait - jb.n_pre; sw.ctr = ctr; sw.ctr_total = ctr_total; sw.epoch = epoch; sw.info = info;
       if (jb.mode == 0) {
         for (int t0 = jb.first; t0 < jb.first + jb.n; t0 += RR_NW + 1) { // light tasks: one per wave
           const int tk = t0 + wave;
-          if (tk < jb.first + jb.n) update_task_wave<true>(base, t0 == jb.first ? tpre : tasks[tk], srcs, lane);
+          if (tk < jb.first + jb.n) update_task_wave<true>(base, t0 == jb.first ? tpre : tasks[tk], srcs, lane, sw);
         }
       } else { // heavy tasks: three at a time, four waves each (K or the sources split, fixed-order LDS reduction)
         double (*sAcc)[3][3][4][64] = (double (*)[3][3][4][64])smem; // [parity of the round][group]
@@ -1713,7 +1747,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ bas
         for (int t0 = jb.first; t0 < jb.first + jb.n; t0 += 3, ++round) {
           const int tk = t0 + grp;
           const bool live = tk < jb.first + jb.n;
-          update_task_body<true>(base, t0 == jb.first ? tpre : tasks[live ? tk : t0], srcs, sAcc[round & 1][grp], wave & 3, lane, live, nullptr, 0, info);
+          update_task_body<true>(base, t0 == jb.first ? tpre : tasks[live ? tk : t0], srcs, sAcc[round & 1][grp], wave & 3, lane, live, nullptr, 0, info, sw);
         }
       }
     }

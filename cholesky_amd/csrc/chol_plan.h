@@ -71,6 +71,8 @@ typedef struct {
   int range;            /* 0: the source covers the whole sub-tile; else r0 | r1 << 8 | c0 << 16 | c1 << 24: it covers rows
                          * [r0, r1) x columns [c0, c1) of it only (grid-cell tasks: a 16x16 cell of the target block cuts
                          * through the cluster tiles of the reference) */
+  int stage, pad;       /* program launch, extend-add jobs: the source may be read once the first `stage` staged waits of the job hold (0: no
+                         * staged wait); a task's sources are sorted by stage */
 } chol_upd_src;
 
 typedef struct {
@@ -95,7 +97,8 @@ typedef struct {
   int sig[2], sig_add; /* counters raised by sig_add once the job's stores have completed (-1: none); POTRF jobs publish
                         * their column progress themselves */
   int ext_first, n_ext;/* POTRF: the external panels it follows (chol_ext), none = plain POTRF */
-  int mode, pad;       /* update: 0 = one wave per task (light tasks, twelve at a time), 1 = four waves per task splitting K / the sources
+  int mode, n_pre;     /* n_pre: the leading waits that gate the whole job; the others are STAGED (update jobs of the extend-add: one per source
+                        * pivot block in expected order of completion, chol_upd_src.stage) and are looked at by the tasks.  mode: update: 0 = one wave per task (light tasks, twelve at a time), 1 = four waves per task splitting K / the sources
                         * (heavy tasks, three at a time) */
 } chol_job;
 typedef struct {       /* one followed column tile: (rows of the follower's block) x (16 columns of a source pivot block).  A follower's items are
@@ -136,6 +139,7 @@ typedef struct {
   int follow;               /* ... in which pivot blocks follow their children's / predecessor's TRSM strips */
   int dist_top;             /* 0 / 1 / 2 = auto (CHOL_DIST_MIN); world > 1: the levels above the cut are distributed over the ranks by column blocks (owner factors and
                              * solves a block, broadcasts it, every rank updates the column blocks it owns) instead of replicated */
+  int staged;               /* program launch: the extend-add jobs take their sources as the source pivots finish (staged waits) */
   int follow_tail;          /* a follower wider than CHOL_FOLLOW_ALL_MAXT column tiles takes only the LAST follow_tail column tiles of each source
                              * itself; the columns before them reach its diagonal block through update jobs on other CUs (0: follows everything) */
   int super_blocks;         /* column blocks per super-block of a wide pivot: the trailing matrix beyond a super-block gets one update of

@@ -46,6 +46,7 @@ typedef struct {
   int64_t c_off, a_off, b_off;
   int ldc, lda, ldb, m, n, k, syrk;
   int bc, crow, ccol; /* the target block and the tile's first row / column inside it */
+  int src_sep;        /* the separator whose panel the contribution comes from */
 } upd_tuple;
 
 static int cmp_tuple(const void *x, const void *y)
@@ -84,7 +85,7 @@ static int env_int(const char *name, int dflt) { const char *e = getenv(name); r
 void chol_sched_opts_default(chol_sched_opts *o)
 {
   o->split_min = CHOL_SPLIT_MIN; o->split_nb = CHOL_SPLIT_NB; o->fuse = 1; o->fuse_update_max = CHOL_FUSE_UPDATE_MAX;
-  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL;
+  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL; o->staged = 1;
 }
 void chol_sched_opts_from_env(chol_sched_opts *o)
 {
@@ -100,6 +101,7 @@ void chol_sched_opts_from_env(chol_sched_opts *o)
   o->dist_top = env_int("CHOLAMD_DIST_TOP", o->dist_top);
   o->super_blocks = env_int("CHOLAMD_SUPER_BLOCKS", o->super_blocks);
   o->follow_tail = env_int("CHOLAMD_FOLLOW_TAIL", o->follow_tail);
+  o->staged = !env_int("CHOLAMD_NO_STAGED", 0);
 }
 static int split_nb(const chol_sched_opts *o) { int v = o->split_nb; if (v > CHOL_RR_MAXN) v = CHOL_RR_MAXN; v = (v + 15) / 16 * 16; if (v < 16) v = 16; return v; }
 static int pivot_blocks(const chol_sched_opts *o, int n) { return n > o->split_min || n > CHOL_RR_MAXN ? (n + split_nb(o) - 1) / split_nb(o) : 1; }
@@ -239,7 +241,7 @@ static void flush_targets(builder *B)
  * chol_upd_src.range); sources stay in program order, every element keeps exactly one owner.  Diagonal blocks: cells
  * above the diagonal are skipped, diagonal cells store row >= column only (the reference skips col > row cluster
  * pairs and runs SYRK on col == row, blas.rg:396-431: the same elements).  Returns the number of tasks. */
-typedef struct { int64_t key, seq, c_off, a_off, b_off; int ldc, lda, ldb, k, mv, nv, lower, range; } cell_piece;
+typedef struct { int64_t key, seq, c_off, a_off, b_off; int ldc, lda, ldb, k, mv, nv, lower, range, src_sep; } cell_piece;
 static int cmp_piece(const void *x, const void *y)
 {
   const cell_piece *a = x, *b = y;
@@ -276,6 +278,7 @@ static int emit_cell_tasks(builder *B, const plan_t *p, const upd_tuple *tu, int
         q->a_off = u->a_off + (16 * I - u->crow); q->lda = u->lda;
         q->b_off = u->b_off + (16 * J - u->ccol); q->ldb = u->ldb;
         q->k = u->k;
+        q->src_sep = u->src_sep;
         q->range = r0 | (r1 << 8) | (c0 << 16) | (c1 << 24);
       }
   }
@@ -298,8 +301,21 @@ static int emit_cell_tasks(builder *B, const plan_t *p, const upd_tuple *tu, int
         if (b1 > c1) c1 = b1;
         f++;
       }
-      chol_upd_src sd = { pc[q].a_off, pc[q].b_off, pc[q].lda, pc[q].ldb, pc[q].k, r0 | (r1 << 8) | (c0 << 16) | (c1 << 24) };
-      push_src(B, sd);
+      const int rg_ = r0 | (r1 << 8) | (c0 << 16) | (c1 << 24);
+      if (B->force_fine && B->o->staged) {
+        /* program launch with staged waits: one source per pivot BLOCK of the source separator (its columns c0 .. c0 + nb of the
+         * panel), tagged -(64 separator + block) - 1 for now (emit_update_jobs turns the tag into the stage): what is left to
+         * do when the separator's last block has been solved is that block's columns, not the whole pivot's */
+        const int bw_ = pivot_block_width(B->o, p->sep_size[pc[q].src_sep]);
+        for (int cb = 0, st_ = 0; cb < pc[q].k; cb += bw_, st_++) {
+          const int kb = pc[q].k - cb < bw_ ? pc[q].k - cb : bw_;
+          chol_upd_src sd = { pc[q].a_off + (int64_t)cb * pc[q].lda, pc[q].b_off + (int64_t)cb * pc[q].ldb, pc[q].lda, pc[q].ldb, kb, rg_, -(64 * pc[q].src_sep + st_) - 1, 0 };
+          push_src(B, sd);
+        }
+      } else {
+        chol_upd_src sd = { pc[q].a_off, pc[q].b_off, pc[q].lda, pc[q].ldb, pc[q].k, rg_, 0, 0 };
+        push_src(B, sd);
+      }
       q = f;
     }
     if (w->n_task == B->cap_k) { B->cap_k = B->cap_k ? 2 * B->cap_k : 256; w->task = realloc(w->task, B->cap_k * sizeof(chol_upd_task)); }
@@ -440,16 +456,16 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
         B->tgt_col0 = c0 + nb;
         if (ncol > 0) {
           const int64_t x_piv = p->panel_off[s] + (c0 + nb) + colbase;         /* solved pivot rows under the block, k = nb */
-          chol_upd_src sp = { x_piv, x_piv, ld, ld, nb, 0 };
+          chol_upd_src sp = { x_piv, x_piv, ld, ld, nb, 0, 0, 0 };
           const int sidx = push_src(B, sp);
           push_tasks(B, p->panel_off[s] + (c0 + nb) + (int64_t)(c0 + nb) * ld, ld, ncol, ncol, 1, sidx, sidx + 1); /* rows inside the super-block: lower triangle */
           if (below > ncol) { /* pivot rows beyond the super-block x its remaining columns */
-            chol_upd_src sq = { x_piv + ncol, x_piv, ld, ld, nb, 0 };
+            chol_upd_src sq = { x_piv + ncol, x_piv, ld, ld, nb, 0, 0, 0 };
             const int si = push_src(B, sq);
             push_tasks(B, p->panel_off[s] + cse + (int64_t)(c0 + nb) * ld, ld, below - ncol, ncol, 0, si, si + 1);
           }
           for (int r = 0; r < nr; r++) {
-            chol_upd_src sa = { runs[r].off + colbase, x_piv, ld, ld, nb, 0 };
+            chol_upd_src sa = { runs[r].off + colbase, x_piv, ld, ld, nb, 0, 0, 0 };
             const int si = push_src(B, sa);
             push_tasks(B, runs[r].off + (int64_t)(c0 + nb) * ld, ld, runs[r].m, ncol, 0, si, si + 1);
           }
@@ -459,11 +475,11 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
         if (last_in_sb && cse < n) {
           const int K = cse - cs0, rest = n - cse;
           const int64_t x_sb = p->panel_off[s] + cse + (int64_t)cs0 * ld;      /* pivot rows beyond the super-block, its columns */
-          chol_upd_src sp = { x_sb, x_sb, ld, ld, K, 0 };
+          chol_upd_src sp = { x_sb, x_sb, ld, ld, K, 0, 0, 0 };
           const int sidx = push_src(B, sp);
           push_tasks(B, p->panel_off[s] + cse + (int64_t)cse * ld, ld, rest, rest, 1, sidx, sidx + 1);
           for (int r = 0; r < nr; r++) {
-            chol_upd_src sa = { runs[r].off + (int64_t)cs0 * ld, x_sb, ld, ld, K, 0 };
+            chol_upd_src sa = { runs[r].off + (int64_t)cs0 * ld, x_sb, ld, ld, K, 0, 0, 0 };
             const int si = push_src(B, sa);
             push_tasks(B, runs[r].off + (int64_t)cse * ld, ld, runs[r].m, rest, 0, si, si + 1);
           }
@@ -538,7 +554,7 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
             u->b_off = Bb->off + (fb_->lo_x - Bb->lo_x); u->ldb = Bb->ld;
             u->m = fa->hi_x - fa->lo_x + 1; u->n = fb_->hi_x - fb_->lo_x + 1; u->k = n;
             u->syrk = (gp == par && fb_->cluster == fa->cluster);
-            u->bc = bc; u->crow = crow; u->ccol = ccol;
+            u->bc = bc; u->crow = crow; u->ccol = ccol; u->src_sep = s;
           }
         }
       }
@@ -554,7 +570,7 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
       while (e < ntu && tu[e].key == tu[i].key) e++;
       const int sb = w->n_src;
       for (int q = i; q < e; q++) {
-        chol_upd_src sd = { tu[q].a_off, tu[q].b_off, tu[q].lda, tu[q].ldb, tu[q].k, 0 };
+        chol_upd_src sd = { tu[q].a_off, tu[q].b_off, tu[q].lda, tu[q].ldb, tu[q].k, 0, 0, 0 };
         push_src(B, sd);
       }
       if (dist) { B->tgt_sep = p->blk[tu[i].bc].c; B->tgt_col0 = tu[i].ccol; }
@@ -650,7 +666,7 @@ static chol_job *add_job(pbuild *P, int kind, int first, int n, int wait_first)
 {
   chol_program *g = P->pg;
   if (g->n_job == P->cap_j) { P->cap_j = P->cap_j ? 2 * P->cap_j : 1024; g->job = realloc(g->job, P->cap_j * sizeof(chol_job)); }
-  chol_job j = { kind, first, n, wait_first, g->n_wait - wait_first, { -1, -1 }, 0, g->n_ext, 0, 0, 0 };
+  chol_job j = { kind, first, n, wait_first, g->n_wait - wait_first, { -1, -1 }, 0, g->n_ext, 0, 0, g->n_wait - wait_first };
   g->job[g->n_job] = j;
   return &g->job[g->n_job++];
 }
@@ -707,10 +723,12 @@ static int emit_trsm_jobs(pbuild *P, builder *B, int t0, int c_upd, int need_upd
 /* update jobs over the tasks [k0, n_task): consecutive tasks of one target block, at most PROG_JOB_TASKS each; every job waits
  * for the strips of its source pivot blocks (src_ctr / src_need pairs) and for the update jobs of earlier phases into its panel */
 static void emit_update_jobs(pbuild *P, builder *B, const plan_t *p, int k0, const int *c_upd, const int *c_updd, const int *snap_upd, int *cnt_upd, int *cnt_updd,
-                             const int *src_ctr, const int *src_need, int n_src_ctr, const int *src_sep_of /* NULL: all sources apply */)
-{
+                             const int *src_ctr, const int *src_need, int n_src_ctr, const int *stage_sep /* NULL: every wait gates the whole job */)
+{ /* stage_sep (extend-add of a level): src_ctr[i] is the strips counter of a pivot block of separator stage_sep[i], the list in the
+   * order the blocks are expected to finish.  Those waits are STAGED: the job starts as soon as the earlier update jobs into its
+   * panel are through, every task takes its sources in that order and looks at wait i only before the first source that needs it --
+   * what is left once the last source pivot has been solved is that pivot's contribution alone, not every descendant's */
   chol_level_work *w = B->w;
-  (void)src_sep_of;
   for (int i = k0; i < w->n_task;) {
     /* a task is heavy when its sources add up to PROG_HEAVY_STEPS MFMA k-steps or more (one wave would take them one memory
      * round trip after the other): heavy tasks go three to a job, four waves each; light ones twelve to a job, one wave each */
@@ -722,10 +740,34 @@ static void emit_update_jobs(pbuild *P, builder *B, const plan_t *p, int k0, con
 #undef TASK_STEPS
     const chol_block *Bc = &p->blk[w->task[i].blk];
     const int wf = P->pg->n_wait;
+    if (stage_sep) add_wait(P, c_upd[Bc->c], snap_upd[Bc->c]);
+    const int n_pre = P->pg->n_wait - wf;
     for (int q = 0; q < n_src_ctr; q++) add_wait(P, src_ctr[q], src_need[q]);
-    add_wait(P, c_upd[Bc->c], snap_upd[Bc->c]);
+    if (!stage_sep) add_wait(P, c_upd[Bc->c], snap_upd[Bc->c]);
     chol_job *j = add_job(P, 2, i, e - i, wf);
     j->mode = heavy;
+    if (stage_sep) {
+      j->n_pre = n_pre;
+      for (int t = i; t < e; t++) {
+        chol_upd_task *tk = &w->task[t];
+        for (int q = tk->src_begin; q < tk->src_end; q++) { /* -(separator) - 1 -> number of staged waits that must hold: through its last pivot
+                                                              * block; sub-tiles of one target share their sources: converted once */
+          if (w->src[q].stage > 0) continue;
+          int st = n_src_ctr;
+          if (w->src[q].stage < 0) { /* tag 64 separator + block (block 63: the whole pivot): the last listed block of the separator up to that one */
+            const int tag = -w->src[q].stage - 1;
+            for (int z = n_src_ctr - 1; z >= 0; z--) if (stage_sep[z] / 64 == tag / 64 && stage_sep[z] % 64 <= tag % 64) { st = z + 1; break; }
+          }
+          w->src[q].stage = st;
+        }
+        for (int a = tk->src_begin + 1; a < tk->src_end; a++) { /* stable insertion sort by stage */
+          const chol_upd_src x = w->src[a];
+          int b = a - 1;
+          while (b >= tk->src_begin && w->src[b].stage > x.stage) { w->src[b + 1] = w->src[b]; b--; }
+          w->src[b + 1] = x;
+        }
+      }
+    } else for (int t = i; t < e; t++) for (int q = w->task[t].src_begin; q < w->task[t].src_end; q++) w->src[q].stage = 0;
     j->sig[0] = c_upd[Bc->c]; j->sig[1] = Bc->r == Bc->c ? c_updd[Bc->c] : -1; j->sig_add = 1;
     cnt_upd[Bc->c]++;
     if (Bc->r == Bc->c) cnt_updd[Bc->c]++;
@@ -751,7 +793,7 @@ static void emit_early_cells(pbuild *P, builder *B, const plan_t *p, int64_t c_o
     for (int J = 0; J <= I; J++) {
       const int sb = w->n_src;
       for (int q = 0; q < nes; q++)
-        if (es[q].k > 0) { chol_upd_src sd = { es[q].off + CHOL_NB * I, es[q].off + CHOL_NB * J, es[q].ld, es[q].ld, es[q].k, 0 }; push_src(B, sd); }
+        if (es[q].k > 0) { chol_upd_src sd = { es[q].off + CHOL_NB * I, es[q].off + CHOL_NB * J, es[q].ld, es[q].ld, es[q].k, 0, 0, 0 }; push_src(B, sd); }
       if (w->n_task == B->cap_k) { B->cap_k = B->cap_k ? 2 * B->cap_k : 256; w->task = realloc(w->task, B->cap_k * sizeof(chol_upd_task)); }
       chol_upd_task *t = &w->task[w->n_task++];
       memset(t, 0, sizeof *t);
@@ -959,21 +1001,21 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
             const int nb1 = pb[s][st + 1].nb, r2 = below - nb1;
             if (r2 > 0) {
               const int64_t x2 = x_piv + nb1;
-              chol_upd_src s1 = { x2, x_piv, ld, ld, nb, 0 }, s2 = { x2, x2, ld, ld, nb, 0 };
+              chol_upd_src s1 = { x2, x_piv, ld, ld, nb, 0, 0, 0 }, s2 = { x2, x2, ld, ld, nb, 0, 0, 0 };
               const int i1 = push_src(B, s1);
               push_tasks(B, p->panel_off[s] + (c0 + nb + nb1) + (int64_t)(c0 + nb) * ld, ld, r2, nb1, 0, i1, i1 + 1);
               const int i2 = push_src(B, s2);
               push_tasks(B, p->panel_off[s] + (c0 + nb + nb1) + (int64_t)(c0 + nb + nb1) * ld, ld, r2, r2, 1, i2, i2 + 1);
             }
           } else {
-            chol_upd_src sp = { x_piv, x_piv, ld, ld, nb, 0 };
+            chol_upd_src sp = { x_piv, x_piv, ld, ld, nb, 0, 0, 0 };
             const int sidx = push_src(B, sp);
             push_tasks(B, p->panel_off[s] + (c0 + nb) + (int64_t)(c0 + nb) * ld, ld, below, below, 1, sidx, sidx + 1);
           }
           row_run *runs; const int nr = ancestor_runs(p, h, snap, first, count, &runs);
           for (int r = 0; r < nr; r++) {
             /* which ancestor block the run lies in (runs never span two blocks' targets differently: the target is panel s) */
-            chol_upd_src sa = { runs[r].off + colbase, x_piv, ld, ld, nb, 0 };
+            chol_upd_src sa = { runs[r].off + colbase, x_piv, ld, ld, nb, 0, 0, 0 };
             const int si = push_src(B, sa);
             push_tasks(B, runs[r].off + (int64_t)(c0 + nb) * ld, ld, runs[r].m, below, 0, si, si + 1);
           }
@@ -1065,7 +1107,7 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
                 u->b_off = Bb->off + (fb_->lo_x - Bb->lo_x); u->ldb = Bb->ld;
                 u->m = fa->hi_x - fa->lo_x + 1; u->n = fb_->hi_x - fb_->lo_x + 1; u->k = n;
                 u->syrk = (gp == par && fb_->cluster == fa->cluster);
-                u->bc = bc; u->crow = crow; u->ccol = ccol;
+                u->bc = bc; u->crow = crow; u->ccol = ccol; u->src_sep = s;
               }
             }
           }
@@ -1084,7 +1126,7 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
             int e = i + 1;
             while (e < ntu && tu[e].key == tu[i].key) e++;
             const int sb = w->n_src;
-            for (int q = i; q < e; q++) { chol_upd_src sd = { tu[q].a_off, tu[q].b_off, tu[q].lda, tu[q].ldb, tu[q].k, 0 }; push_src(B, sd); }
+            for (int q = i; q < e; q++) { chol_upd_src sd = { tu[q].a_off, tu[q].b_off, tu[q].lda, tu[q].ldb, tu[q].k, 0, -(64 * tu[q].src_sep + 63) - 1, 0 }; push_src(B, sd); }
             B->cur_blk = tu[i].bc;
             push_tasks(B, tu[i].c_off, tu[i].ldc, tu[i].m, tu[i].n, tu[i].syrk, sb, w->n_src);
             i = e;
@@ -1119,17 +1161,27 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
           const int hpar = p->heap_of[Bc->c], dl = level - p->level_of[Bc->c];
           int nsc = 0, capsc = 1;
           for (int hh = hpar << dl; hh < ((hpar + 1) << dl); hh++) capsc += nblk_of[p->tree[hh]];
-          int *sc = malloc(capsc * sizeof(int)), *sn = malloc(capsc * sizeof(int));
+          int *sc = malloc(capsc * sizeof(int)), *sn = malloc(capsc * sizeof(int)), *ssep = malloc(capsc * sizeof(int)), *sest = malloc(capsc * sizeof(int));
           for (int hh = hpar << dl; hh < ((hpar + 1) << dl); hh++) {
             const int s = p->tree[hh];
-            for (int st = 0; st < nblk_of[s]; st++)
-              if (pb[s][st].n_groups > 0) { sc[nsc] = pb[s][st].c_strips; sn[nsc] = pb[s][st].n_groups; nsc++; }
+            int through = 0;
+            for (int st = 0; st < nblk_of[s]; st++) {
+              through += (pb[s][st].nb + CHOL_NB - 1) / CHOL_NB;
+              if (pb[s][st].n_groups > 0) { sc[nsc] = pb[s][st].c_strips; sn[nsc] = pb[s][st].n_groups; ssep[nsc] = 64 * s + st; sest[nsc] = est_start[s] + through; nsc++; }
+            }
+          }
+          for (int a = 1; a < nsc; a++) { /* expected order of completion (stable) */
+            const int c0_ = sc[a], n0_ = sn[a], s0_ = ssep[a], e0_ = sest[a];
+            int b = a - 1;
+            while (b >= 0 && sest[b] > e0_) { sc[b + 1] = sc[b]; sn[b + 1] = sn[b]; ssep[b + 1] = ssep[b]; sest[b + 1] = sest[b]; b--; }
+            sc[b + 1] = c0_; sn[b + 1] = n0_; ssep[b + 1] = s0_; sest[b + 1] = e0_;
           }
           /* emit_update_jobs walks [i, n_task): hand it exactly this block's tasks */
           const int keep = w->n_task;
           w->n_task = e;
-          emit_update_jobs(P, B, p, i, c_upd, c_updd, snap_upd, cnt_upd, cnt_updd, sc, sn, nsc, NULL);
+          emit_update_jobs(P, B, p, i, c_upd, c_updd, snap_upd, cnt_upd, cnt_updd, sc, sn, nsc, opts->staged ? ssep : NULL);
           w->n_task = keep;
+          free(ssep); free(sest);
           free(sc); free(sn);
         }
         free(rg);

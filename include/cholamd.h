@@ -283,7 +283,9 @@ int cholamd_factor_info(cholamd_device *d, int *sep_out);
  * "split_nb", "fuse", "fuse_update_max", "mt_min_tiles", "cells", "solve_reference_shape", "program" (the whole factorisation
  * of a small problem as one launch; CHOLAMD_NO_PROGRAM), "follow" (its pivot blocks follow their children's TRSM strips;
  * CHOLAMD_NO_FOLLOW), "follow_tail" (followers of more than four tile columns take the last follow_tail column tiles of each source
- * themselves, update jobs bring the rest; 0 = they take everything; CHOLAMD_FOLLOW_TAIL), "super_blocks", "dist_top" (0 / 1 / 2 = automatic: top levels of a partitioned run distributed by column
+ * themselves, update jobs bring the rest; 0 = they take everything; CHOLAMD_FOLLOW_TAIL), "staged" (the extend-add jobs of the
+ * program launch take their sources pivot block by pivot block as those are solved instead of waiting for all of them;
+ * CHOLAMD_NO_STAGED), "super_blocks", "dist_top" (0 / 1 / 2 = automatic: top levels of a partitioned run distributed by column
  * blocks, see Multi-GPU below; CHOLAMD_DIST_TOP).  Rebuilds the work lists. */
 int cholamd_device_set_option(cholamd_device *d, const char *name, int value);
 /* Solve phase, mmat.rg:1364-1495: b and x in ORIGINAL dof order (device pointers, n doubles).

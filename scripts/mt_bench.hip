@@ -44,7 +44,7 @@ int main(int argc, char **argv)
       t.lower = a == b; t.src_begin = 0; t.src_end = 1; t.ar = a * TSZ; t.br = b * TSZ;
       tasks.push_back(t);
     }
-  chol_upd_src src = { (int64_t)((uintptr_t)dX / 8), (int64_t)((uintptr_t)dX / 8), n, n, k, 0 };
+  chol_upd_src src = { (int64_t)((uintptr_t)dX / 8), (int64_t)((uintptr_t)dX / 8), n, n, k, 0, 0, 0 };
   chol_upd_task *dt; chol_upd_src *ds;
   hipMalloc(&dt, tasks.size() * sizeof(chol_upd_task)); hipMalloc(&ds, sizeof src);
   hipMemcpy(dt, tasks.data(), tasks.size() * sizeof(chol_upd_task), hipMemcpyHostToDevice);

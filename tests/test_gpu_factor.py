@@ -214,6 +214,8 @@ def _ntiles_table(case):
     {"follow_tail": 0},                                # followers take every column tile of their sources themselves (no early update jobs)
     {"follow_tail": 2},                                # ... only the last two (most of the contribution through early jobs)
     {"follow_tail": 7},
+    {"staged": 0},                                     # extend-add jobs that wait for every source before they start (no staged waits)
+    {"follow": 0, "staged": 1},                        # without followers every contribution goes through (staged) update jobs
     {"split_min": 96, "split_nb": 96, "follow_tail": 1}, # three / four column blocks per leaf: chains of followers with early jobs
     {"program": 0},                                    # level by level: fused POTRF+TRSM launches + update launches
     {"program": 0, "fuse": 0},                         # separate POTRF / TRSM launches (k_potrf_rr, k_trsm_rr, k_trsm_w)
