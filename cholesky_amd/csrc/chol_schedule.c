@@ -780,20 +780,40 @@ static void emit_update_jobs(pbuild *P, builder *B, const plan_t *p, int k0, con
  * columns).  They become ordinary update jobs on other CUs that wait for the sources' channel counters (the strips publish their
  * column tiles in order: the last column needed stands for all) and for the earlier update jobs into the panel; the follower
  * itself takes only the last column tiles of each source (follow_external) and sees these through its own tiles. */
-typedef struct { int64_t off; int ld, k, ctr, need; } early_src;
+typedef struct { int64_t off; int ld, k, ctr, need; } early_src; /* ctr: the channel counter of the source's LAST early column tile (tiles before it: ctr - 1, ...) */
+#ifndef EARLY_CHUNK
+#define EARLY_CHUNK 2 /* column tiles per staged source of an early job (1 / 2 / 3 at follow_tail 3: 193.5 / 194.5 / 197.3 us on lapl_3375) */
+#endif
 static void emit_early_cells(pbuild *P, builder *B, const plan_t *p, int64_t c_off, int ldc, int lim, int blk, const early_src *es, int nes,
                              const int *c_upd, const int *c_updd, int *snap_upd, int *cnt_upd, int *cnt_updd)
 {
   chol_level_work *w = B->w;
-  int nsrc = 0;
-  for (int q = 0; q < nes; q++) nsrc += es[q].k > 0;
-  if (nsrc == 0) return;
+  /* the staged waits of these jobs: the sources in chunks of EARLY_CHUNK column tiles, chunk by chunk over the sources (the order
+   * in which the strips publish them, near enough); stage = position in this list + 1 */
+  int nst = 0, maxch = 0;
+  for (int q = 0; q < nes; q++) if (es[q].k > 0) { const int ch = ((es[q].k + CHOL_NB - 1) / CHOL_NB + EARLY_CHUNK - 1) / EARLY_CHUNK; nst += ch; if (ch > maxch) maxch = ch; }
+  if (nst == 0) return;
+  int *sc = malloc(nst * sizeof(int)), *sn = malloc(nst * sizeof(int)), *sq = malloc(nst * sizeof(int)), *sch = malloc(nst * sizeof(int));
+  nst = 0;
+  for (int c = 0; c < maxch; c++)
+    for (int q = 0; q < nes; q++) {
+      if (es[q].k <= 0) continue;
+      const int et = (es[q].k + CHOL_NB - 1) / CHOL_NB;
+      if (c * EARLY_CHUNK >= et) continue;
+      const int last = (c + 1) * EARLY_CHUNK < et ? (c + 1) * EARLY_CHUNK - 1 : et - 1; /* last column tile of the chunk */
+      sc[nst] = es[q].ctr - (et - 1) + last; sn[nst] = es[q].need; sq[nst] = q; sch[nst] = c; nst++;
+    }
+  const int staged = B->o->staged;
   const int k0 = w->n_task, Tl = (lim + CHOL_NB - 1) / CHOL_NB;
   for (int I = 0; I < Tl; I++)
     for (int J = 0; J <= I; J++) {
       const int sb = w->n_src;
-      for (int q = 0; q < nes; q++)
-        if (es[q].k > 0) { chol_upd_src sd = { es[q].off + CHOL_NB * I, es[q].off + CHOL_NB * J, es[q].ld, es[q].ld, es[q].k, 0, 0, 0 }; push_src(B, sd); }
+      for (int z = 0; z < nst; z++) {
+        const early_src *e = &es[sq[z]];
+        const int col0 = sch[z] * EARLY_CHUNK * CHOL_NB, kc = e->k - col0 < EARLY_CHUNK * CHOL_NB ? e->k - col0 : EARLY_CHUNK * CHOL_NB;
+        chol_upd_src sd = { e->off + CHOL_NB * I + (int64_t)col0 * e->ld, e->off + CHOL_NB * J + (int64_t)col0 * e->ld, e->ld, e->ld, kc, 0, staged ? z + 1 : 0, 0 };
+        push_src(B, sd);
+      }
       if (w->n_task == B->cap_k) { B->cap_k = B->cap_k ? 2 * B->cap_k : 256; w->task = realloc(w->task, B->cap_k * sizeof(chol_upd_task)); }
       chol_upd_task *t = &w->task[w->n_task++];
       memset(t, 0, sizeof *t);
@@ -804,12 +824,10 @@ static void emit_early_cells(pbuild *P, builder *B, const plan_t *p, int64_t c_o
       t->src_begin = sb; t->src_end = w->n_src;
       t->blk = blk;
     }
-  int *sc = malloc(nes * sizeof(int)), *sn = malloc(nes * sizeof(int)), ns = 0;
-  for (int q = 0; q < nes; q++) if (es[q].k > 0) { sc[ns] = es[q].ctr; sn[ns] = es[q].need; ns++; }
   const int col_sep = p->blk[blk].c;
   snap_upd[col_sep] = cnt_upd[col_sep];
-  emit_update_jobs(P, B, p, k0, c_upd, c_updd, snap_upd, cnt_upd, cnt_updd, sc, sn, ns, NULL);
-  free(sc); free(sn);
+  emit_update_jobs(P, B, p, k0, c_upd, c_updd, snap_upd, cnt_upd, cnt_updd, sc, sn, nst, staged ? sq : NULL); /* sq: only "staged" (the stages are set) */
+  free(sc); free(sn); free(sq); free(sch);
 }
 
 int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_work *w, chol_program *pg)
