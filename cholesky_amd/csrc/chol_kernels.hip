@@ -884,8 +884,14 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
   // whenever all of it is known to be ready.
   int ready = 0, ng = 0; // ng: items of the round starting at i whose loads are in flight (0 = not issued)
   double va[FOLLOW_LOADS], vb[FOLLOW_LOADS];
-  const int pair_lim = 2 * T <= RR_MAXT ? f.n_ext - 2 : 0; // items [i, i + 1] form a round while i + 1 < pair_lim
-  const int own_at = f.n_ext >= 2 ? f.n_ext - 2 : f.n_ext - 1; // never the second item of a pair
+#ifndef FOLLOW_SINGLE_TAIL
+#define FOLLOW_SINGLE_TAIL 2 /* last items of a follower's list that go one by one */
+#endif
+#ifndef FOLLOW_OWN_BEFORE
+#define FOLLOW_OWN_BEFORE 2  /* the follower's own tiles are added before its last FOLLOW_OWN_BEFORE items (<= FOLLOW_SINGLE_TAIL: never inside a pair) */
+#endif
+  const int pair_lim = 2 * T <= RR_MAXT ? f.n_ext - FOLLOW_SINGLE_TAIL : 0; // items [i, i + 1] form a round while i + 1 < pair_lim
+  const int own_at = f.n_ext >= FOLLOW_OWN_BEFORE ? f.n_ext - FOLLOW_OWN_BEFORE : 0;
 #define EXT_ROUND(I_) ((I_) + 1 < pair_lim ? 2 : 1)
 #define EXT_LOAD(I_, V_)                                                                                             \
   {                                                                                                                  \

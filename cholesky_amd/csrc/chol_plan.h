@@ -21,7 +21,10 @@ extern "C" {
 
 #define CHOL_NB 16        /* diagonal-block width of the POTRF/TRSM kernels = one fp64 MFMA tile */
 #define CHOL_RR_MAXN 272  /* largest pivot the register-resident kernels take (17 tiles) */
-#define CHOL_FOLLOW_ALL_MAXT 4 /* followers of at most this many column tiles take every column of their sources themselves */
+#ifndef CHOL_FOLLOW_ALL_MAXT
+#define CHOL_FOLLOW_ALL_MAXT 4
+#endif
+// /* followers of at most this many column tiles take every column of their sources themselves */
 #define CHOL_FOLLOW_TAIL 3     /* default of option follow_tail */
 #define CHOL_FOLLOW_MAXT 10 /* most column tiles of a pivot block that follows its sources inside the program launch (chol_kernels.hip, follow_external) */
 #define CHOL32_MAXN 128   /* widest pivot block of the fp32 path: its lower triangle is factored out of LDS (chol_kernels_f32.hip) */
