@@ -41,6 +41,7 @@ profiles) # every rocprofv3 pass behind profiles/r2/summary.json: key | bench ar
         SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU"
         while IFS='|' read -r key bargs nsteps mops traffic; do
           [ -z "$key" ] && continue
+          [ -n "$PROFILE_KEYS" ] && ! echo " $PROFILE_KEYS " | grep -q " $key " && continue
           d=$out/$key; mkdir -p $d
           (cd /tmp && run stats_$key 500 rocprofv3 --kernel-trace --stats --output-format csv -d $d/stats -o s -- python3 /root/repo/bench.py $bargs --steps $nsteps --warmup 2 --no-cpu-baseline > $d/bench_under_rocprof.json 2> $d/stats.err) || tail -3 $d/stats.err
           (cd /tmp && run pmc_$key 500 rocprofv3 --kernel-trace --pmc $SQ $mops GRBM_GUI_ACTIVE --output-format csv -d $d/pmc_SQ -o p -- python3 /root/repo/bench.py $bargs --steps $nsteps --warmup 2 --no-cpu-baseline > $d/pmc_SQ.json 2> $d/pmc_SQ.err) || tail -3 $d/pmc_SQ.err
@@ -49,8 +50,8 @@ profiles) # every rocprofv3 pass behind profiles/r2/summary.json: key | bench ar
           done; fi
           rm -f $d/*/*_kernel_trace.csv $d/*/*agent_info.csv   # per-dispatch traces are large; the stats / counter CSVs are what is kept
         done <<'LIST'
-lapl_3375|--case lapl_3375x3375|20|SQ_INSTS_VALU_MFMA_MOPS_F64|1
-lapl_3375_levels|--case lapl_3375x3375 --option program=0|20|SQ_INSTS_VALU_MFMA_MOPS_F64|1
+lapl_3375|--case lapl_3375x3375 --in-flight 0|20|SQ_INSTS_VALU_MFMA_MOPS_F64|1
+lapl_3375_levels|--case lapl_3375x3375 --option program=0 --in-flight 0|20|SQ_INSTS_VALU_MFMA_MOPS_F64|1
 gen_40_6|--case gen:40:6|5|SQ_INSTS_VALU_MFMA_MOPS_F64|0
 gen_60_8|--case gen:60:8|3|SQ_INSTS_VALU_MFMA_MOPS_F64|1
 gen_60_8_mixed|--case gen:60:8 --precision mixed|3|SQ_INSTS_VALU_MFMA_MOPS_F32|0
