@@ -294,7 +294,9 @@ __device__ __forceinline__ void lds_dma16(const double *g, double *lds)
 //   64 x 64, 2 x 2 waves (k_update_mt): 2 x 2 accumulators per wave, 8 flop per byte staged into LDS.
 //   Measured against it (scripts/mt_bench.hip 8192^2 SYRK, TF/s at K = 144 / 432 / 512): 128 x 128 tiles, 4 x 2 waves of
 //   2 x 4 accumulators, 16 flop per byte: 27 / 41 / 42 against 38 / 49 / 49 -- two workgroups of eight waves per CU (64 KB of LDS each)
-//   hide less than four or five of four; at K = 144 either shape is bound by the read-modify-write of C, not by the MFMAs
+//   hide less than four or five of four; 128 x 64 tiles (8 waves of 2 x 2 accumulators, three workgroups per CU, 25 % less staging
+//   traffic per flop): 36 / 47 / 47 -- the staging traffic is not what bounds it; at K = 144 every shape is bound by the
+//   read-modify-write of C, not by the MFMAs
 // one 16-deep chunk out of the LDS images sa ([k][TM rows]) / sb ([k][TN rows]) into the wave's accumulators; the operands of k-step
 // kk + 1 are requested before the MFMAs of k-step kk are issued (the LDS round trip is off the MFMA chain)
 template <int TM, int TN, int RM, int RN>
@@ -451,7 +453,7 @@ __device__ __forceinline__ void update_mt_body(double *__restrict__ base, const 
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c = (TN / WC) * wc + 16 * j + g + 4 * q;
-        if (r < t.mv && c < t.nv && (!t.lower || r >= c)) C[(int64_t)c * t.ldc] = cv[i][j][q] - acc[i][j][q];
+        if (r < t.mv && c < t.nv && (!t.lower || t.ar + r >= t.br + c)) C[(int64_t)c * t.ldc] = cv[i][j][q] - acc[i][j][q]; // lower: a SYRK tile on the diagonal (ar, br: its origin in the target's own rows)
       }
     }
 }
