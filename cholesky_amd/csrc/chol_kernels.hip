@@ -873,8 +873,8 @@ __device__ __forceinline__ int ext_ready(const follow_args &f, int from, int lan
 }
 template <bool UPD, bool PUB>
 __device__ __forceinline__ void follow_external(const double *__restrict__ base, const follow_args f, int T, int n, double *sE, d4 (&tile)[11], d4 (&stage)[3],
-                                                const int (&ijp)[12], int w, int lane, int tid, int *info, const double *A, int lda, int r15, int g)
-{
+                                                const int (&ijp)[12], int w, int lane, int tid, int *info, const double *A, int lda, int r15, int g, int *sReady)
+{ // sReady: LDS word (0 at entry): leading items the factor wave has seen published
   const int lp = lane; // accumulator layout: register q of lane l at q * 64 + l
   int buf = 0;
   // Column tiles are consumed in the order of the list, TWO per round where two fit an LDS buffer (T <= 8) -- a column tile of a wide
@@ -943,11 +943,24 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
     if (ng == 0) {
       const int need = i + EXT_ROUND(i);
       if (ready < need) {
-        ready = ext_ready(f, i, lane);
-        for (int it = 0; ready < need; ++it) { // bounded like wait_progress: a stall fails the factorisation through info
-          if (it >= (1 << 16)) { if (lane == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); ready = f.n_ext; break; }
-          __builtin_amdgcn_s_sleep(4);
+        // ONE wave of the workgroup polls the counters in global memory (the factor wave: it owns no tile) and passes what it has seen on
+        // through an LDS word; the tile waves watch that word (dozens of followers are resident at a time: twelve polling waves each would
+        // sit on the memory system the working jobs hand their data through).  The others load only after the word has moved.
+        if (!UPD) {
           ready = ext_ready(f, i, lane);
+          for (int it = 0; ready < need; ++it) { // bounded like wait_progress: a stall fails the factorisation through info
+            if (it >= (1 << 16)) { if (lane == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); ready = f.n_ext; break; }
+            __builtin_amdgcn_s_sleep(4);
+            ready = ext_ready(f, i, lane);
+          }
+          if (lane == 0) __hip_atomic_store(sReady, ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          for (int it = 0;; ++it) {
+            ready = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (ready >= need) break;
+            if (it >= (1 << 20)) { if (lane == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); ready = f.n_ext; break; }
+            __builtin_amdgcn_s_sleep(2);
+          }
         }
       }
       EXT_LOAD_ROUND(i);
@@ -965,7 +978,7 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
     int pv = 0, pneed = 0;
     bool polled = false;
     if (j < f.n_ext && j + EXT_ROUND(j) <= ready) { EXT_LOAD_ROUND(j); }
-    else if (j < f.n_ext) { // ask now, look after the update
+    else if (j < f.n_ext && !UPD) { // ask now, look after the update (the factor wave; the tile waves look at its LDS word then)
       polled = true;
       if (j + lane < f.n_ext) { const int c = f.ext[j + lane].ctr; pv = __hip_atomic_load(&f.ctr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pneed = f.epoch * f.ctr_total[c] + f.ext[j + lane].need; }
     }
@@ -984,6 +997,9 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
     if (polled) {
       const unsigned long long notok = __ballot(j + lane < f.n_ext && pv < pneed);
       const int r2 = min(j + (notok ? __builtin_ctzll(notok) : 64), f.n_ext);
+      if (r2 > ready) { ready = r2; if (lane == 0) __hip_atomic_store(sReady, ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    } else if (UPD && j < f.n_ext && ready < j + EXT_ROUND(j)) {
+      const int r2 = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
       ready = r2 > ready ? r2 : ready;
     }
     i = j;
@@ -1048,7 +1064,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
     if (FOLLOW && fa.n_ext > 0) { // loads and barriers of the external panel steps (it owns no tile)
       d4 tdummy[RR_RSLOTS], sdummy[3];
       int idummy[RR_SLOTS];
-      follow_external<false, PUB>(base, fa, T, n, smem + RR_OFF_SOL, tdummy, sdummy, idummy, 0, lane, tid, info, A, lda, r15, g);
+      follow_external<false, PUB>(base, fa, T, n, smem + RR_OFF_SOL, tdummy, sdummy, idummy, 0, lane, tid, info, A, lda, r15, g, &sFlag[5]);
       lds_barrier(); // the last panel has been read: the prologue may park column 1 in its place
       if (fa.stamp && lane == 0) *fa.stamp = __builtin_amdgcn_s_memrealtime(); // diagnostic runs: the followed columns are in
     }
@@ -1150,7 +1166,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
         if (early && ijp[s] != 0xffff) v = load_tile<PUB>(A, lda, n, ijp[s] & 0xff, ijp[s] >> 8, r15, g);
         tile[s] = v;
       }
-      follow_external<true, PUB>(base, fa, T, n, smem + RR_OFF_SOL, tile, stage, ijp, w, lane, tid, info, A, lda, r15, g);
+      follow_external<true, PUB>(base, fa, T, n, smem + RR_OFF_SOL, tile, stage, ijp, w, lane, tid, info, A, lda, r15, g, &sFlag[5]);
 #pragma unroll
       for (int s = FOLLOW_SLOTS; s < RR_RSLOTS; ++s) tile[s] = zero4; // not live across the followed columns
       lds_barrier();
