@@ -52,7 +52,10 @@ __device__ __forceinline__ int wait_progress(const int *progress, int target, in
   for (int it = 0; it < (1 << 16); ++it) {
     v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (v >= target) return v;
-    __builtin_amdgcn_s_sleep(8);
+#ifndef PROG_SLEEP
+#define PROG_SLEEP 8
+#endif
+    __builtin_amdgcn_s_sleep(PROG_SLEEP);
   }
   if ((threadIdx.x & 63) == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); // no progress: the factorisation is reported as failed
   return target;
@@ -153,7 +156,10 @@ __device__ __forceinline__ int wait_stage(const stage_waits &sw, int need, int l
   int have = stages_holding(sw, lane);
   for (int it = 0; have < need; ++it) {
     if (it >= (1 << 15)) { if (lane == 0) atomicCAS(&sw.info[0], 0, CHOLAMD_ERR_STALL); return sw.n; }
-    __builtin_amdgcn_s_sleep(16);
+#ifndef STAGE_SLEEP
+#define STAGE_SLEEP 16
+#endif
+    __builtin_amdgcn_s_sleep(STAGE_SLEEP);
     have = stages_holding(sw, lane);
   }
   return have;
@@ -950,7 +956,10 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
           ready = ext_ready(f, i, lane);
           for (int it = 0; ready < need; ++it) { // bounded like wait_progress: a stall fails the factorisation through info
             if (it >= (1 << 16)) { if (lane == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); ready = f.n_ext; break; }
-            __builtin_amdgcn_s_sleep(4);
+#ifndef EXT_SLEEP
+#define EXT_SLEEP 4
+#endif
+            __builtin_amdgcn_s_sleep(EXT_SLEEP);
             ready = ext_ready(f, i, lane);
           }
           if (lane == 0) __hip_atomic_store(sReady, ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
