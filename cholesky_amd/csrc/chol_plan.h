@@ -142,6 +142,7 @@ typedef struct {
   int follow;               /* ... in which pivot blocks follow their children's / predecessor's TRSM strips */
   int dist_top;             /* 0 / 1 / 2 = auto (CHOL_DIST_MIN); world > 1: the levels above the cut are distributed over the ranks by column blocks (owner factors and
                              * solves a block, broadcasts it, every rank updates the column blocks it owns) instead of replicated */
+  int fine_upd;             /* program launch: followed strips wait for the update jobs into THEIR rows' block, not for all into the panel */
   int staged;               /* program launch: the extend-add jobs take their sources as the source pivots finish (staged waits) */
   int follow_tail;          /* a follower wider than CHOL_FOLLOW_ALL_MAXT column tiles takes only the LAST follow_tail column tiles of each source
                              * itself; the columns before them reach its diagonal block through update jobs on other CUs (0: follows everything) */

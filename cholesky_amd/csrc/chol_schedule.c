@@ -85,7 +85,7 @@ static int env_int(const char *name, int dflt) { const char *e = getenv(name); r
 void chol_sched_opts_default(chol_sched_opts *o)
 {
   o->split_min = CHOL_SPLIT_MIN; o->split_nb = CHOL_SPLIT_NB; o->fuse = 1; o->fuse_update_max = CHOL_FUSE_UPDATE_MAX;
-  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL; o->staged = 1;
+  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL; o->staged = 1; o->fine_upd = 1;
 }
 void chol_sched_opts_from_env(chol_sched_opts *o)
 {
@@ -102,6 +102,7 @@ void chol_sched_opts_from_env(chol_sched_opts *o)
   o->super_blocks = env_int("CHOLAMD_SUPER_BLOCKS", o->super_blocks);
   o->follow_tail = env_int("CHOLAMD_FOLLOW_TAIL", o->follow_tail);
   o->staged = !env_int("CHOLAMD_NO_STAGED", 0);
+  o->fine_upd = !env_int("CHOLAMD_NO_FINE_UPD", 0);
 }
 static int split_nb(const chol_sched_opts *o) { int v = o->split_nb; if (v > CHOL_RR_MAXN) v = CHOL_RR_MAXN; v = (v + 15) / 16 * 16; if (v < 16) v = 16; return v; }
 static int pivot_blocks(const chol_sched_opts *o, int n) { return n > o->split_min || n > CHOL_RR_MAXN ? (n + split_nb(o) - 1) / split_nb(o) : 1; }
@@ -619,7 +620,9 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
 #endif
 #define PROG_MAX_TASKS 24000 /* beyond this the per-level launches (macro tiles) are the better schedule */
 typedef struct { int potrf, c_prog, c_strips, n_groups, c0, nb, emitted; int ch_below, ns_below; int ch_par, ns_par; int64_t par_off; } pblock;
-typedef struct { chol_program *pg; int cap_j, cap_w, cap_e, cap_c; } pbuild;
+typedef struct { chol_program *pg; int cap_j, cap_w, cap_e, cap_c;
+  int *c_updp, *cnt_updp; /* per separator: update jobs into the block (parent, separator) -- what the followed strips of the parent's rows wait for */
+} pbuild;
 static int new_ctr(pbuild *P, int total)
 {
   chol_program *g = P->pg;
@@ -704,15 +707,21 @@ static int push_block_rows(builder *B, const plan_t *p, int anc, int s, int lo, 
   return w->n_trsm - t_before;
 }
 /* TRSM jobs over the strips [t0, n_trsm): groups of three, never mixing channels */
-static int emit_trsm_jobs(pbuild *P, builder *B, int t0, int c_upd, int need_upd, int c_strips)
-{
+static int emit_trsm_jobs(pbuild *P, builder *B, int t0, int c_upd, int need_upd, int c_strips,
+                          int ch_par, int c_updp, int need_updp, int ch_below, int c_updd, int need_updd)
+{ /* a job waits for the update jobs into the rows its strips solve: the followed strips of the parent's rows (channel ch_par) for
+   * those into the block (parent, separator), the followed strips of the pivot's next column block (ch_below) for those into the
+   * diagonal block, every other job for all the update jobs into the panel (ch_par / ch_below < 0: that for every job) */
   chol_level_work *w = B->w;
   int njobs = 0;
   for (int i = t0; i < w->n_trsm;) {
     int e = i + 1;
     while (e < w->n_trsm && e - i < 3 && w->trsm[e].chan == w->trsm[i].chan) e++;
     const int wf = P->pg->n_wait;
-    add_wait(P, c_upd, need_upd);
+    const int ch = w->trsm[i].chan;
+    if (ch >= 0 && ch == ch_par && c_updp >= 0) add_wait(P, c_updp, need_updp);
+    else if (ch >= 0 && ch == ch_below && ch_par >= -1 && c_updp >= 0) add_wait(P, c_updd, need_updd);
+    else add_wait(P, c_upd, need_upd);
     chol_job *j = add_job(P, 1, i, e - i, wf);
     j->sig[0] = c_strips; j->sig_add = 1;
     njobs++;
@@ -768,9 +777,12 @@ static void emit_update_jobs(pbuild *P, builder *B, const plan_t *p, int k0, con
         }
       }
     } else for (int t = i; t < e; t++) for (int q = w->task[t].src_begin; q < w->task[t].src_end; q++) w->src[q].stage = 0;
-    j->sig[0] = c_upd[Bc->c]; j->sig[1] = Bc->r == Bc->c ? c_updd[Bc->c] : -1; j->sig_add = 1;
+    const int hpc = p->heap_of[Bc->c] / 2;
+    const int is_par = P->c_updp && Bc->r != Bc->c && hpc >= 1 && Bc->r == p->tree[hpc];
+    j->sig[0] = c_upd[Bc->c]; j->sig[1] = Bc->r == Bc->c ? c_updd[Bc->c] : is_par ? P->c_updp[Bc->c] : -1; j->sig_add = 1;
     cnt_upd[Bc->c]++;
     if (Bc->r == Bc->c) cnt_updd[Bc->c]++;
+    if (is_par) P->cnt_updp[Bc->c]++;
     i = e;
   }
 }
@@ -867,12 +879,14 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
   int *count = malloc(p->nblk * sizeof(int));
   /* per panel: counters and running counts of update jobs; per separator: its pivot blocks */
   int *c_upd = malloc((ns + 1) * sizeof(int)), *c_updd = malloc((ns + 1) * sizeof(int));
+  if (opts->fine_upd && opts->follow && opts->cells) { P->c_updp = malloc((ns + 1) * sizeof(int)); P->cnt_updp = calloc(ns + 1, sizeof(int)); }
   int *cnt_upd = calloc(ns + 1, sizeof(int)), *cnt_updd = calloc(ns + 1, sizeof(int)), *snap_upd = calloc(ns + 1, sizeof(int));
   int *nblk_of = calloc(ns + 1, sizeof(int));
   pblock **pb = calloc(ns + 1, sizeof(pblock *));
   int *follow_lim = calloc(p->nblk, sizeof(int));
   for (int s = 1; s <= ns; s++) {
     c_upd[s] = new_ctr(P, 0); c_updd[s] = new_ctr(P, 0);
+    if (P->c_updp) P->c_updp[s] = new_ctr(P, 0);
     const int n = p->sep_size[s];
     const int nbk = n > 0 ? pivot_blocks(opts, n) : 0, bw = pivot_block_width(opts, n);
     nblk_of[s] = nbk;
@@ -977,7 +991,7 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
           if (BIDX(p, anc, s) < 0) continue;
           push_block_rows(B, p, anc, s, ha == hp ? par_lim : 0, p->sep_size[anc], snap, first, count, diag, dinv, nb, ld, colbase, b->c_prog, -1);
         }
-        b->n_groups = emit_trsm_jobs(P, B, t0, c_upd[s], cnt_upd[s], b->c_strips);
+        b->n_groups = emit_trsm_jobs(P, B, t0, c_upd[s], cnt_upd[s], b->c_strips, b->ch_par, P->c_updp ? P->c_updp[s] : -1, P->c_updp ? P->cnt_updp[s] : 0, b->ch_below, c_updd[s], cnt_updd[s]);
         pg->ctr_total[b->c_strips] = b->n_groups;
       }
       /* (C) the next column block of a split pivot follows the strips of its own rows */
@@ -1013,6 +1027,38 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
           if (below <= 0) continue;
           const int64_t colbase = (int64_t)c0 * ld;
           const int64_t x_piv = p->panel_off[s] + (c0 + nb) + colbase; /* solved pivot rows below the block, k = nb */
+          /* fast part: (followed rows of the parent) x (columns of the NEXT column block) -- what that block's followed strips of
+           * the parent's rows wait for.  Its operands are channel strips on both sides (the parent-row strips, the strips of the next
+           * block's own rows), so these jobs wait for the channels' last column instead of every strip of the block, and are queued
+           * ahead of the rest of the step's trailing update */
+          const int hpp_ = h / 2, par_ = hpp_ >= 1 ? p->tree[hpp_] : -1, blkp_ = par_ >= 0 ? BIDX(p, par_, s) : -1;
+          const int fast = P->c_updp && b->ch_par >= 0 && b->ch_below >= 0 && blkp_ >= 0 && count[blkp_] > 0;
+          const int fast_cols = fast ? pb[s][st + 1].nb : 0; /* columns of the parent's followed rows the fast jobs cover */
+          if (fast) {
+            const chol_block *Bk = &p->blk[blkp_];
+            const int plim = pb[par_][0].nb, kf0 = w->n_task, ntl_ = (nb + CHOL_NB - 1) / CHOL_NB;
+            B->cur_blk = blkp_;
+            int run_lo = -1, run_hi = -1;
+            for (int q2 = 0; q2 <= count[blkp_]; q2++) {
+              int a0 = -1, a1 = -1;
+              if (q2 < count[blkp_]) {
+                const cholamd_filled *f = &snap[first[blkp_] + q2];
+                a0 = f->lo_x - Bk->lo_x; a1 = f->hi_x - Bk->lo_x + 1;
+                if (a1 > plim) a1 = plim;
+                if (a0 >= a1) continue;
+                if (run_hi == a0) { run_hi = a1; continue; }
+              }
+              if (run_lo >= 0) {
+                chol_upd_src sa = { Bk->off + run_lo + colbase, x_piv, ld, ld, nb, 0, 0, 0 };
+                const int si = push_src(B, sa);
+                push_tasks(B, Bk->off + run_lo + (int64_t)(c0 + nb) * ld, ld, run_hi - run_lo, fast_cols, 0, si, si + 1);
+              }
+              run_lo = a0; run_hi = a1;
+            }
+            flush_targets(B);
+            const int scf[2] = { b->ch_par + ntl_ - 1, b->ch_below + ntl_ - 1 }, snf[2] = { b->ns_par, b->ns_below };
+            emit_update_jobs(P, B, p, kf0, c_upd, c_updd, snap_upd, cnt_upd, cnt_updd, scf, snf, 2, NULL);
+          }
           const int k0 = w->n_task;
           B->cur_blk = BIDX(p, s, s);
           if (b->ch_below >= 0) {
@@ -1030,22 +1076,61 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
             const int sidx = push_src(B, sp);
             push_tasks(B, p->panel_off[s] + (c0 + nb) + (int64_t)(c0 + nb) * ld, ld, below, below, 1, sidx, sidx + 1);
           }
-          row_run *runs; const int nr = ancestor_runs(p, h, snap, first, count, &runs);
-          for (int r = 0; r < nr; r++) {
-            /* which ancestor block the run lies in (runs never span two blocks' targets differently: the target is panel s) */
-            chol_upd_src sa = { runs[r].off + colbase, x_piv, ld, ld, nb, 0, 0, 0 };
-            const int si = push_src(B, sa);
-            push_tasks(B, runs[r].off + (int64_t)(c0 + nb) * ld, ld, runs[r].m, below, 0, si, si + 1);
+          /* ancestor rows.  `blk` of these tasks: the true block for the followed rows of the parent (rows [0, par_lim) of block
+           * (parent, s): their update jobs are what the followed strips of the later column blocks wait for, counter updp), a
+           * non-parent, non-diagonal block of the panel for every other ancestor row (they raise the panel counter only) */
+          const int hpp = h / 2, hgp = h / 4;
+          const int par = hpp >= 1 ? p->tree[hpp] : -1;
+          const int blk_par = par >= 0 ? BIDX(p, par, s) : -1;
+          const int blk_rest = hgp >= 1 && BIDX(p, p->tree[hgp], s) >= 0 ? BIDX(p, p->tree[hgp], s) : blk_par;
+          const int fine = P->c_updp && b->ch_par >= 0 && blk_par >= 0 && count[blk_par] > 0;
+          const int par_lim = fine ? pb[par][0].nb : 0;
+          if (fine) { /* followed parent rows: filled row runs of block (parent, s) within [0, par_lim) */
+            const chol_block *Bk = &p->blk[blk_par];
+            B->cur_blk = blk_par;
+            int run_lo = -1, run_hi = -1;
+            for (int q2 = 0; q2 <= count[blk_par]; q2++) {
+              int a0 = -1, a1 = -1;
+              if (q2 < count[blk_par]) {
+                const cholamd_filled *f = &snap[first[blk_par] + q2];
+                a0 = f->lo_x - Bk->lo_x; a1 = f->hi_x - Bk->lo_x + 1;
+                if (a1 > par_lim) a1 = par_lim;
+                if (a0 >= a1) continue;
+                if (run_hi == a0) { run_hi = a1; continue; }
+              }
+              if (run_lo >= 0 && below > fast_cols) { /* the columns beyond the fast part */
+                chol_upd_src sa = { Bk->off + run_lo + colbase, x_piv + fast_cols, ld, ld, nb, 0, 0, 0 };
+                const int si = push_src(B, sa);
+                push_tasks(B, Bk->off + run_lo + (int64_t)(c0 + nb + fast_cols) * ld, ld, run_hi - run_lo, below - fast_cols, 0, si, si + 1);
+              }
+              run_lo = a0; run_hi = a1;
+            }
           }
-          free(runs);
+          B->cur_blk = blk_rest;
+          for (int ha = hpp; ha >= 1; ha /= 2) { /* every other ancestor row: the rest of the parent block, the other ancestors */
+            const int anc = p->tree[ha], ba = BIDX(p, anc, s);
+            if (ba < 0) continue;
+            const chol_block *Bk = &p->blk[ba];
+            const int lo = (fine && ha == hpp) ? par_lim : 0;
+            int run_lo = -1, run_hi = -1;
+            for (int q2 = 0; q2 <= count[ba]; q2++) {
+              int a0 = -1, a1 = -1;
+              if (q2 < count[ba]) {
+                const cholamd_filled *f = &snap[first[ba] + q2];
+                a0 = f->lo_x - Bk->lo_x; a1 = f->hi_x - Bk->lo_x + 1;
+                if (a0 < lo) a0 = lo;
+                if (a0 >= a1) continue;
+                if (run_hi == a0) { run_hi = a1; continue; }
+              }
+              if (run_lo >= 0) {
+                chol_upd_src sa = { Bk->off + run_lo + colbase, x_piv, ld, ld, nb, 0, 0, 0 };
+                const int si = push_src(B, sa);
+                push_tasks(B, Bk->off + run_lo + (int64_t)(c0 + nb) * ld, ld, run_hi - run_lo, below, 0, si, si + 1);
+              }
+              run_lo = a0; run_hi = a1;
+            }
+          }
           flush_targets(B);
-          /* all of these target panel s: blk = the diagonal block for the pivot rows; the ancestor rows are counted into the
-           * same panel counter, their `blk` only has to be constant within a job and must not claim the diagonal counter */
-          /* ancestor-row targets: give them the block of the first ancestor so that they do not raise updd[s] */
-          for (int i = k0; i < w->n_task; i++) {
-            const int64_t row_in_panel = (w->task[i].c_off - p->panel_off[s]) % ld;
-            if (row_in_panel >= n) { const int hpp = h / 2; w->task[i].blk = hpp >= 1 ? BIDX(p, p->tree[hpp], s) : w->task[i].blk; }
-          }
           const int sc[1] = { b->c_strips }, sn[1] = { b->n_groups };
           emit_update_jobs(P, B, p, k0, c_upd, c_updd, snap_upd, cnt_upd, cnt_updd, sc, sn, 1, NULL);
         }
@@ -1212,7 +1297,8 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
   #undef EMIT_POTRF
   if (!rc && w->n_task_mt > 0) { chol_set_error("program launch: macro-tile update phases"); rc = CHOLAMD_ERR_ARG; }
   if (!rc && w->n_task > PROG_MAX_TASKS) { chol_set_error("program launch: %d update tasks", w->n_task); rc = CHOLAMD_ERR_ARG; }
-  for (int s = 1; s <= ns; s++) { pg->ctr_total[c_upd[s]] = cnt_upd[s]; pg->ctr_total[c_updd[s]] = cnt_updd[s]; }
+  for (int s = 1; s <= ns; s++) { pg->ctr_total[c_upd[s]] = cnt_upd[s]; pg->ctr_total[c_updd[s]] = cnt_updd[s]; if (P->c_updp) pg->ctr_total[P->c_updp[s]] = P->cnt_updp[s]; }
+  free(P->c_updp); free(P->cnt_updp); P->c_updp = P->cnt_updp = NULL;
   for (int s = 1; s <= ns; s++) free(pb[s]);
   free(est_start); free(pb); free(nblk_of); free(first); free(count); free(c_upd); free(c_updd); free(cnt_upd); free(cnt_updd); free(snap_upd); free(follow_lim);
   free(B->pend);
