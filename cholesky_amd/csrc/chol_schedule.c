@@ -1048,16 +1048,25 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
                 if (a0 >= a1) continue;
                 if (run_hi == a0) { run_hi = a1; continue; }
               }
-              if (run_lo >= 0) {
-                chol_upd_src sa = { Bk->off + run_lo + colbase, x_piv, ld, ld, nb, 0, 0, 0 };
-                const int si = push_src(B, sa);
-                push_tasks(B, Bk->off + run_lo + (int64_t)(c0 + nb) * ld, ld, run_hi - run_lo, fast_cols, 0, si, si + 1);
+              if (run_lo >= 0) { /* sources in chunks of EARLY_CHUNK column tiles, chunk c behind the waits 2 c, 2 c + 1 (both channels) */
+                const int sb_ = w->n_src;
+                for (int c = 0; c * EARLY_CHUNK < ntl_; c++) {
+                  const int col0 = c * EARLY_CHUNK * CHOL_NB, kc = nb - col0 < EARLY_CHUNK * CHOL_NB ? nb - col0 : EARLY_CHUNK * CHOL_NB;
+                  chol_upd_src sa = { Bk->off + run_lo + colbase + (int64_t)col0 * ld, x_piv + (int64_t)col0 * ld, ld, ld, kc, 0, opts->staged ? 2 * c + 2 : 0, 0 };
+                  push_src(B, sa);
+                }
+                push_tasks(B, Bk->off + run_lo + (int64_t)(c0 + nb) * ld, ld, run_hi - run_lo, fast_cols, 0, sb_, w->n_src);
               }
               run_lo = a0; run_hi = a1;
             }
             flush_targets(B);
-            const int scf[2] = { b->ch_par + ntl_ - 1, b->ch_below + ntl_ - 1 }, snf[2] = { b->ns_par, b->ns_below };
-            emit_update_jobs(P, B, p, kf0, c_upd, c_updd, snap_upd, cnt_upd, cnt_updd, scf, snf, 2, NULL);
+            int scf[2 * 32], snf[2 * 32], nwf = 0;
+            for (int c = 0; c * EARLY_CHUNK < ntl_ && nwf < 62; c++) {
+              const int last = (c + 1) * EARLY_CHUNK < ntl_ ? (c + 1) * EARLY_CHUNK - 1 : ntl_ - 1;
+              scf[nwf] = b->ch_par + last; snf[nwf++] = b->ns_par;
+              scf[nwf] = b->ch_below + last; snf[nwf++] = b->ns_below;
+            }
+            emit_update_jobs(P, B, p, kf0, c_upd, c_updd, snap_upd, cnt_upd, cnt_updd, scf, snf, nwf, opts->staged ? scf : NULL); /* non-NULL: staged (the stages are set) */
           }
           const int k0 = w->n_task;
           B->cur_blk = BIDX(p, s, s);

@@ -285,7 +285,8 @@ int cholamd_factor_info(cholamd_device *d, int *sep_out);
  * CHOLAMD_NO_FOLLOW), "follow_tail" (followers of more than four tile columns take the last follow_tail column tiles of each source
  * themselves, update jobs bring the rest; 0 = they take everything; CHOLAMD_FOLLOW_TAIL), "staged" (the extend-add jobs of the
  * program launch take their sources pivot block by pivot block as those are solved instead of waiting for all of them;
- * CHOLAMD_NO_STAGED), "super_blocks", "dist_top" (0 / 1 / 2 = automatic: top levels of a partitioned run distributed by column
+ * CHOLAMD_NO_STAGED), "fine_upd" (followed strips wait for the update jobs into their own rows' block only; CHOLAMD_NO_FINE_UPD),
+ * "super_blocks", "dist_top" (0 / 1 / 2 = automatic: top levels of a partitioned run distributed by column
  * blocks, see Multi-GPU below; CHOLAMD_DIST_TOP).  Rebuilds the work lists. */
 int cholamd_device_set_option(cholamd_device *d, const char *name, int value);
 /* Solve phase, mmat.rg:1364-1495: b and x in ORIGINAL dof order (device pointers, n doubles).

@@ -214,6 +214,7 @@ def _ntiles_table(case):
     {"follow_tail": 0},                                # followers take every column tile of their sources themselves (no early update jobs)
     {"follow_tail": 2},                                # ... only the last two (most of the contribution through early jobs)
     {"follow_tail": 7},
+    {"fine_upd": 0},                                   # followed strips that wait for every update job into their panel
     {"staged": 0},                                     # extend-add jobs that wait for every source before they start (no staged waits)
     {"follow": 0, "staged": 1},                        # without followers every contribution goes through (staged) update jobs
     {"split_min": 96, "split_nb": 96, "follow_tail": 1}, # three / four column blocks per leaf: chains of followers with early jobs
