@@ -895,11 +895,17 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
 #ifndef FOLLOW_SINGLE_TAIL
 #define FOLLOW_SINGLE_TAIL 2 /* last items of a follower's list that go one by one */
 #endif
+#ifndef FOLLOW_OWN_LAST_MAX
+#define FOLLOW_OWN_LAST_MAX 0 /* followers with at most this many items add their own tiles after the last one (3: lapl_3375 unchanged, lapl_400 45.8 -> 48.9 us) */
+#endif
 #ifndef FOLLOW_OWN_BEFORE
 #define FOLLOW_OWN_BEFORE 2  /* the follower's own tiles are added before its last FOLLOW_OWN_BEFORE items (<= FOLLOW_SINGLE_TAIL: never inside a pair) */
 #endif
   const int pair_lim = 2 * T <= RR_MAXT ? f.n_ext - FOLLOW_SINGLE_TAIL : 0; // items [i, i + 1] form a round while i + 1 < pair_lim
-  const int own_at = f.n_ext >= FOLLOW_OWN_BEFORE ? f.n_ext - FOLLOW_OWN_BEFORE : 0;
+  // where the follower's own tiles go in: before the last FOLLOW_OWN_BEFORE items (their round trip hides behind the wait for those) -- or,
+  // for a follower with one source and a tail only (the next column block of a split pivot: its early jobs hang on the same strips as
+  // its tail, they end after the tail has arrived), after the last item
+  const int own_at = f.n_ext <= FOLLOW_OWN_LAST_MAX ? f.n_ext : f.n_ext - FOLLOW_OWN_BEFORE;
 #define EXT_ROUND(I_) ((I_) + 1 < pair_lim ? 2 : 1)
 #define EXT_LOAD(I_, V_)                                                                                             \
   {                                                                                                                  \
@@ -926,26 +932,30 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
         acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(sB2[(tj_) * (TS * TS) + st * 64 + lp], -sB2[(ti_) * (TS * TS) + st * 64 + lp], acc_, 0, 0, 0); \
     }                                                                                                                \
   }
+#define OWN_TILES()                                                                                                  \
+  {                                                                                                                  \
+ /* the follower's own tiles, before the last two followed column tiles (their round trip hides behind the wait for those) */ \
+      if (!UPD) wait_list(f.wl, f.n_wl, f.ctr, f.ctr_total, f.epoch, lane, info); /* the factor wave polls */ \
+      if (!UPD && f.xstamp && lane == 0) f.xstamp[0] = __builtin_amdgcn_s_memrealtime(); \
+      lds_barrier(); \
+      if (UPD) { \
+        int rx = r15, gx = g; /* opaque here: the addresses of these loads are invariant in the loop around them, and hoisting them spills */ \
+        asm volatile("" : "+v"(rx), "+v"(gx)); \
+    _Pragma("unroll")                                                                                            \
+        for (int it = 0; it < 3; ++it) { \
+          const int u = min(w + it * RR_NW, 2 * T - 2); \
+          stage[it] += load_tile<PUB>(A, lda, n, u < T ? u : u - T + 1, u < T ? 0 : 1, rx, gx); \
+        } \
+        __builtin_amdgcn_sched_barrier(0); /* two batches of loads: all 28 values and their addresses at once do not fit the registers */ \
+    _Pragma("unroll")                                                                                            \
+        for (int s = 0; s < FOLLOW_SLOTS; ++s) \
+          if (ijp[s] != 0xffff) tile[s] += load_tile<PUB>(A, lda, n, ijp[s] & 0xff, ijp[s] >> 8, rx, gx); \
+        __builtin_amdgcn_sched_barrier(0); \
+      } \
+ \
+  }
   for (int i = 0; i < f.n_ext;) {
-    if (f.n_wl > 0 && i == own_at) { // the follower's own tiles, before the last two followed column tiles (their round trip hides behind the wait for those)
-      if (!UPD) wait_list(f.wl, f.n_wl, f.ctr, f.ctr_total, f.epoch, lane, info); // the factor wave polls
-      if (!UPD && f.xstamp && lane == 0) f.xstamp[0] = __builtin_amdgcn_s_memrealtime();
-      lds_barrier();
-      if (UPD) {
-        int rx = r15, gx = g; // opaque here: the addresses of these loads are invariant in the loop around them, and hoisting them spills
-        asm volatile("" : "+v"(rx), "+v"(gx));
-#pragma unroll
-        for (int it = 0; it < 3; ++it) {
-          const int u = min(w + it * RR_NW, 2 * T - 2);
-          stage[it] += load_tile<PUB>(A, lda, n, u < T ? u : u - T + 1, u < T ? 0 : 1, rx, gx);
-        }
-        __builtin_amdgcn_sched_barrier(0); // two batches of loads: all 28 values and their addresses at once do not fit the registers
-#pragma unroll
-        for (int s = 0; s < FOLLOW_SLOTS; ++s)
-          if (ijp[s] != 0xffff) tile[s] += load_tile<PUB>(A, lda, n, ijp[s] & 0xff, ijp[s] >> 8, rx, gx);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
+    if (f.n_wl > 0 && i == own_at) OWN_TILES();
     if (ng == 0) {
       const int need = i + EXT_ROUND(i);
       if (ready < need) {
@@ -1013,6 +1023,8 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
     }
     i = j;
   }
+  if (f.n_wl > 0 && own_at >= f.n_ext) OWN_TILES();
+#undef OWN_TILES
 #undef EXT_LOAD_ROUND
 #undef EXT_ROUND
 #undef EXT_UPDATE
