@@ -893,7 +893,7 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
   int ready = 0, ng = 0; // ng: items of the round starting at i whose loads are in flight (0 = not issued)
   double va[FOLLOW_LOADS], vb[FOLLOW_LOADS];
 #ifndef FOLLOW_SINGLE_TAIL
-#define FOLLOW_SINGLE_TAIL 2 /* last items of a follower's list that go one by one */
+#define FOLLOW_SINGLE_TAIL 0 /* last items of a follower's list that go one by one (0 / 1 / 2: 189.5 / 190.4 / 190.2 us on lapl_3375, 44.5 / 45.0 / 45.1 on lapl_400) */
 #endif
 #ifndef FOLLOW_OWN_LAST_MAX
 #define FOLLOW_OWN_LAST_MAX 0 /* followers with at most this many items add their own tiles after the last one (3: lapl_3375 unchanged, lapl_400 45.8 -> 48.9 us) */
@@ -905,7 +905,10 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
   // where the follower's own tiles go in: before the last FOLLOW_OWN_BEFORE items (their round trip hides behind the wait for those) -- or,
   // for a follower with one source and a tail only (the next column block of a split pivot: its early jobs hang on the same strips as
   // its tail, they end after the tail has arrived), after the last item
-  const int own_at = f.n_ext <= FOLLOW_OWN_LAST_MAX ? f.n_ext : f.n_ext - FOLLOW_OWN_BEFORE;
+  int own_at = f.n_ext <= FOLLOW_OWN_LAST_MAX ? f.n_ext : 0;
+  if (own_at == 0) // the last round that starts at or before item n_ext - FOLLOW_OWN_BEFORE (never the second item of a pair)
+    for (int i = 0; i < f.n_ext; i += (i + 1 < pair_lim ? 2 : 1))
+      if (i <= f.n_ext - FOLLOW_OWN_BEFORE) own_at = i;
 #define EXT_ROUND(I_) ((I_) + 1 < pair_lim ? 2 : 1)
 #define EXT_LOAD(I_, V_)                                                                                             \
   {                                                                                                                  \
