@@ -839,8 +839,9 @@ template <bool PUB> __device__ __forceinline__ d4 load_tile(const double *A, int
 // the slots [0, FOLLOW_SLOTS) of rr_owner's deal, an external panel is FOLLOW_LOADS doubles per thread.
 #define FOLLOW_SLOTS 4
 #define FOLLOW_LOADS ((CHOL_FOLLOW_MAXT * TS * TS + RR_THREADS - 1) / RR_THREADS)
+template <int SLEEP = 0>
 __device__ __forceinline__ void wait_list(const chol_wait *__restrict__ wl, int n, const int *ctr, const int *__restrict__ ctr_total, int epoch, int lane, int *info)
-{
+{ // SLEEP: poll interval in units of 64 cycles (0: WAIT_SLEEP, the interval of a blocked job)
   for (int b0 = 0; b0 < n; b0 += 64) {
     int c = 0, need = 0;
     const bool mine = b0 + lane < n;
@@ -852,7 +853,7 @@ __device__ __forceinline__ void wait_list(const chol_wait *__restrict__ wl, int 
 #ifndef WAIT_SLEEP
 #define WAIT_SLEEP 32
 #endif
-      __builtin_amdgcn_s_sleep(WAIT_SLEEP); // ~1 us between polls: a blocked job is not on anybody's critical path by less than that
+      __builtin_amdgcn_s_sleep(SLEEP ? SLEEP : WAIT_SLEEP); // ~1 us between polls: a blocked job is not on anybody's critical path by less than that
     }
   }
 }
@@ -894,6 +895,9 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
   double va[FOLLOW_LOADS], vb[FOLLOW_LOADS];
 #ifndef FOLLOW_SINGLE_TAIL
 #define FOLLOW_SINGLE_TAIL 0 /* last items of a follower's list that go one by one (0 / 1 / 2: 189.5 / 190.4 / 190.2 us on lapl_3375, 44.5 / 45.0 / 45.1 on lapl_400) */
+#endif
+#ifndef FOLLOW_OWN_SLEEP
+#define FOLLOW_OWN_SLEEP 4
 #endif
 #ifndef FOLLOW_OWN_LAST_MAX
 #define FOLLOW_OWN_LAST_MAX 0 /* followers with at most this many items add their own tiles after the last one (3: lapl_3375 unchanged, lapl_400 45.8 -> 48.9 us) */
@@ -938,7 +942,7 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
 #define OWN_TILES()                                                                                                  \
   {                                                                                                                  \
  /* the follower's own tiles, before the last two followed column tiles (their round trip hides behind the wait for those) */ \
-      if (!UPD) wait_list(f.wl, f.n_wl, f.ctr, f.ctr_total, f.epoch, lane, info); /* the factor wave polls */ \
+      if (!UPD) wait_list<FOLLOW_OWN_SLEEP>(f.wl, f.n_wl, f.ctr, f.ctr_total, f.epoch, lane, info); /* the factor wave polls: a follower waiting for its own tiles IS on the critical path */ \
       if (!UPD && f.xstamp && lane == 0) f.xstamp[0] = __builtin_amdgcn_s_memrealtime(); \
       lds_barrier(); \
       if (UPD) { \
