@@ -246,6 +246,7 @@ extern "C" int cholamd_device_set_option(cholamd_device *d, const char *name, in
   else if (n == "follow") d->opt.follow = value != 0;
   else if (n == "super_blocks") d->opt.super_blocks = value;
   else if (n == "follow_tail") d->opt.follow_tail = value;
+  else if (n == "follow_tail_split") d->opt.follow_tail_split = value;
   else if (n == "staged") d->opt.staged = value != 0;
   else if (n == "fine_upd") d->opt.fine_upd = value != 0;
   else if (n == "dist_top") d->opt.dist_top = value;

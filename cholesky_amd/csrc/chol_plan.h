@@ -144,6 +144,7 @@ typedef struct {
                              * solves a block, broadcasts it, every rank updates the column blocks it owns) instead of replicated */
   int fine_upd;             /* program launch: followed strips wait for the update jobs into THEIR rows' block, not for all into the panel */
   int staged;               /* program launch: the extend-add jobs take their sources as the source pivots finish (staged waits) */
+  int follow_tail_split;    /* the same tail for the next column block of a split pivot (one source: the strips of its own rows) */
   int follow_tail;          /* a follower wider than CHOL_FOLLOW_ALL_MAXT column tiles takes only the LAST follow_tail column tiles of each source
                              * itself; the columns before them reach its diagonal block through update jobs on other CUs (0: follows everything) */
   int super_blocks;         /* column blocks per super-block of a wide pivot: the trailing matrix beyond a super-block gets one update of

@@ -85,7 +85,7 @@ static int env_int(const char *name, int dflt) { const char *e = getenv(name); r
 void chol_sched_opts_default(chol_sched_opts *o)
 {
   o->split_min = CHOL_SPLIT_MIN; o->split_nb = CHOL_SPLIT_NB; o->fuse = 1; o->fuse_update_max = CHOL_FUSE_UPDATE_MAX;
-  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL; o->staged = 1; o->fine_upd = 1;
+  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL; o->follow_tail_split = CHOL_FOLLOW_TAIL; o->staged = 1; o->fine_upd = 1;
 }
 void chol_sched_opts_from_env(chol_sched_opts *o)
 {
@@ -101,6 +101,7 @@ void chol_sched_opts_from_env(chol_sched_opts *o)
   o->dist_top = env_int("CHOLAMD_DIST_TOP", o->dist_top);
   o->super_blocks = env_int("CHOLAMD_SUPER_BLOCKS", o->super_blocks);
   o->follow_tail = env_int("CHOLAMD_FOLLOW_TAIL", o->follow_tail);
+  o->follow_tail_split = env_int("CHOLAMD_FOLLOW_TAIL_SPLIT", o->follow_tail_split);
   o->staged = !env_int("CHOLAMD_NO_STAGED", 0);
   o->fine_upd = !env_int("CHOLAMD_NO_FINE_UPD", 0);
 }
@@ -1004,7 +1005,7 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
         const int64_t e_off = p->panel_off[s] + (b->c0 + b->nb) + (int64_t)b->c0 * ld;
         const int nb1 = pb[s][st + 1].nb, nt = (b->nb + CHOL_NB - 1) / CHOL_NB;
         int bt = 0; /* column tiles of this block that reach the next block's diagonal block through early update jobs */
-        if (opts->follow_tail > 0 && (nb1 + CHOL_NB - 1) / CHOL_NB > CHOL_FOLLOW_ALL_MAXT && nt > opts->follow_tail) bt = nt - opts->follow_tail;
+        if (opts->follow_tail_split > 0 && (nb1 + CHOL_NB - 1) / CHOL_NB > CHOL_FOLLOW_ALL_MAXT && nt > opts->follow_tail_split) bt = nt - opts->follow_tail_split;
         if (bt > 0) {
           const early_src es = { e_off, ld, bt * CHOL_NB, b->ch_below + bt - 1, b->ns_below };
           emit_early_cells(P, B, p, p->panel_off[s] + (b->c0 + b->nb) + (int64_t)(b->c0 + b->nb) * ld, ld, nb1, BIDX(p, s, s), &es, 1, c_upd, c_updd, snap_upd, cnt_upd, cnt_updd);

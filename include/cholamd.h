@@ -283,7 +283,8 @@ int cholamd_factor_info(cholamd_device *d, int *sep_out);
  * "split_nb", "fuse", "fuse_update_max", "mt_min_tiles", "cells", "solve_reference_shape", "program" (the whole factorisation
  * of a small problem as one launch; CHOLAMD_NO_PROGRAM), "follow" (its pivot blocks follow their children's TRSM strips;
  * CHOLAMD_NO_FOLLOW), "follow_tail" (followers of more than four tile columns take the last follow_tail column tiles of each source
- * themselves, update jobs bring the rest; 0 = they take everything; CHOLAMD_FOLLOW_TAIL), "staged" (the extend-add jobs of the
+ * themselves, update jobs bring the rest; 0 = they take everything; CHOLAMD_FOLLOW_TAIL; "follow_tail_split": the same for the next
+ * column block of a split pivot), "staged" (the extend-add jobs of the
  * program launch take their sources pivot block by pivot block as those are solved instead of waiting for all of them;
  * CHOLAMD_NO_STAGED), "fine_upd" (followed strips wait for the update jobs into their own rows' block only; CHOLAMD_NO_FINE_UPD),
  * "super_blocks", "dist_top" (0 / 1 / 2 = automatic: top levels of a partitioned run distributed by column
