@@ -2220,12 +2220,25 @@ __global__ __launch_bounds__(256) void k_solve_trsv(const TL *__restrict__ base,
     }
     if (BWD) {
       // x_J <- x_J - L(rows below, J)^T x(rows below): wave w takes the columns w, w+4, ..., lanes stride the rows
-      for (int c = wave; c < SNB; c += 4) {
-        double acc = 0.0;
-        if (c < jb)
-          for (int i = J0 + jb + lane; i < n; i += 64) acc += (double)Lm[i + (int64_t)(J0 + c) * lda] * x[i];
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-        if (lane == 0) sx[c] = (c < jb) ? x[J0 + c] - acc : 0.0;
+      // sixteen columns per wave, all sixteen loads of a row chunk in flight (one column after the other is one memory round trip
+      // after the other: the launch was latency bound at ~115 us per 256-column span)
+      double acc[SNB / 4];
+#pragma unroll
+      for (int cc = 0; cc < SNB / 4; ++cc) acc[cc] = 0.0;
+      for (int i = J0 + jb + lane; i < n; i += 64) {
+        const double xi = x[i];
+        TL lv[SNB / 4];
+#pragma unroll
+        for (int cc = 0; cc < SNB / 4; ++cc) { const int c = wave + 4 * cc; lv[cc] = Lm[i + (int64_t)(J0 + min(c, jb - 1)) * lda]; }
+#pragma unroll
+        for (int cc = 0; cc < SNB / 4; ++cc) acc[cc] += (double)lv[cc] * xi;
+      }
+#pragma unroll
+      for (int cc = 0; cc < SNB / 4; ++cc) {
+        const int c = wave + 4 * cc;
+        double a = acc[cc];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+        if (lane == 0) sx[c] = (c < jb) ? x[J0 + c] - a : 0.0;
       }
     } else {
       if (tid < SNB) sx[tid] = (tid < jb) ? x[J0 + tid] : 0.0;
@@ -2259,7 +2272,16 @@ __global__ __launch_bounds__(256) void k_solve_trsv(const TL *__restrict__ base,
     if (!BWD) { // rows below the block: x[r] -= L(r, J) x_J
       for (int r = J0 + jb + tid; r < n; r += 256) {
         double acc = 0.0;
-        for (int k = 0; k < jb; ++k) acc += (double)Lm[r + (int64_t)(J0 + k) * lda] * sx[k];
+        const TL *A = Lm + r + (int64_t)J0 * lda;
+        int k = 0;
+        for (; k + 16 <= jb; k += 16) { // sixteen loads in flight
+          TL a[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) a[u] = A[(int64_t)(k + u) * lda];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc += (double)a[u] * sx[k + u];
+        }
+        for (; k < jb; ++k) acc += (double)A[(int64_t)k * lda] * sx[k];
         x[r] -= acc;
       }
     }
