@@ -2359,6 +2359,13 @@ __global__ __launch_bounds__(256) void k_solve_gemv_fwd(const TL *__restrict__ b
     __syncthreads();
     const TL *Ak = A + (int64_t)k0 * d.lda;
     int k = 0;
+    for (; k + 16 <= kb; k += 16) { // sixteen loads in flight per thread
+      TL a[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a[u] = Ak[(int64_t)(k + u) * d.lda];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += (double)a[u] * sx[k + u];
+    }
     for (; k + 8 <= kb; k += 8) {
       double a[8];
 #pragma unroll
@@ -2388,7 +2395,25 @@ __global__ __launch_bounds__(256) void k_solve_gather_bwd(const TL *__restrict__
     const int i = row0 + lane + 64 * u;
     ya[u] = i < d.m ? y[d.x_off + i] : 0.0;
   }
-  for (int c = wave; c < d.n; c += 4) {
+  int c = wave;
+  for (; c + 12 < d.n; c += 16) { // four columns per round: 4 PER loads in flight per lane (one column at a time is PER loads per memory round trip)
+    TL a[4][PER];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const TL *Ac = A + (int64_t)(c + 4 * q) * d.lda;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) a[q][u] = Ac[min(row0 + lane + 64 * u, d.m - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) acc += (double)a[q][u] * ya[u];
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+      if (lane == 0) unsafeAtomicAdd(&y[d.y_off + c + 4 * q], -acc);
+    }
+  }
+  for (; c < d.n; c += 4) {
     const TL *Ac = A + (int64_t)c * d.lda;
     double a[PER];
 #pragma unroll
