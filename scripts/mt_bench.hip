@@ -1,6 +1,7 @@
 // Development aid: the macro-tile update kernel on one large SYRK target (n x n lower, one source of depth k), TF/s
 //   hipcc --offload-arch=gfx950 -O3 -Iinclude -Icholesky_amd/csrc scripts/mt_bench.hip -o scripts/mt_bench
 #include "../cholesky_amd/csrc/chol_kernels.hip"
+#if MKB >= 16
 // the 128 x 128 / 8-wave instance of the macro-tile body: measured here only (slower than the product's 64 x 64: chol_kernels.hip)
 __global__ __launch_bounds__(512) void k_update_mt128(double *__restrict__ base, const chol_upd_task *__restrict__ tasks,
                                                       const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd)
@@ -28,6 +29,10 @@ static int chol_launch_update_mt128(double *base, const chol_upd_task *tasks, co
   hipLaunchKernelGGL(k_update_mt128, dim3(per_xcd * 8), dim3(512), 0, st, base, tasks, srcs, ntask, per_xcd);
   return (int)hipGetLastError();
 }
+#else
+static int chol_launch_update_mt128(double *, const chol_upd_task *, const chol_upd_src *, int, hipStream_t) { return -1; }
+static int chol_launch_update_mt128x64(double *, const chol_upd_task *, const chol_upd_src *, int, hipStream_t) { return -1; }
+#endif
 #include <cstdio>
 #include <vector>
 #include <cstring>
