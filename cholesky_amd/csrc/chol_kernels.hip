@@ -303,7 +303,8 @@ __device__ __forceinline__ void lds_dma16(const double *g, double *lds)
 //   hide less than four or five of four; 128 x 64 tiles (8 waves of 2 x 2 accumulators, three workgroups per CU, 25 % less staging
 //   traffic per flop): 36 / 47 / 47 -- the staging traffic is not what bounds it; at K = 144 every shape is bound by the
 //   read-modify-write of C, not by the MFMAs.  Workgroups per CU (LDS padded in the bench): 1 / 2 / 3 / 4 -> 27 / 40 / 46 / 48.6 TF/s at K = 432;
-//   8-deep chunks x 2 stages (more workgroups, twice the barriers): 44.8; 32-deep x 2: 41.8
+//   8-deep chunks x 2 stages (more workgroups, twice the barriers): 44.8; 32-deep x 2: 41.8; source descriptors by scalar loads instead of
+//   the LDS copy (32 KB of LDS per workgroup exactly, a fifth workgroup per CU): 47.2
 // one 16-deep chunk out of the LDS images sa ([k][TM rows]) / sb ([k][TN rows]) into the wave's accumulators; the operands of k-step
 // kk + 1 are requested before the MFMAs of k-step kk are issued (the LDS round trip is off the MFMA chain)
 template <int TM, int TN, int RM, int RN>
