@@ -57,7 +57,7 @@ $(ASAN_OUT)/%.o: $(CSRC)/%.c $(CSRC)/chol_plan.h include/cholamd.h
 	$(CC) $(CFLAGS) -O1 $(SAN) -c $< -o $@
 $(ASAN_OUT)/chol_api.o: $(CSRC)/chol_api.cpp $(CSRC)/chol_plan.h $(CSRC)/chol_kernels.h include/cholamd.h
 	@mkdir -p $(ASAN_OUT)
-	$(HIPCC) $(HIPFLAGS) -O1 $(SAN) -fno-gpu-sanitize -x hip -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -O1 $(SAN) -fno-sanitize=function -fno-gpu-sanitize -x hip -c $< -o $@
 $(ASAN_OUT)/libcholamd.so: $(ASAN_HOST_OBJS) $(ASAN_OUT)/chol_api.o $(OUT)/chol_kernels.o $(OUT)/chol_kernels_f32.o
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(SAN) -fno-gpu-sanitize -o $@ $^ -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 asan: $(ASAN_OUT)/libcholamd.so oracle
