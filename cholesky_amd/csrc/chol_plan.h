@@ -142,6 +142,7 @@ typedef struct {
   int follow;               /* ... in which pivot blocks follow their children's / predecessor's TRSM strips */
   int dist_top;             /* 0 / 1 / 2 = auto (CHOL_DIST_MIN); world > 1: the levels above the cut are distributed over the ranks by column blocks (owner factors and
                              * solves a block, broadcasts it, every rank updates the column blocks it owns) instead of replicated */
+  int skyline;              /* program launch: the tile-level skyline of the leaf pivots is used (zero early parts, zero tile updates skipped) */
   int fine_upd;             /* program launch: followed strips wait for the update jobs into THEIR rows' block, not for all into the panel */
   int staged;               /* program launch: the extend-add jobs take their sources as the source pivots finish (staged waits) */
   int follow_tail_split;    /* the same tail for the next column block of a split pivot (one source: the strips of its own rows) */

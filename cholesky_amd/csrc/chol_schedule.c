@@ -85,7 +85,7 @@ static int env_int(const char *name, int dflt) { const char *e = getenv(name); r
 void chol_sched_opts_default(chol_sched_opts *o)
 {
   o->split_min = CHOL_SPLIT_MIN; o->split_nb = CHOL_SPLIT_NB; o->fuse = 1; o->fuse_update_max = CHOL_FUSE_UPDATE_MAX;
-  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL; o->follow_tail_split = CHOL_FOLLOW_TAIL; o->staged = 1; o->fine_upd = 1;
+  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL; o->follow_tail_split = CHOL_FOLLOW_TAIL; o->staged = 1; o->fine_upd = 1; o->skyline = 1;
 }
 void chol_sched_opts_from_env(chol_sched_opts *o)
 {
@@ -104,6 +104,7 @@ void chol_sched_opts_from_env(chol_sched_opts *o)
   o->follow_tail_split = env_int("CHOLAMD_FOLLOW_TAIL_SPLIT", o->follow_tail_split);
   o->staged = !env_int("CHOLAMD_NO_STAGED", 0);
   o->fine_upd = !env_int("CHOLAMD_NO_FINE_UPD", 0);
+  o->skyline = !env_int("CHOLAMD_NO_SKYLINE", 0);
 }
 static int split_nb(const chol_sched_opts *o) { int v = o->split_nb; if (v > CHOL_RR_MAXN) v = CHOL_RR_MAXN; v = (v + 15) / 16 * 16; if (v < 16) v = 16; return v; }
 static int pivot_blocks(const chol_sched_opts *o, int n) { return n > o->split_min || n > CHOL_RR_MAXN ? (n + split_nb(o) - 1) / split_nb(o) : 1; }
@@ -788,6 +789,47 @@ static void emit_update_jobs(pbuild *P, builder *B, const plan_t *p, int k0, con
   }
 }
 
+/* Tile-level skyline of the LEAF pivots.  A leaf's diagonal block receives nothing from below, so its factor stays inside the envelope
+ * of A: L(i, j) = 0 for j < first(i), first(i) = the first column of row i of tril(P A P^T) inside the block.  fcol[tile row] = the
+ * first 16-column tile that can be non-zero in any of the tile's rows (lapl_3375's 259-column leaf: 56 of its 153 tiles, a band of
+ * three below the diagonal).  Returns a malloc'ed array over the separators (NULL for a separator with descendants or no pivot). */
+static unsigned char **leaf_skylines(const plan_t *p)
+{
+  const int ns = p->nsep, L = p->levels;
+  unsigned char **sky = calloc(ns + 1, sizeof(unsigned char *));
+  int **first = calloc(ns + 1, sizeof(int *));
+  for (int h = 1 << (L - 1); h <= ns; h++) {
+    const int s = p->tree[h], n = p->sep_size[s];
+    if (n <= 0) continue;
+    first[s] = malloc(n * sizeof(int));
+    for (int r = 0; r < n; r++) first[s][r] = r; /* the diagonal */
+  }
+  for (int64_t e = 0; e < p->nnz_a; e++) { /* entries of tril(A) by arena offset: the leaf panels' diagonal blocks */
+    const int64_t off = p->a_dst[e];
+    int lo = 1, hi = ns; /* the panel that holds the offset: panels are laid out by label */
+    while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (p->panel_off[mid] <= off) lo = mid; else hi = mid - 1; }
+    const int s = lo;
+    if (!first[s]) continue;
+    const int64_t rel = off - p->panel_off[s];
+    const int ld = p->panel_ld[s], row = (int)(rel % ld), col = (int)(rel / ld);
+    if (row < p->sep_size[s] && col < first[s][row]) first[s][row] = col;
+  }
+  for (int s = 1; s <= ns; s++) {
+    if (!first[s]) continue;
+    const int n = p->sep_size[s], T = (n + CHOL_NB - 1) / CHOL_NB;
+    sky[s] = malloc(T);
+    for (int i = 0; i < T; i++) {
+      int f = n;
+      for (int r = i * CHOL_NB; r < n && r < (i + 1) * CHOL_NB; r++) if (first[s][r] < f) f = first[s][r];
+      sky[s][i] = (unsigned char)(f / CHOL_NB);
+    }
+    free(first[s]);
+  }
+  free(first);
+  return sky;
+}
+static void free_skylines(unsigned char **sky, int ns) { if (!sky) return; for (int s = 1; s <= ns; s++) free(sky[s]); free(sky); }
+
 /* Early part of a wide follower's sources: dense 16x16 cell tasks  C(I, J) -= sum over the sources of E_I E_J^T  over the lower
  * triangle of the lim x lim target block at c_off, E = rows of the target in a source panel (off = row 0 in the first of k
  * columns).  They become ordinary update jobs on other CUs that wait for the sources' channel counters (the strips publish their
@@ -900,6 +942,7 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
       b->c_strips = new_ctr(P, 0);
     }
   }
+  unsigned char **sky = opts->skyline ? leaf_skylines(p) : calloc(ns + 1, sizeof(unsigned char *));
   /* expected position (in 16-column steps) at which a separator's pivot chain starts: the longest chain below it; leaves start at 0.
    * A follower consumes its children's column tiles in the order of these positions */
   int *est_start = calloc(ns + 1, sizeof(int));
@@ -1006,6 +1049,11 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
         const int nb1 = pb[s][st + 1].nb, nt = (b->nb + CHOL_NB - 1) / CHOL_NB;
         int bt = 0; /* column tiles of this block that reach the next block's diagonal block through early update jobs */
         if (opts->follow_tail_split > 0 && (nb1 + CHOL_NB - 1) / CHOL_NB > CHOL_FOLLOW_ALL_MAXT && nt > opts->follow_tail_split) bt = nt - opts->follow_tail_split;
+        if (bt > 0 && sky[s]) { /* a leaf: columns left of the next block's skyline bring nothing into its diagonal block */
+          int fmin = 1 << 20;
+          for (int i = (b->c0 + b->nb) / CHOL_NB; i * CHOL_NB < b->c0 + b->nb + nb1; i++) if (sky[s][i] < fmin) fmin = sky[s][i];
+          if (fmin - b->c0 / CHOL_NB >= bt) bt = 0; /* (the tail items stay: they are cheap, and the follower's list must not be empty) */
+        }
         if (bt > 0) {
           const early_src es = { e_off, ld, bt * CHOL_NB, b->ch_below + bt - 1, b->ns_below };
           emit_early_cells(P, B, p, p->panel_off[s] + (b->c0 + b->nb) + (int64_t)(b->c0 + b->nb) * ld, ld, nb1, BIDX(p, s, s), &es, 1, c_upd, c_updd, snap_upd, cnt_upd, cnt_updd);
@@ -1310,6 +1358,7 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
   for (int s = 1; s <= ns; s++) { pg->ctr_total[c_upd[s]] = cnt_upd[s]; pg->ctr_total[c_updd[s]] = cnt_updd[s]; if (P->c_updp) pg->ctr_total[P->c_updp[s]] = P->cnt_updp[s]; }
   free(P->c_updp); free(P->cnt_updp); P->c_updp = P->cnt_updp = NULL;
   for (int s = 1; s <= ns; s++) free(pb[s]);
+  free_skylines(sky, ns);
   free(est_start); free(pb); free(nblk_of); free(first); free(count); free(c_upd); free(c_updd); free(cnt_upd); free(cnt_updd); free(snap_upd); free(follow_lim);
   free(B->pend);
   if (rc) { chol_level_work_free(w); chol_program_free(pg); }
