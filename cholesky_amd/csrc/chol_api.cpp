@@ -852,7 +852,7 @@ extern "C" int cholamd_fused_dpotrf(const cholamd_region *rA, const cholamd_fill
              fa[i].sep_x, fa[i].sep_y, fa[i].cluster, fa[i].lo_x, fa[i].lo_y, fa[i].hi_x, fa[i].hi_y, m, fa[i].hi_y - fa[i].lo_y + 1,
              fa[i].sep_x, fa[i].sep_y, level, interval);
     if (m == 0) continue; // blas.rg:68
-    chol_potrf_desc p = { poff(tile_ptr(rA, &fa[i])), 0, m, rA->ld, fa[i].sep_x, 0 };
+    chol_potrf_desc p = { poff(tile_ptr(rA, &fa[i])), 0, m, rA->ld, fa[i].sep_x, 0, 0, 0, { 0 } };
     v.push_back(p);
   }
   int info = 0;

@@ -765,7 +765,8 @@ __device__ __forceinline__ void tile_of_index(int idx, int T, int &ti, int &tj)
 #define RR_OFF_OV (RR_OFF_CONV + 2 * TS * (TS + 1))
 #define RR_OFF_IJ (RR_OFF_OV + RR_NHEAVY * TS * TS)
 #define RR_OFF_FLAG (RR_OFF_IJ + (RR_SLOTS * RR_NW + 16 + 3) / 4)
-#define RR_SMEM_DOUBLES (RR_OFF_FLAG + 4)
+#define RR_OFF_KM (RR_OFF_FLAG + 4)                       /* per (slot, wave): first step whose update can be non-zero (skyline) */
+#define RR_SMEM_DOUBLES (RR_OFF_KM + (RR_SLOTS * RR_NW + 7) / 8)
 // Note (measured): waves of a workgroup are dealt to the four SIMDs round-robin, so waves 0, 4 and 8
 // share a SIMD, and fp64 MFMA runs on the same DP units as fp64 VALU: the tile waves' 64-cycle MFMAs
 // on the factor wave's SIMD stretch its scalar chain (chol16 3.4k -> 4.9k cycles).  Leaving waves 4 and
@@ -1042,8 +1043,9 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
 
 template <bool PUB, bool FOLLOW = false>
 __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double *__restrict__ ws, const chol_potrf_desc d, int *__restrict__ info,
-                                              int *__restrict__ progress, int progress_base, double *smem, const follow_args fa = follow_args(), const int tid = threadIdx.x)
-{ // tid: the thread index, passed in by k_program as a value the compiler cannot see through (nothing derived from it may be
+                                              int *__restrict__ progress, int progress_base, double *smem, const unsigned char *__restrict__ sky, const follow_args fa = follow_args(), const int tid = threadIdx.x)
+{ // sky: the descriptor's skyline in global memory (indexed per tile: a by-value copy would go to scratch)
+ // tid: the thread index, passed in by k_program as a value the compiler cannot see through (nothing derived from it may be
   // hoisted out of the job loop: that is what would spill)
   // tiles in LDS are stored like accumulator registers: element (r, c) at c * 16 + r, so lane (r15, g)
   // register q sits at q * 64 + lp with lp = g * 16 + r15 (conflict free, and directly an MFMA operand)
@@ -1056,6 +1058,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
   double (*const sOv)[TS * TS] = (double (*)[TS * TS])(smem + RR_OFF_OV);              // [RR_NHEAVY] slot RR_RSLOTS of the heavy waves
   unsigned short *const sIJ = (unsigned short *)(smem + RR_OFF_IJ);                    // [RR_SLOTS * RR_NW + 16]
   int *const sFlag = (int *)(smem + RR_OFF_FLAG);                                      // [8] fL, fP, cSol, cUpd, cRaw, fA, fD
+  unsigned char *const sKm = (unsigned char *)(smem + RR_OFF_KM);                      // [RR_SLOTS * RR_NW]
   int *const fL = &sFlag[0], *const fP = &sFlag[1], *const cSol = &sFlag[2], *const cUpd = &sFlag[3];
   int *const cRaw = &sFlag[4]; // raw tiles parked in sRaw so far (column j contributes T - 1 - j)
   int *const fA = &sFlag[6];   // j: raw tile (j, j-1) is in sRaw[j]
@@ -1071,7 +1074,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
   const int r15 = lane & 15, g = lane >> 4;
   const int lp0 = g * TS + r15;
 
-  for (int t = tid; t < RR_SLOTS * RR_NW; t += RR_THREADS) sIJ[t] = (unsigned short)0xffff;
+  for (int t = tid; t < RR_SLOTS * RR_NW; t += RR_THREADS) { sIJ[t] = (unsigned short)0xffff; sKm[t] = 0; }
   if (tid < 8) sFlag[tid] = (tid == 6 || tid == 7) ? 1 : 0; // (1,0) and (1,1) are parked by the prologue
   if (tid < TS * TS) sConv[TS + (tid >> 4)][tid & 15] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
   __syncthreads();
@@ -1086,6 +1089,8 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
     tile_of_index(t, T, ti, tj);
     rr_owner(ntl - 1 - t, ntl2, ow, os);
     sIJ[os * RR_NW + ow] = (unsigned short)(ti | (tj << 8));
+    // skyline (leaf pivots): tile (i, j) receives P(i, k) P(j, k)^T, zero while k is left of either row's first tile
+    sKm[os * RR_NW + ow] = max(sky[min(ti, 23)], sky[min(tj, 23)]);
   }
   __syncthreads();
 
@@ -1170,6 +1175,9 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
     int ijp[RR_SLOTS]; // packed (i | j << 8) per slot, wave uniform
 #pragma unroll
     for (int s = 0; s < RR_SLOTS; ++s) ijp[s] = __builtin_amdgcn_readfirstlane((int)sIJ[s * RR_NW + w]);
+    int kmn[RR_SLOTS]; // per slot: the first step whose update of the tile can be non-zero (skyline of a leaf pivot; 0 otherwise)
+#pragma unroll
+    for (int s = 0; s < RR_SLOTS; ++s) kmn[s] = __builtin_amdgcn_readfirstlane((int)sKm[s * RR_NW + w]);
     // ---- prologue: columns 0 and 1 go straight to LDS -- (0,0), (1,1) -> sDg, (i,0) -> sRaw[i],
     //      (i,1), i >= 2 -> sSol[1][i] (free until the panel solve of step 1) -- then the register tiles
     //      Every load of the prologue is issued before the first wait: three tiles of columns 0 / 1 per wave at
@@ -1307,10 +1315,12 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       const int live = (T - k - 1) * (T - k) / 2;
       const int top = rr_count(live < ntl2 ? live : ntl2, ntl2, w, hw) - 1;
       // one tile: acc -= P(ti) P(tj)^T, then park it if this was its last update; true if it was parked
-#define RR_UPDATE(acc_, ti_, tj_)                                                                                  \
+#define RR_UPDATE(acc_, ti_, tj_, kmin_)                                                                           \
   {                                                                                                                \
+    if (k >= (kmin_)) { /* left of the skyline P(ti, k) or P(tj, k) is zero: nothing to subtract */                \
     _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                               \
       acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(sS[(tj_) * (TS * TS) + st * 64 + lp], -sS[(ti_) * (TS * TS) + st * 64 + lp], acc_, 0, 0, 0); \
+    }                                                                                                              \
     if ((tj_) == k + 1) { /* last update: next panel column */                                                    \
       _Pragma("unroll") for (int q = 0; q < 4; ++q) sRaw[ti_][q * 64 + lp] = acc_[q];                              \
       lds_inc(cRaw, lane);                                                                                         \
@@ -1326,7 +1336,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
           d4 acc;
 #pragma unroll
           for (int q = 0; q < 4; ++q) acc[q] = sOv[hw][q * 64 + lp];
-          RR_UPDATE(acc, ti, tj);
+          RR_UPDATE(acc, ti, tj, kmn[RR_RSLOTS]);
 #pragma unroll
           for (int q = 0; q < 4; ++q) sOv[hw][q * 64 + lp] = acc[q];
         }
@@ -1341,7 +1351,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
               const int ti = ijp[s] & 0xff, tj = ijp[s] >> 8;
               if (!(ti == tj && tj == k + 1)) { // (k+1,k+1) went to the factor wave one step ago
                 d4 acc = tile[s];
-                RR_UPDATE(acc, ti, tj);
+                RR_UPDATE(acc, ti, tj, kmn[s]);
                 tile[s] = acc;
               }
             }
@@ -1389,7 +1399,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_rr(double *__restrict__ ba
                                                          const chol_potrf_desc *__restrict__ descs, int *__restrict__ info)
 {
   __shared__ double smem[RR_SMEM_DOUBLES];
-  potrf_rr_body<false>(base, ws, descs[blockIdx.x], info, nullptr, 0, smem);
+  potrf_rr_body<false>(base, ws, descs[blockIdx.x], info, nullptr, 0, smem, descs[blockIdx.x].sky);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1696,7 +1706,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_trsm(double *__restrict__ 
   const int grp = wave >> 2;
   const int n_tg = (n_trsm + 2) / 3;
   if ((int)blockIdx.x < n_potrf) {
-    potrf_rr_body<true>(base, ws, pdescs[blockIdx.x], info, progress + blockIdx.x, progress_base, smem);
+    potrf_rr_body<true>(base, ws, pdescs[blockIdx.x], info, progress + blockIdx.x, progress_base, smem, pdescs[blockIdx.x].sky);
   } else if ((int)blockIdx.x < n_potrf + n_tg) {
     double (*sX)[3][TS * TS] = (double (*)[3][TS * TS])smem;
     const int id = ((int)blockIdx.x - n_potrf) * 3 + grp;
@@ -1781,7 +1791,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ bas
       const chol_potrf_desc pd = pdescs[jb.first];
       follow_args fa;
       fa.ext = exts + jb.ext_first; fa.n_ext = jb.n_ext; fa.ctr = ctr; fa.ctr_total = ctr_total; fa.epoch = epoch; fa.wl = waits + jb.wait_first; fa.n_wl = jb.n_wait; fa.stamp = trace ? &trace[4 * j + 1] : nullptr; fa.xstamp = trace ? &trace[4 * njobs + 48 * j] : nullptr;
-      potrf_rr_body<true, true>(base, ws, pd, info, ctr + pd.ctr, epoch * ctr_total[pd.ctr], smem, fa, tid);
+      potrf_rr_body<true, true>(base, ws, pd, info, ctr + pd.ctr, epoch * ctr_total[pd.ctr], smem, pdescs[jb.first].sky, fa, tid);
     } else if (jb.kind == 1) {
       double (*sX)[3][TS * TS] = (double (*)[3][TS * TS])smem;
       chol_trsm_desc d = tdescs[jb.first + min(grp, jb.n - 1)];

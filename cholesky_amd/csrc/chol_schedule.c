@@ -435,7 +435,7 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
         B->tgt_sep = s;
       }
       if (mine) {
-        chol_potrf_desc pd = { diag, dinv, nb, ld, s, c0, 0, 0 };
+        chol_potrf_desc pd = { diag, dinv, nb, ld, s, c0, 0, 0, { 0 } };
         push_potrf(B, pd);
         const int flag = w->n_potrf - 1 - p0; /* this block's POTRF descriptor within the step */
         if (below > 0) push_trsm_run(B, diag, dinv, p->panel_off[s] + (c0 + nb) + colbase, nb, ld, below, flag);
@@ -962,7 +962,12 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
       const int ld_ = p->panel_ld[s_];                                                                            \
       const int64_t diag_ = p->panel_off[s_] + b_->c0 + (int64_t)b_->c0 * ld_;                                    \
       const int64_t dinv_ = p->dinv_off[s_] + (int64_t)(b_->c0 / CHOL_NB) * CHOL_NB * CHOL_NB;                    \
-      chol_potrf_desc pd_ = { diag_, dinv_, b_->nb, ld_, s_, b_->c0, b_->c_prog, 0 };                             \
+      chol_potrf_desc pd_ = { diag_, dinv_, b_->nb, ld_, s_, b_->c0, b_->c_prog, 0, { 0 } };                      \
+      if (sky[s_]) /* the block's skyline, relative to its own first tile column */                              \
+        for (int i_ = 0; i_ * CHOL_NB < b_->nb && i_ < 24; i_++) {                                                \
+          const int f_ = sky[s_][b_->c0 / CHOL_NB + i_] - b_->c0 / CHOL_NB;                                       \
+          pd_.sky[i_] = (unsigned char)(f_ > 0 ? f_ : 0);                                                         \
+        }                                                                                                         \
       push_potrf(B, pd_);                                                                                         \
       b_->potrf = w->n_potrf - 1;                                                                                 \
       const int wf_ = pg->n_wait;                                                                                 \
