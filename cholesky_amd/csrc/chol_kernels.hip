@@ -1540,7 +1540,10 @@ __global__ __launch_bounds__(64) void k_dinv(const double *__restrict__ Lp, int 
 // ------------------------------------------------------------------------------------------------
 #define TRSM_SLOTS 5 /* ceil(17 / 4) */
 // one strip, four waves (wave = 0..3 of the strip's group); sX = the group's three LDS tiles
-template <bool PUB, int SLOTS>
+// BAND (program launch, a banded leaf pivot factored as ONE block of up to CHOL_RR_MAXN columns): tile (J2, J) of the block's L is zero for
+// J2 - J > d.band (<= 4), so step J touches at most one tile per wave (J2 = wave mod 4 within (J, J + band]): the L prefetch ring
+// holds ONE tile per step instead of one per slot -- what lets a strip of seventeen column tiles fit the registers.
+template <bool PUB, int SLOTS, bool BAND = false>
 __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const double *__restrict__ ws, const chol_trsm_desc d, double (*sX)[TS * TS],
                                              int wave, int lane, const int *__restrict__ progress, int progress_base, int *__restrict__ info,
                                              int *__restrict__ chan = nullptr)
@@ -1554,6 +1557,8 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
   const int r15 = lane & 15, g = lane >> 4;
   const int lp = g * TS + r15;
   const bool vrow = r15 < m;
+  const int bw = BAND ? d.band : (1 << 20); // tiles below the diagonal that can be non-zero
+#define LS(s_) (BAND ? 0 : (s_))
 
   d4 tile[SLOTS];
   int64_t voff[SLOTS]; // lane part of the address of L(J2 * 16 + r15, g): rows past n are clamped (their
@@ -1579,8 +1584,8 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
     const double *lb_ = Lm + (int64_t)((J_) * TS) * ldl;                                                \
     _Pragma("unroll") for (int s = 0; s < SLOTS; ++s) {                                            \
       const int J2_ = wave + 4 * s;                                                                     \
-      if (J2_ > (J_) && J2_ < T) {                                                                      \
-        _Pragma("unroll") for (int st = 0; st < 4; ++st) buf_[s][st] = gload<PUB>(&lb_[voff[s] + (int64_t)(4 * st) * ldl]); \
+      if (J2_ > (J_) && J2_ < T && J2_ <= (J_) + bw) {                                                  \
+        _Pragma("unroll") for (int st = 0; st < 4; ++st) buf_[LS(s)][st] = gload<PUB>(&lb_[voff[s] + (int64_t)(4 * st) * ldl]); \
       }                                                                                                 \
     }                                                                                                   \
   }
@@ -1605,20 +1610,20 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
   {                                                                                                     \
     d4 acc_ = tile[s_];                                                                                 \
     _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                    \
-      acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(lpre[(JX_) % 3][s_][st], -sX[(JX_) % 3][st * 64 + lp], acc_, 0, 0, 0); \
+      acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(lpre[(JX_) % 3][LS(s_)][st], -sX[(JX_) % 3][st * 64 + lp], acc_, 0, 0, 0); \
     tile[s_] = acc_;                                                                                    \
   }
   // operands are fetched two steps ahead; vmcnt retires in order, so the inverse the next solve waits
   // for is issued before the L tiles of the same step
   int seen = 0; // last progress value read (fused launch)
-  double lpre[3][SLOTS][4], wpre[3][4];
+  double lpre[3][BAND ? 1 : SLOTS][4], wpre[3][4];
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       wpre[u][st] = 0.0;
 #pragma unroll
-      for (int s = 0; s < SLOTS; ++s) lpre[u][s][st] = 0.0;
+      for (int s = 0; s < (BAND ? 1 : SLOTS); ++s) lpre[u][s][st] = 0.0;
     }
   }
   if (wave == 0) LOAD_W(0, wpre[0]);
@@ -1652,13 +1657,13 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
 #pragma unroll
           for (int s = 0; s < SLOTS; ++s) {
             const int J2 = wave + 4 * s;
-            if (J2 > J && J2 < T) APPLY_X(J - 1, s);
+            if (J2 > J && J2 < T && J2 <= J - 1 + bw) APPLY_X(J - 1, s);
           }
         }
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
           const int J2 = wave + 4 * s;
-          if (J2 > J + 1 && J2 < T) APPLY_X(J, s);
+          if (J2 > J + 1 && J2 < T && J2 <= J + bw) APPLY_X(J, s);
         }
       }
       STAMP(2);
@@ -1673,6 +1678,7 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
 #undef LOAD_W
 #undef PUBLISH_X
 #undef APPLY_X
+#undef LS
 }
 
 __global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base, const double *__restrict__ ws,
@@ -1796,7 +1802,10 @@ __global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ bas
       double (*sX)[3][TS * TS] = (double (*)[3][TS * TS])smem;
       chol_trsm_desc d = tdescs[jb.first + min(grp, jb.n - 1)];
       if (grp >= jb.n) d.m = 0; // every group runs the same number of barriers: the strips of a job share one pivot block
-      trsm_rr_body<true, FUSED_SLOTS>(base, ws, d, sX[grp], wave & 3, lane, ctr + d.flag, epoch * ctr_total[d.flag], info, d.chan >= 0 ? ctr + d.chan : nullptr);
+      if (d.band > 0) // a banded leaf pivot factored as one block (up to CHOL_RR_MAXN columns: (CHOL_RR_MAXN / 16 + 3) / 4 column tiles per wave)
+        trsm_rr_body<true, (CHOL_RR_MAXN / TS + 3) / 4, true>(base, ws, d, sX[grp], wave & 3, lane, ctr + d.flag, epoch * ctr_total[d.flag], info, d.chan >= 0 ? ctr + d.chan : nullptr);
+      else
+        trsm_rr_body<true, FUSED_SLOTS>(base, ws, d, sX[grp], wave & 3, lane, ctr + d.flag, epoch * ctr_total[d.flag], info, d.chan >= 0 ? ctr + d.chan : nullptr);
     } else {
       stage_waits sw;
       sw.w = waits + jb.wait_first + jb.n_pre; sw.n = jb.n_wait - jb.n_pre; sw.ctr = ctr; sw.ctr_total = ctr_total; sw.epoch = epoch; sw.info = info;

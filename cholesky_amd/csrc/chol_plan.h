@@ -63,6 +63,8 @@ typedef struct {
   int n, ldl, m, ldb; /* m rows (<= CHOL_TRSM_ROWS) */
   int flag;           /* fused POTRF+TRSM launch: index of the pivot block's POTRF descriptor in the same launch; program launch: its progress counter */
   int chan;           /* program launch: first counter of the follow channel the strip reports its column tiles on, or -1 */
+  int band, pad;      /* program launch, banded leaf pivot wider than CHOL_FUSE_MAXN factored as ONE block: tile (J2, J) of its L is zero for
+                       * J2 - J > band (<= 4): the strip keeps one L tile per step and wave (0: dense pivot block) */
 } chol_trsm_desc;
 
 #define CHOL_TRSM_W_MAXN 64 /* widest pivot block the one-wave-per-strip TRSM kernel takes (4 tiles); measured against k_trsm_rr: 6.6 vs 8.0 us at 32, 8.4 vs 9.6 at 64, 12.6 vs 11.1 at 128 */
@@ -144,7 +146,8 @@ typedef struct {
   int follow;               /* ... in which pivot blocks follow their children's / predecessor's TRSM strips */
   int dist_top;             /* 0 / 1 / 2 = auto (CHOL_DIST_MIN); world > 1: the levels above the cut are distributed over the ranks by column blocks (owner factors and
                              * solves a block, broadcasts it, every rank updates the column blocks it owns) instead of replicated */
-  int skyline;              /* program launch: the tile-level skyline of the leaf pivots is used (zero early parts, zero tile updates skipped) */
+  int skyline;              /* program launch: the tile-level skyline of the leaf pivots is used (zero early parts, zero tile updates skipped,
+                             * banded leaves up to CHOL_RR_MAXN columns factored as one block) */
   int fine_upd;             /* program launch: followed strips wait for the update jobs into THEIR rows' block, not for all into the panel */
   int staged;               /* program launch: the extend-add jobs take their sources as the source pivots finish (staged waits) */
   int follow_tail_split;    /* the same tail for the next column block of a split pivot (one source: the strips of its own rows) */

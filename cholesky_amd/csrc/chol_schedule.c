@@ -73,6 +73,8 @@ typedef struct { int64_t c_off; int ldc, m, n, syrk, src_begin, src_end, blk, ar
 typedef struct { chol_level_work *w; const chol_sched_opts *o; int force_fine; int cur_blk; const int *follow_lim;
   /* distributed top level: targets are cut at the column blocks of the target separator and kept only where this rank owns the block */
   int dist_world, dist_rank; const struct cholamd_plan *dist_plan; int tgt_sep, tgt_col0; int cap_b;
+  int cur_band; const int *bw_of; /* program launch: band of the pivot block whose strips are being pushed (0: dense); column-block width per
+                                   * separator where it differs from pivot_block_width() (banded leaves factored as one block), or NULL */
   int cap_p, cap_t, cap_k, cap_km, cap_s, cap_ph; upd_target *pend; int n_pend, cap_pend; } builder;
 /* Blocking of a pivot at the schedule level.  The POTRF kernel takes pivots up to CHOL_RR_MAXN whole, but one
  * workgroup's MFMA throughput bounds the early steps of a large one (the trailing update of step 0 of a
@@ -140,7 +142,7 @@ static void push_trsm_run(builder *B, int64_t l_off, int64_t dinv_off, int64_t b
   for (int r0 = 0; r0 < m; r0 += CHOL_TRSM_ROWS) {
     if (w->n_trsm == B->cap_t) { B->cap_t = B->cap_t ? 2 * B->cap_t : 64; w->trsm = realloc(w->trsm, B->cap_t * sizeof(chol_trsm_desc)); }
     const int mm = m - r0 < CHOL_TRSM_ROWS ? m - r0 : CHOL_TRSM_ROWS;
-    chol_trsm_desc td = { l_off, dinv_off, b_off + r0, n, ld, mm, ld, flag, -1 };
+    chol_trsm_desc td = { l_off, dinv_off, b_off + r0, n, ld, mm, ld, flag, -1, B->cur_band, 0 };
     w->trsm[w->n_trsm++] = td;
   }
 }
@@ -151,7 +153,7 @@ static void pad_trsm_group(builder *B, int phase_first, int group, int64_t l_off
   chol_level_work *w = B->w;
   while ((w->n_trsm - phase_first) % group != 0) {
     if (w->n_trsm == B->cap_t) { B->cap_t = B->cap_t ? 2 * B->cap_t : 64; w->trsm = realloc(w->trsm, B->cap_t * sizeof(chol_trsm_desc)); }
-    chol_trsm_desc td = { l_off, dinv_off, b_off, n, ld, 0, ld, flag, -1 };
+    chol_trsm_desc td = { l_off, dinv_off, b_off, n, ld, 0, ld, flag, -1, B->cur_band, 0 };
     w->trsm[w->n_trsm++] = td;
   }
 }
@@ -309,7 +311,7 @@ static int emit_cell_tasks(builder *B, const plan_t *p, const upd_tuple *tu, int
         /* program launch with staged waits: one source per pivot BLOCK of the source separator (its columns c0 .. c0 + nb of the
          * panel), tagged -(64 separator + block) - 1 for now (emit_update_jobs turns the tag into the stage): what is left to
          * do when the separator's last block has been solved is that block's columns, not the whole pivot's */
-        const int bw_ = pivot_block_width(B->o, p->sep_size[pc[q].src_sep]);
+        const int bw_ = B->bw_of ? B->bw_of[pc[q].src_sep] : pivot_block_width(B->o, p->sep_size[pc[q].src_sep]);
         for (int cb = 0, st_ = 0; cb < pc[q].k; cb += bw_, st_++) {
           const int kb = pc[q].k - cb < bw_ ? pc[q].k - cb : bw_;
           chol_upd_src sd = { pc[q].a_off + (int64_t)cb * pc[q].lda, pc[q].b_off + (int64_t)cb * pc[q].ldb, pc[q].lda, pc[q].ldb, kb, rg_, -(64 * pc[q].src_sep + st_) - 1, 0 };
@@ -898,10 +900,25 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
   pbuild *P = &Pd;
   const int L = p->levels, ns = p->nsep;
   int rc = 0;
+  /* column-block width per separator.  A LEAF whose factor is banded at tile level (skyline: at most four tiles below the diagonal)
+   * is factored as ONE block up to CHOL_RR_MAXN columns: its POTRF skips the zero tiles, so one CU keeps up with the pivot chain, and
+   * its strips keep one L tile per step (trsm_rr_body, band form) -- no split, no transition between column blocks */
+  unsigned char **sky = opts->skyline ? leaf_skylines(p) : calloc(ns + 1, sizeof(unsigned char *));
+  int *bw_of = malloc((ns + 1) * sizeof(int)), *band_of = calloc(ns + 1, sizeof(int));
+  for (int s = 1; s <= ns; s++) {
+    const int n = p->sep_size[s];
+    bw_of[s] = pivot_block_width(opts, n);
+    if (sky[s] && n > CHOL_FUSE_MAXN && n <= CHOL_RR_MAXN && pivot_blocks(opts, n) > 1) {
+      int band = 1;
+      for (int i = 0; i * CHOL_NB < n; i++) if (i - sky[s][i] > band) band = i - sky[s][i];
+      if (band <= 4) { bw_of[s] = n; band_of[s] = band; }
+    }
+  }
+  B->bw_of = bw_of;
   /* eligibility: every pivot block fits both fused roles */
   for (int s = 1; s <= ns && !rc; s++) {
-    const int bw = pivot_block_width(opts, p->sep_size[s]);
-    if (bw > CHOL_FUSE_MAXN || bw > CHOL_RR_MAXN) { chol_set_error("program launch: pivot block of %d columns (separator %d) exceeds %d", bw, s, CHOL_FUSE_MAXN); rc = CHOLAMD_ERR_ARG; }
+    const int bw = bw_of[s];
+    if ((bw > CHOL_FUSE_MAXN && !band_of[s]) || bw > CHOL_RR_MAXN) { chol_set_error("program launch: pivot block of %d columns (separator %d) exceeds %d", bw, s, CHOL_FUSE_MAXN); rc = CHOLAMD_ERR_ARG; }
   }
   { /* cheap early refusal of large problems: 16x16 tiles of the trailing updates of split pivots, and of every panel once per
      * tree level below it (extend-add cells) */
@@ -909,13 +926,13 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
     for (int s = 1; s <= ns; s++) {
       const int n = p->sep_size[s], rows = p->panel_rows[s];
       if (n <= 0) continue;
-      const int nbk = pivot_blocks(opts, n), bw = pivot_block_width(opts, n);
+      const int bw = bw_of[s], nbk = (n + bw - 1) / bw;
       for (int st = 0; st + 1 < nbk; st++) est += (double)((rows - (st + 1) * bw) / 16 + 1) * ((n - (st + 1) * bw) / 16 + 1);
       est += (double)(rows / 16 + 1) * (n / 16 + 1) * (L - 1 - p->level_of[s]);
     }
-    if (est > 2.0 * PROG_MAX_TASKS) { chol_set_error("program launch: about %.0f update tasks", est); return CHOLAMD_ERR_ARG; }
+    if (est > 2.0 * PROG_MAX_TASKS) { chol_set_error("program launch: about %.0f update tasks", est); rc = CHOLAMD_ERR_ARG; }
   }
-  if (rc) return rc;
+  if (rc) { free_skylines(sky, ns); free(bw_of); free(band_of); return rc; }
   const int follow = opts->follow && opts->cells;
   pg->follow = follow;
   int64_t *first = malloc(p->nblk * sizeof(int64_t));
@@ -931,7 +948,7 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
     c_upd[s] = new_ctr(P, 0); c_updd[s] = new_ctr(P, 0);
     if (P->c_updp) P->c_updp[s] = new_ctr(P, 0);
     const int n = p->sep_size[s];
-    const int nbk = n > 0 ? pivot_blocks(opts, n) : 0, bw = pivot_block_width(opts, n);
+    const int bw = bw_of[s], nbk = n > 0 ? (n + bw - 1) / bw : 0;
     nblk_of[s] = nbk;
     pb[s] = calloc(nbk > 0 ? nbk : 1, sizeof(pblock));
     for (int st = 0; st < nbk; st++) {
@@ -942,7 +959,6 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
       b->c_strips = new_ctr(P, 0);
     }
   }
-  unsigned char **sky = opts->skyline ? leaf_skylines(p) : calloc(ns + 1, sizeof(unsigned char *));
   /* expected position (in 16-column steps) at which a separator's pivot chain starts: the longest chain below it; leaves start at 0.
    * A follower consumes its children's column tiles in the order of these positions */
   int *est_start = calloc(ns + 1, sizeof(int));
@@ -1007,6 +1023,7 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
         const int64_t colbase = (int64_t)c0 * ld;
         const int below = n - c0 - nb;
         const int t0 = w->n_trsm;
+        B->cur_band = band_of[s]; /* strips of a banded leaf factored as one block */
         /* rows of the next column block of this pivot */
         int nb1 = 0;
         if (below > 0) {
@@ -1040,6 +1057,7 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
           if (BIDX(p, anc, s) < 0) continue;
           push_block_rows(B, p, anc, s, ha == hp ? par_lim : 0, p->sep_size[anc], snap, first, count, diag, dinv, nb, ld, colbase, b->c_prog, -1);
         }
+        B->cur_band = 0;
         b->n_groups = emit_trsm_jobs(P, B, t0, c_upd[s], cnt_upd[s], b->c_strips, b->ch_par, P->c_updp ? P->c_updp[s] : -1, P->c_updp ? P->cnt_updp[s] : 0, b->ch_below, c_updd[s], cnt_updd[s]);
         pg->ctr_total[b->c_strips] = b->n_groups;
       }
@@ -1363,7 +1381,7 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
   for (int s = 1; s <= ns; s++) { pg->ctr_total[c_upd[s]] = cnt_upd[s]; pg->ctr_total[c_updd[s]] = cnt_updd[s]; if (P->c_updp) pg->ctr_total[P->c_updp[s]] = P->cnt_updp[s]; }
   free(P->c_updp); free(P->cnt_updp); P->c_updp = P->cnt_updp = NULL;
   for (int s = 1; s <= ns; s++) free(pb[s]);
-  free_skylines(sky, ns);
+  free_skylines(sky, ns); free(bw_of); free(band_of);
   free(est_start); free(pb); free(nblk_of); free(first); free(count); free(c_upd); free(c_updd); free(cnt_upd); free(cnt_updd); free(snap_upd); free(follow_lim);
   free(B->pend);
   if (rc) { chol_level_work_free(w); chol_program_free(pg); }
@@ -1433,12 +1451,17 @@ int chol_program_check(const plan_t *p, const chol_sched_opts *opts, int workers
       chol_level_work lw;
       rc = chol_build_level_work(p, opts, l, 0, 1, &lw);
       if (rc) break;
-      for (int i = 0; i < lw.n_potrf; i++) PUSHQ(a, na, ca, -1, lw.potrf[i].a_off, lw.potrf[i].n, lw.potrf[i].col0);
-      for (int i = 0; i < lw.n_trsm; i++) for (int r = 0; r < lw.trsm[i].m; r++) PUSHQ(a, na, ca, -2, lw.trsm[i].b_off + r, lw.trsm[i].n, lw.trsm[i].l_off);
+      /* per 16-column tile (the program may factor a banded leaf as one block where the level lists split it): the diagonal tiles
+       * factored, and per solved row the first element of every column tile */
+      /* coverage per (row, 16-column tile) of the panels -- the program may factor a banded leaf as one block where the level lists
+       * split it (rows of the later blocks are then panel rows of the POTRF, not TRSM rows): the first element of every column tile of
+       * every row a POTRF block factors (diagonal tile and below) or a strip solves; each exactly once on both sides */
+      for (int i = 0; i < lw.n_potrf; i++) for (int ct = 0; ct * CHOL_NB < lw.potrf[i].n; ct++) for (int r = ct * CHOL_NB; r < lw.potrf[i].n; r++) PUSHQ(a, na, ca, -1, lw.potrf[i].a_off + r + (int64_t)ct * CHOL_NB * lw.potrf[i].lda, 0, 0);
+      for (int i = 0; i < lw.n_trsm; i++) for (int r = 0; r < lw.trsm[i].m; r++) for (int ct = 0; ct * CHOL_NB < lw.trsm[i].n; ct++) PUSHQ(a, na, ca, -1, lw.trsm[i].b_off + r + (int64_t)ct * CHOL_NB * lw.trsm[i].ldb, 0, 0);
       chol_level_work_free(&lw);
     }
-    for (int i = 0; i < w.n_potrf; i++) PUSHQ(b, nb, cb, -1, w.potrf[i].a_off, w.potrf[i].n, w.potrf[i].col0);
-    for (int i = 0; i < w.n_trsm; i++) for (int r = 0; r < w.trsm[i].m; r++) PUSHQ(b, nb, cb, -2, w.trsm[i].b_off + r, w.trsm[i].n, w.trsm[i].l_off);
+    for (int i = 0; i < w.n_potrf; i++) for (int ct = 0; ct * CHOL_NB < w.potrf[i].n; ct++) for (int r = ct * CHOL_NB; r < w.potrf[i].n; r++) PUSHQ(b, nb, cb, -1, w.potrf[i].a_off + r + (int64_t)ct * CHOL_NB * w.potrf[i].lda, 0, 0);
+    for (int i = 0; i < w.n_trsm; i++) for (int r = 0; r < w.trsm[i].m; r++) for (int ct = 0; ct * CHOL_NB < w.trsm[i].n; ct++) PUSHQ(b, nb, cb, -1, w.trsm[i].b_off + r + (int64_t)ct * CHOL_NB * w.trsm[i].ldb, 0, 0);
 #undef PUSHQ
     if (!rc) {
       qsort(a, na, sizeof(quad), cmp_quad);
