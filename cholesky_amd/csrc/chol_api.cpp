@@ -250,6 +250,7 @@ extern "C" int cholamd_device_set_option(cholamd_device *d, const char *name, in
   else if (n == "staged") d->opt.staged = value != 0;
   else if (n == "fine_upd") d->opt.fine_upd = value != 0;
   else if (n == "skyline") d->opt.skyline = value != 0;
+  else if (n == "stage_chunk") d->opt.stage_chunk = value < 0 ? 0 : value;
   else if (n == "dist_top") d->opt.dist_top = value;
   else if (n == "solve_reference_shape") { d->solve_reference_shape = value != 0; rebuild = false; }
   else { chol_set_error("unknown option '%s'", n.c_str()); return CHOLAMD_ERR_ARG; }

@@ -504,6 +504,8 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_[i]) :: "memory"); __builtin_amdgcn_sched_barrier(0); if ((i) > 0) acc_[i] += st_[i] - st_[(i) - 1]; } while (0)
 __device__ unsigned long long g_trace[12][20][8]; // [wave][step][stamp]: absolute times, k_potrf_rr only
 #define STAMPK(i) do { STAMP(i); if (lane == 0 && k < 20) g_trace[wave][k][i] = st_[i]; } while (0)
+__device__ unsigned long long g_walk[12][20][8]; // [wave][step][point]: absolute times inside the tile waves' update walk
+#define STAMPX(i) do { unsigned long long x_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x_) :: "memory"); __builtin_amdgcn_sched_barrier(0); if (lane == 0 && k < 20) g_walk[wave][k][i] = x_; } while (0)
 #define STAMP_FLUSH do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) g_stamps[i_] = acc_[i_]; } while (0)
 #define STAMP_FLUSH2 do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) g_stamps[8 + i_] = acc_[i_]; } while (0)
 #ifndef STAMP_WAVE
@@ -514,6 +516,7 @@ __device__ unsigned long long g_trace[12][20][8]; // [wave][step][stamp]: absolu
 #define STAMP_DECL
 #define STAMP(i)
 #define STAMPK(i)
+#define STAMPX(i)
 #define STAMP_FLUSH
 #define STAMP_FLUSH2
 #endif
@@ -766,7 +769,11 @@ __device__ __forceinline__ void tile_of_index(int idx, int T, int &ti, int &tj)
 #define RR_OFF_IJ (RR_OFF_OV + RR_NHEAVY * TS * TS)
 #define RR_OFF_FLAG (RR_OFF_IJ + (RR_SLOTS * RR_NW + 16 + 3) / 4)
 #define RR_OFF_KM (RR_OFF_FLAG + 4)                       /* per (slot, wave): first step whose update can be non-zero (skyline) */
-#define RR_SMEM_DOUBLES (RR_OFF_KM + (RR_SLOTS * RR_NW + 7) / 8)
+#define RR_OFF_MASK (RR_OFF_KM + (RR_SLOTS * RR_NW + 7) / 8) /* per (step, wave): the slots that have work in the step, the panel tiles to solve */
+#define RR_OFF_SKY (RR_OFF_MASK + (RR_MAXT * RR_NW + 1) / 2)  /* the block's tile-level skyline (24 bytes) */
+#define RR_SMEM_DOUBLES (RR_OFF_SKY + 3)
+#define RR_M_SOLVE0 12 /* step mask: bit s < 12 = slot s; bits 12, 13 = the wave's first / second panel tile of the step is not structurally zero */
+#define RR_M_SOLVE1 13
 // Note (measured): waves of a workgroup are dealt to the four SIMDs round-robin, so waves 0, 4 and 8
 // share a SIMD, and fp64 MFMA runs on the same DP units as fp64 VALU: the tile waves' 64-cycle MFMAs
 // on the factor wave's SIMD stretch its scalar chain (chol16 3.4k -> 4.9k cycles).  Leaving waves 4 and
@@ -1059,6 +1066,8 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
   unsigned short *const sIJ = (unsigned short *)(smem + RR_OFF_IJ);                    // [RR_SLOTS * RR_NW + 16]
   int *const sFlag = (int *)(smem + RR_OFF_FLAG);                                      // [8] fL, fP, cSol, cUpd, cRaw, fA, fD
   unsigned char *const sKm = (unsigned char *)(smem + RR_OFF_KM);                      // [RR_SLOTS * RR_NW]
+  int *const sMask = (int *)(smem + RR_OFF_MASK);                                      // [RR_MAXT * RR_NW] step k, tile wave w at k * RR_NW + w
+  unsigned char *const sSky = (unsigned char *)(smem + RR_OFF_SKY);                    // [24]
   int *const fL = &sFlag[0], *const fP = &sFlag[1], *const cSol = &sFlag[2], *const cUpd = &sFlag[3];
   int *const cRaw = &sFlag[4]; // raw tiles parked in sRaw so far (column j contributes T - 1 - j)
   int *const fA = &sFlag[6];   // j: raw tile (j, j-1) is in sRaw[j]
@@ -1075,6 +1084,8 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
   const int lp0 = g * TS + r15;
 
   for (int t = tid; t < RR_SLOTS * RR_NW; t += RR_THREADS) { sIJ[t] = (unsigned short)0xffff; sKm[t] = 0; }
+  for (int t = tid; t < RR_MAXT * RR_NW; t += RR_THREADS) sMask[t] = 0;
+  if (tid < 24) sSky[tid] = sky[tid];
   if (tid < 8) sFlag[tid] = (tid == 6 || tid == 7) ? 1 : 0; // (1,0) and (1,1) are parked by the prologue
   if (tid < TS * TS) sConv[TS + (tid >> 4)][tid & 15] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
   __syncthreads();
@@ -1090,7 +1101,20 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
     rr_owner(ntl - 1 - t, ntl2, ow, os);
     sIJ[os * RR_NW + ow] = (unsigned short)(ti | (tj << 8));
     // skyline (leaf pivots): tile (i, j) receives P(i, k) P(j, k)^T, zero while k is left of either row's first tile
-    sKm[os * RR_NW + ow] = max(sky[min(ti, 23)], sky[min(tj, 23)]);
+    const int kmin = max(sky[min(ti, 23)], sky[min(tj, 23)]);
+    sKm[os * RR_NW + ow] = kmin;
+    // the steps in which the slot has work: its updates (steps kmin .. last) and its hand-over in step `last` -- an off-diagonal
+    // tile is parked as a raw panel tile after step tj - 1, a diagonal tile goes to the factor wave one step earlier
+    const int last = ti == tj ? tj - 2 : tj - 1;
+    for (int k = min(kmin, last); k <= last; ++k) atomicOr(&sMask[k * RR_NW + ow], 1 << os);
+  }
+  // panel tile i of step k (i >= k + 2; (k+1, k) is the factor wave's) is solved by heavy wave i mod 9, unless it is left of the skyline
+  for (int t = tid; t < T * T; t += RR_THREADS) {
+    const int k = t / T, i = t % T;
+    if (i >= k + 2 && sky[min(i, 23)] <= k) {
+      const int hv = i % RR_NHEAVY;
+      atomicOr(&sMask[k * RR_NW + hv + hv / 3], 1 << (i < k + 2 + RR_NHEAVY ? RR_M_SOLVE0 : RR_M_SOLVE1));
+    }
   }
   __syncthreads();
 
@@ -1246,46 +1270,50 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       int k2 = k + 2; // opaque: otherwise "ti == k + 2" makes the flag value a per-slot constant, hoisted and spilled
       asm volatile("" : "+s"(k2));
       const int par = k & 1;
+      const int mk = __builtin_amdgcn_readfirstlane(sMask[k * RR_NW + w]); // what this wave does in the step (arrives with the first poll)
       // ---- 1. panel solve out of LDS (needs L(k,k) and every raw tile of column k)
       lds_wait_ge(fL, k + 1);
       STAMPK(1);
       lds_wait_ge(cRaw, (k + 1) * (T - 1) - k * (k + 1) / 2);
       STAMPK(2);
-      if (hw >= 0) {
+      if (mk & ((1 << RR_M_SOLVE0) | (1 << RR_M_SOLVE1))) {
         // panel tile i goes to heavy wave i mod 9 (at most two each: T <= 17); the light waves keep the
-        // factor wave's SIMD quiet.  X = T Linv^T: four accumulating MFMAs per tile, two tiles interleaved
+        // factor wave's SIMD quiet.  X = T Linv^T: four accumulating MFMAs per tile, two tiles interleaved.  Tiles left of a
+        // leaf pivot's skyline are zero and stay so: nobody solves, stores or (RR_UPDATE: kmin) reads them
         const int i0 = k + 2 + ((hw + RR_NHEAVY - ((k + 2) % RR_NHEAVY)) % RR_NHEAVY), i1 = i0 + RR_NHEAVY;
-        if (i0 < T) {
-          double wv[4];
+        double wv[4];
 #pragma unroll
-          for (int st = 0; st < 4; ++st) wv[st] = sLW[par][TS + 4 * st + g][r15];
+        for (int st = 0; st < 4; ++st) wv[st] = sLW[par][TS + 4 * st + g][r15];
+        double *const col = A + (int64_t)(k * TS + g) * lda;
+        if (((mk >> RR_M_SOLVE0) & 3) == 3) { // two tiles (pivot blocks wider than 11 tiles only), interleaved
           const int row0 = i0 * TS + r15, row1 = i1 * TS + r15;
-          double *const col = A + (int64_t)(k * TS + g) * lda;
-          d4 raw0, x0 = { 0.0, 0.0, 0.0, 0.0 };
+          d4 raw0, raw1, x0 = { 0.0, 0.0, 0.0, 0.0 }, x1 = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
-          for (int q = 0; q < 4; ++q) raw0[q] = sRaw[i0][q * 64 + lp];
-          if (i1 < T) { // two tiles (pivot blocks wider than 11 tiles only), interleaved
-            d4 raw1, x1 = { 0.0, 0.0, 0.0, 0.0 };
+          for (int q = 0; q < 4; ++q) { raw0[q] = sRaw[i0][q * 64 + lp]; raw1[q] = sRaw[i1][q * 64 + lp]; }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) raw1[q] = sRaw[i1][q * 64 + lp];
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-              x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[st], raw0[st], x0, 0, 0, 0);
-              x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[st], raw1[st], x1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              sSol[par][i1][q * 64 + lp] = x1[q];
-              if (row1 < n) gstore<PUB>(&col[row1 + (int64_t)(4 * q) * lda], x1[q]);
-            }
-          } else {
-#pragma unroll
-            for (int st = 0; st < 4; ++st) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[st], raw0[st], x0, 0, 0, 0);
+          for (int st = 0; st < 4; ++st) {
+            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[st], raw0[st], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[st], raw1[st], x1, 0, 0, 0);
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             sSol[par][i0][q * 64 + lp] = x0[q];
+            sSol[par][i1][q * 64 + lp] = x1[q];
             if (row0 < n) gstore<PUB>(&col[row0 + (int64_t)(4 * q) * lda], x0[q]);
+            if (row1 < n) gstore<PUB>(&col[row1 + (int64_t)(4 * q) * lda], x1[q]);
+          }
+        } else {
+          const int i = (mk & (1 << RR_M_SOLVE0)) ? i0 : i1;
+          const int row = i * TS + r15;
+          d4 raw, x = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+          for (int q = 0; q < 4; ++q) raw[q] = sRaw[i][q * 64 + lp];
+#pragma unroll
+          for (int st = 0; st < 4; ++st) x = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[st], raw[st], x, 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            sSol[par][i][q * 64 + lp] = x[q];
+            if (row < n) gstore<PUB>(&col[row + (int64_t)(4 * q) * lda], x[q]);
           }
         }
       }
@@ -1303,17 +1331,18 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
           d4 acc;
 #pragma unroll
           for (int q = 0; q < 4; ++q) acc[q] = sSol[1][i][q * 64 + lp];
+          if (sSky[min(i, 23)] == 0) { // P(i, 0) is zero, and was not solved, otherwise
 #pragma unroll
           for (int st = 0; st < 4; ++st)
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sS[1 * (TS * TS) + st * 64 + lp], -sS[i * (TS * TS) + st * 64 + lp], acc, 0, 0, 0);
+          }
 #pragma unroll
           for (int q = 0; q < 4; ++q) sRaw[i][q * 64 + lp] = acc[q];
           lds_inc(cRaw, lane);
           if (i == 2) lds_set(fA, 2, lane);
         }
       }
-      const int live = (T - k - 1) * (T - k) / 2;
-      const int top = rr_count(live < ntl2 ? live : ntl2, ntl2, w, hw) - 1;
+      STAMPX(0);
       // one tile: acc -= P(ti) P(tj)^T, then park it if this was its last update; true if it was parked
 #define RR_UPDATE(acc_, ti_, tj_, kmin_)                                                                           \
   {                                                                                                                \
@@ -1330,36 +1359,36 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       lds_set(fD, k2, lane);                                                                                       \
     }                                                                                                              \
   }
-      if (top >= RR_RSLOTS) { // the LDS-resident slot holds the wave's earliest columns: first in line
+      // the step mask names the slots with work: live tiles (column > k) that receive a non-zero update or are handed over
+      if (mk & (1 << RR_RSLOTS)) { // the LDS-resident slot holds the wave's earliest columns: first in line
         const int ti = ijp[RR_RSLOTS] & 0xff, tj = ijp[RR_RSLOTS] >> 8;
-        if (!(ti == tj && tj == k + 1)) {
-          d4 acc;
+        d4 acc;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q] = sOv[hw][q * 64 + lp];
-          RR_UPDATE(acc, ti, tj, kmn[RR_RSLOTS]);
+        for (int q = 0; q < 4; ++q) acc[q] = sOv[hw][q * 64 + lp];
+        RR_UPDATE(acc, ti, tj, kmn[RR_RSLOTS]);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) sOv[hw][q * 64 + lp] = acc[q];
-        }
+        for (int q = 0; q < 4; ++q) sOv[hw][q * 64 + lp] = acc[q];
         __builtin_amdgcn_sched_barrier(0);
       }
+      STAMPX(1);
 #pragma unroll
       for (int sg = (RR_RSLOTS - 1) / 4; sg >= 0; --sg) {
-        if (top >= 4 * sg) {
+        STAMPX(2 + sg);
+        if (mk & (0xf << (4 * sg))) {
 #pragma unroll
           for (int s = (4 * sg + 3 < RR_RSLOTS ? 4 * sg + 3 : RR_RSLOTS - 1); s >= 4 * sg; --s) {
-            if (s <= top) {
+            if (mk & (1 << s)) { // ((k+1,k+1) went to the factor wave one step ago: not in the mask)
               const int ti = ijp[s] & 0xff, tj = ijp[s] >> 8;
-              if (!(ti == tj && tj == k + 1)) { // (k+1,k+1) went to the factor wave one step ago
-                d4 acc = tile[s];
-                RR_UPDATE(acc, ti, tj, kmn[s]);
-                tile[s] = acc;
-              }
+              d4 acc = tile[s];
+              RR_UPDATE(acc, ti, tj, kmn[s]);
+              tile[s] = acc;
             }
             __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
 #undef RR_UPDATE
+      STAMPX(5);
       // ---- the light waves solve no panel tiles: one of them copies L(k,k) and Linv(k,k) from LDS to global
       //      memory after its (short) update chain, off every other wave's path (sLW of this parity stays
       //      valid until every tile wave has finished step k)

@@ -148,6 +148,8 @@ typedef struct {
                              * solves a block, broadcasts it, every rank updates the column blocks it owns) instead of replicated */
   int skyline;              /* program launch: the tile-level skyline of the leaf pivots is used (zero early parts, zero tile updates skipped,
                              * banded leaves up to CHOL_RR_MAXN columns factored as one block) */
+  int stage_chunk;          /* program launch: a banded leaf factored as one block hands its columns to the extend-add jobs in chunks of this many
+                             * column tiles (every strip of the block then publishes its column tiles); 0: the whole block at once */
   int fine_upd;             /* program launch: followed strips wait for the update jobs into THEIR rows' block, not for all into the panel */
   int staged;               /* program launch: the extend-add jobs take their sources as the source pivots finish (staged waits) */
   int follow_tail_split;    /* the same tail for the next column block of a split pivot (one source: the strips of its own rows) */
@@ -157,6 +159,7 @@ typedef struct {
                              * rank super_blocks * (block width) instead of one per block */
 } chol_sched_opts;
 #define CHOL_SUPER_BLOCKS 3
+#define CHOL_STAGE_CHUNK 0
 void chol_sched_opts_default(chol_sched_opts *o);
 void chol_sched_opts_from_env(chol_sched_opts *o);
 

@@ -73,6 +73,7 @@ typedef struct { int64_t c_off; int ldc, m, n, syrk, src_begin, src_end, blk, ar
 typedef struct { chol_level_work *w; const chol_sched_opts *o; int force_fine; int cur_blk; const int *follow_lim;
   /* distributed top level: targets are cut at the column blocks of the target separator and kept only where this rank owns the block */
   int dist_world, dist_rank; const struct cholamd_plan *dist_plan; int tgt_sep, tgt_col0; int cap_b;
+  const int *sw_of; /* program launch, staged waits: columns per stage of a separator's sources (its column-block width, or the chunk of a banded leaf) */
   int cur_band; const int *bw_of; /* program launch: band of the pivot block whose strips are being pushed (0: dense); column-block width per
                                    * separator where it differs from pivot_block_width() (banded leaves factored as one block), or NULL */
   int cap_p, cap_t, cap_k, cap_km, cap_s, cap_ph; upd_target *pend; int n_pend, cap_pend; } builder;
@@ -87,7 +88,7 @@ static int env_int(const char *name, int dflt) { const char *e = getenv(name); r
 void chol_sched_opts_default(chol_sched_opts *o)
 {
   o->split_min = CHOL_SPLIT_MIN; o->split_nb = CHOL_SPLIT_NB; o->fuse = 1; o->fuse_update_max = CHOL_FUSE_UPDATE_MAX;
-  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL; o->follow_tail_split = CHOL_FOLLOW_TAIL; o->staged = 1; o->fine_upd = 1; o->skyline = 1;
+  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL; o->follow_tail_split = CHOL_FOLLOW_TAIL; o->staged = 1; o->fine_upd = 1; o->skyline = 1; o->stage_chunk = CHOL_STAGE_CHUNK;
 }
 void chol_sched_opts_from_env(chol_sched_opts *o)
 {
@@ -107,6 +108,7 @@ void chol_sched_opts_from_env(chol_sched_opts *o)
   o->staged = !env_int("CHOLAMD_NO_STAGED", 0);
   o->fine_upd = !env_int("CHOLAMD_NO_FINE_UPD", 0);
   o->skyline = !env_int("CHOLAMD_NO_SKYLINE", 0);
+  o->stage_chunk = env_int("CHOLAMD_STAGE_CHUNK", o->stage_chunk);
 }
 static int split_nb(const chol_sched_opts *o) { int v = o->split_nb; if (v > CHOL_RR_MAXN) v = CHOL_RR_MAXN; v = (v + 15) / 16 * 16; if (v < 16) v = 16; return v; }
 static int pivot_blocks(const chol_sched_opts *o, int n) { return n > o->split_min || n > CHOL_RR_MAXN ? (n + split_nb(o) - 1) / split_nb(o) : 1; }
@@ -311,7 +313,7 @@ static int emit_cell_tasks(builder *B, const plan_t *p, const upd_tuple *tu, int
         /* program launch with staged waits: one source per pivot BLOCK of the source separator (its columns c0 .. c0 + nb of the
          * panel), tagged -(64 separator + block) - 1 for now (emit_update_jobs turns the tag into the stage): what is left to
          * do when the separator's last block has been solved is that block's columns, not the whole pivot's */
-        const int bw_ = B->bw_of ? B->bw_of[pc[q].src_sep] : pivot_block_width(B->o, p->sep_size[pc[q].src_sep]);
+        const int bw_ = B->sw_of ? B->sw_of[pc[q].src_sep] : B->bw_of ? B->bw_of[pc[q].src_sep] : pivot_block_width(B->o, p->sep_size[pc[q].src_sep]);
         for (int cb = 0, st_ = 0; cb < pc[q].k; cb += bw_, st_++) {
           const int kb = pc[q].k - cb < bw_ ? pc[q].k - cb : bw_;
           chol_upd_src sd = { pc[q].a_off + (int64_t)cb * pc[q].lda, pc[q].b_off + (int64_t)cb * pc[q].ldb, pc[q].lda, pc[q].ldb, kb, rg_, -(64 * pc[q].src_sep + st_) - 1, 0 };
@@ -623,7 +625,9 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
 #define PROG_HEAVY_STEPS 48   /* MFMA k-steps (of 4 columns) from which a task is split over four waves */
 #endif
 #define PROG_MAX_TASKS 24000 /* beyond this the per-level launches (macro tiles) are the better schedule */
-typedef struct { int potrf, c_prog, c_strips, n_groups, c0, nb, emitted; int ch_below, ns_below; int ch_par, ns_par; int64_t par_off; } pblock;
+typedef struct { int potrf, c_prog, c_strips, n_groups, c0, nb, emitted; int ch_below, ns_below; int ch_par, ns_par; int64_t par_off;
+  int ch_rest, ns_rest; /* chunked block (stage_chunk): channel of every strip that is not a followed one */
+} pblock;
 typedef struct { chol_program *pg; int cap_j, cap_w, cap_e, cap_c;
   int *c_updp, *cnt_updp; /* per separator: update jobs into the block (parent, separator) -- what the followed strips of the parent's rows wait for */
 } pbuild;
@@ -915,6 +919,14 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
     }
   }
   B->bw_of = bw_of;
+  /* stage width of a separator's extend-add sources: a banded leaf factored as one block is handed on in chunks of stage_chunk column
+   * tiles (all its strips publish their column tiles); everything else block by block */
+  int *sw_of = malloc((ns + 1) * sizeof(int));
+  for (int s = 1; s <= ns; s++) {
+    sw_of[s] = bw_of[s];
+    if (band_of[s] && opts->staged && opts->stage_chunk > 0 && opts->stage_chunk * CHOL_NB < p->sep_size[s]) sw_of[s] = opts->stage_chunk * CHOL_NB;
+  }
+  B->sw_of = sw_of;
   /* eligibility: every pivot block fits both fused roles */
   for (int s = 1; s <= ns && !rc; s++) {
     const int bw = bw_of[s];
@@ -932,7 +944,7 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
     }
     if (est > 2.0 * PROG_MAX_TASKS) { chol_set_error("program launch: about %.0f update tasks", est); rc = CHOLAMD_ERR_ARG; }
   }
-  if (rc) { free_skylines(sky, ns); free(bw_of); free(band_of); return rc; }
+  if (rc) { free_skylines(sky, ns); free(bw_of); free(band_of); free(sw_of); return rc; }
   const int follow = opts->follow && opts->cells;
   pg->follow = follow;
   int64_t *first = malloc(p->nblk * sizeof(int64_t));
@@ -954,7 +966,7 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
     for (int st = 0; st < nbk; st++) {
       pblock *b = &pb[s][st];
       b->c0 = st * bw; b->nb = n - b->c0 < bw ? n - b->c0 : bw;
-      b->potrf = -1; b->ch_below = b->ch_par = -1;
+      b->potrf = -1; b->ch_below = b->ch_par = b->ch_rest = -1;
       b->c_prog = new_ctr(P, (b->nb + CHOL_NB - 1) / CHOL_NB);
       b->c_strips = new_ctr(P, 0);
     }
@@ -1051,11 +1063,17 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
           }
         }
         /* the rest: remaining pivot rows, remaining parent rows, every other ancestor */
+        const int t_rest = w->n_trsm;
         if (below - nb1 > 0) push_trsm_run(B, diag, dinv, p->panel_off[s] + (c0 + nb + nb1) + colbase, nb, ld, below - nb1, b->c_prog);
         for (int ha = hp; ha >= 1; ha /= 2) {
           const int anc = p->tree[ha];
           if (BIDX(p, anc, s) < 0) continue;
           push_block_rows(B, p, anc, s, ha == hp ? par_lim : 0, p->sep_size[anc], snap, first, count, diag, dinv, nb, ld, colbase, b->c_prog, -1);
+        }
+        if (sw_of[s] < bw_of[s] && w->n_trsm > t_rest) { /* chunked: these strips publish their column tiles too */
+          b->ns_rest = w->n_trsm - t_rest; b->ch_rest = new_ctr(P, b->ns_rest);
+          for (int e = 1; e < (nb + CHOL_NB - 1) / CHOL_NB; e++) new_ctr(P, b->ns_rest);
+          for (int i = t_rest; i < w->n_trsm; i++) w->trsm[i].chan = b->ch_rest;
         }
         B->cur_band = 0;
         b->n_groups = emit_trsm_jobs(P, B, t0, c_upd[s], cnt_upd[s], b->c_strips, b->ch_par, P->c_updp ? P->c_updp[s] : -1, P->c_updp ? P->cnt_updp[s] : 0, b->ch_below, c_updd[s], cnt_updd[s]);
@@ -1344,14 +1362,25 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
           const chol_block *Bc = &p->blk[w->task[i].blk];
           const int hpar = p->heap_of[Bc->c], dl = level - p->level_of[Bc->c];
           int nsc = 0, capsc = 1;
-          for (int hh = hpar << dl; hh < ((hpar + 1) << dl); hh++) capsc += nblk_of[p->tree[hh]];
+          for (int hh = hpar << dl; hh < ((hpar + 1) << dl); hh++) capsc += nblk_of[p->tree[hh]] + 2 * ((p->sep_size[p->tree[hh]] + CHOL_NB - 1) / CHOL_NB);
           int *sc = malloc(capsc * sizeof(int)), *sn = malloc(capsc * sizeof(int)), *ssep = malloc(capsc * sizeof(int)), *sest = malloc(capsc * sizeof(int));
           for (int hh = hpar << dl; hh < ((hpar + 1) << dl); hh++) {
             const int s = p->tree[hh];
             int through = 0;
             for (int st = 0; st < nblk_of[s]; st++) {
-              through += (pb[s][st].nb + CHOL_NB - 1) / CHOL_NB;
-              if (pb[s][st].n_groups > 0) { sc[nsc] = pb[s][st].c_strips; sn[nsc] = pb[s][st].n_groups; ssep[nsc] = 64 * s + st; sest[nsc] = est_start[s] + through; nsc++; }
+              const pblock *b = &pb[s][st];
+              if (sw_of[s] < bw_of[s] && b->n_groups > 0) { /* chunked (one block): per chunk the channels' last column tile of the chunk */
+                const int nt = (b->nb + CHOL_NB - 1) / CHOL_NB, ct = sw_of[s] / CHOL_NB;
+                for (int c = 0; c * ct < nt; c++) {
+                  const int last = (c + 1) * ct < nt ? (c + 1) * ct - 1 : nt - 1;
+                  if (b->ch_par >= 0) { sc[nsc] = b->ch_par + last; sn[nsc] = b->ns_par; ssep[nsc] = 64 * s + c; sest[nsc] = est_start[s] + last + 1; nsc++; }
+                  if (b->ch_rest >= 0) { sc[nsc] = b->ch_rest + last; sn[nsc] = b->ns_rest; ssep[nsc] = 64 * s + c; sest[nsc] = est_start[s] + last + 1; nsc++; }
+                }
+                through += nt;
+                continue;
+              }
+              through += (b->nb + CHOL_NB - 1) / CHOL_NB;
+              if (b->n_groups > 0) { sc[nsc] = b->c_strips; sn[nsc] = b->n_groups; ssep[nsc] = 64 * s + st; sest[nsc] = est_start[s] + through; nsc++; }
             }
           }
           for (int a = 1; a < nsc; a++) { /* expected order of completion (stable) */
@@ -1381,7 +1410,7 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
   for (int s = 1; s <= ns; s++) { pg->ctr_total[c_upd[s]] = cnt_upd[s]; pg->ctr_total[c_updd[s]] = cnt_updd[s]; if (P->c_updp) pg->ctr_total[P->c_updp[s]] = P->cnt_updp[s]; }
   free(P->c_updp); free(P->cnt_updp); P->c_updp = P->cnt_updp = NULL;
   for (int s = 1; s <= ns; s++) free(pb[s]);
-  free_skylines(sky, ns); free(bw_of); free(band_of);
+  free_skylines(sky, ns); free(bw_of); free(band_of); free(sw_of);
   free(est_start); free(pb); free(nblk_of); free(first); free(count); free(c_upd); free(c_updd); free(cnt_upd); free(cnt_updd); free(snap_upd); free(follow_lim);
   free(B->pend);
   if (rc) { chol_level_work_free(w); chol_program_free(pg); }
