@@ -1407,6 +1407,19 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
   #undef EMIT_POTRF
   if (!rc && w->n_task_mt > 0) { chol_set_error("program launch: macro-tile update phases"); rc = CHOLAMD_ERR_ARG; }
   if (!rc && w->n_task > PROG_MAX_TASKS) { chol_set_error("program launch: %d update tasks", w->n_task); rc = CHOLAMD_ERR_ARG; }
+  if (!rc && getenv("CHOLAMD_DUMP_JOB")) { /* development aid: the tasks and sources of one update job */
+    const int jd = atoi(getenv("CHOLAMD_DUMP_JOB"));
+    if (jd >= 0 && jd < pg->n_job && pg->job[jd].kind == 2) {
+      const chol_job *jb = &pg->job[jd];
+      fprintf(stderr, "job %d: %d tasks, mode %d, %d waits (%d up front)\n", jd, jb->n, jb->mode, jb->n_wait, jb->n_pre);
+      for (int t = jb->first; t < jb->first + jb->n; t++) {
+        const chol_upd_task *tk = &w->task[t];
+        fprintf(stderr, "  task %d: %d x %d, %d sources:", t, tk->mv, tk->nv, tk->src_end - tk->src_begin);
+        for (int q = tk->src_begin; q < tk->src_end; q++) fprintf(stderr, " [k %d stage %d rows %d-%d cols %d-%d]", w->src[q].k, w->src[q].stage, w->src[q].range & 255, (w->src[q].range >> 8) & 255, (w->src[q].range >> 16) & 255, (w->src[q].range >> 24) & 255);
+        fprintf(stderr, "\n");
+      }
+    }
+  }
   for (int s = 1; s <= ns; s++) { pg->ctr_total[c_upd[s]] = cnt_upd[s]; pg->ctr_total[c_updd[s]] = cnt_updd[s]; if (P->c_updp) pg->ctr_total[P->c_updp[s]] = P->cnt_updp[s]; }
   free(P->c_updp); free(P->cnt_updp); P->c_updp = P->cnt_updp = NULL;
   for (int s = 1; s <= ns; s++) free(pb[s]);
@@ -1511,9 +1524,10 @@ int cholamd_plan_program_check(const cholamd_plan *p, int follow, int workers)
   return chol_program_check(p, &o, workers);
 }
 int cholamd_plan_program_check_opts(const cholamd_plan *p, int follow_tail, int split_min, int split_nb, int workers)
-{ /* the same for other follower tails / pivot splits (negative: the default) */
+{ /* the same for other follower tails / pivot splits (negative: the default); the other switches as the environment sets them
+   * (CHOLAMD_NO_SKYLINE, CHOLAMD_STAGE_CHUNK, ...: what a device object created now would use) */
   chol_sched_opts o;
-  chol_sched_opts_default(&o);
+  chol_sched_opts_from_env(&o);
   if (follow_tail >= 0) o.follow_tail = follow_tail;
   if (split_min >= 0) o.split_min = split_min;
   if (split_nb >= 0) o.split_nb = split_nb;

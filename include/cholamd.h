@@ -184,7 +184,8 @@ int cholamd_plan_level_work_volume(const cholamd_plan *p, int level, int rank, i
  * total up; pivot blocks and TRSM rows equal those of the per-level lists.  0 = consistent, otherwise cholamd_last_error()
  * says what is wrong (also when the problem does not qualify for the program launch).  follow: with / without followers. */
 int cholamd_plan_program_check(const cholamd_plan *p, int follow, int workers);
-/* the same with followers under other values of the options "follow_tail", "split_min", "split_nb" (negative: the default) */
+/* the same with followers under other values of the options "follow_tail", "split_min", "split_nb" (negative: the default); the other
+ * switches as the environment sets them at the time of the call */
 int cholamd_plan_program_check_opts(const cholamd_plan *p, int follow_tail, int split_min, int split_nb, int workers);
 int cholamd_plan_program_counts(const cholamd_plan *p, int follow, int out[6]);
 int64_t cholamd_plan_program_jobs(const cholamd_plan *p, int follow, int64_t cap, int *out); /* diagnostic dump of the job queue (scripts/prog_trace.py) */ /* jobs, following POTRF jobs, update tasks, strips, counters, followed panels */
@@ -287,6 +288,10 @@ int cholamd_factor_info(cholamd_device *d, int *sep_out);
  * column block of a split pivot), "staged" (the extend-add jobs of the
  * program launch take their sources pivot block by pivot block as those are solved instead of waiting for all of them;
  * CHOLAMD_NO_STAGED), "fine_upd" (followed strips wait for the update jobs into their own rows' block only; CHOLAMD_NO_FINE_UPD),
+ * "skyline" (program launch: the tile-level skyline of the leaf pivots -- the envelope of A inside the block -- is used: tile updates and
+ * panel tiles left of it are skipped, banded leaves up to 272 columns are factored as one block; CHOLAMD_NO_SKYLINE), "stage_chunk" (such a
+ * leaf's columns reach the extend-add jobs in chunks of this many column tiles; 0 = the whole block at once, the default;
+ * CHOLAMD_STAGE_CHUNK),
  * "super_blocks", "dist_top" (0 / 1 / 2 = automatic: top levels of a partitioned run distributed by column
  * blocks, see Multi-GPU below; CHOLAMD_DIST_TOP).  Rebuilds the work lists. */
 int cholamd_device_set_option(cholamd_device *d, const char *name, int value);

@@ -112,3 +112,21 @@ for sep in sorted(set(int(v) for v in jobs[jobs[:, 0] == 2, 1]), key=lambda s_: 
         d = us[gq]
         line += f"[jobs {gq[0]}-{gq[-1]} n={len(gq)} tasks={int(jobs[gq, 4].sum())} drawn {d[:, 0].min():.0f}-{d[:, 0].max():.0f} start {d[:, 1].min():.0f}-{d[:, 1].max():.0f} end {d[:, 2].min():.0f}-{d[:, 2].max():.0f}] "
     print(line)
+
+# TRACE_WAITS=lo:hi -- per job of the range: every wait (in list order = stage order) with the time its counter was complete
+if os.environ.get("TRACE_WAITS"):
+    lo, hi = (int(v) for v in os.environ["TRACE_WAITS"].split(":"))
+    print("waits per job (counter: value needed, completed at = end of the last job signalling it; channel counters are raised by strips column by column: shown as the strips' end):")
+    chan_jobs = {}
+    for j in range(len(jobs)):
+        if jobs[j, 0] == 1 and jobs[j, 6] >= 0:
+            for t in range(32):
+                chan_jobs.setdefault(int(jobs[j, 6]) + t, []).append(j)
+    for j in range(lo, min(hi, len(jobs))):
+        ws = waits[waits[:, 0] == j]
+        line = f"  job {j} kind {jobs[j, 0]} sep {jobs[j, 1]} aux {jobs[j, 2]} tasks {jobs[j, 4]}: drawn {us[j, 0]:.1f} start {us[j, 1]:.1f} end {us[j, 2]:.1f} |"
+        for _, c, v in ws:
+            js = sig_jobs.get(int(c), []) or chan_jobs.get(int(c), [])
+            t = max((us[q, 2] for q in js), default=-1.0)
+            line += f" c{c}>={v}@{t:.1f}"
+        print(line)

@@ -214,6 +214,8 @@ def _ntiles_table(case):
     {"follow_tail": 0},                                # followers take every column tile of their sources themselves (no early update jobs)
     {"follow_tail": 2},                                # ... only the last two (most of the contribution through early jobs)
     {"follow_tail": 7},
+    {"skyline": 0},                                    # leaf pivots without their skylines: dense POTRF, every leaf split at split_min
+    {"stage_chunk": 4},                                # unsplit banded leaves handed to the extend-add four column tiles at a time
     {"fine_upd": 0},                                   # followed strips that wait for every update job into their panel
     {"staged": 0},                                     # extend-add jobs that wait for every source before they start (no staged waits)
     {"follow": 0, "staged": 1},                        # without followers every contribution goes through (staged) update jobs

@@ -258,6 +258,16 @@ def test_program_launch_is_live_under_follower_tails_and_splits():
     P.program_check_opts(follow_tail=1, split_min=64, split_nb=64, workers=16)
     P.program_check_opts(follow_tail=3, split_min=96, split_nb=96, workers=16)
     P.program_check_opts(split_min=192, split_nb=192, workers=16)
+    # the leaf skylines off (leaves split like every other pivot); unsplit banded leaves handed to the extend-add in chunks of
+    # column tiles (every strip of such a leaf publishes its column tiles): the switches come from the environment
+    for env in ({"CHOLAMD_NO_SKYLINE": "1"}, {"CHOLAMD_STAGE_CHUNK": "4"}, {"CHOLAMD_STAGE_CHUNK": "2"}):
+        os.environ.update(env)
+        try:
+            P.program_check_opts(workers=16)
+            P.program_check_opts(follow_tail=1, workers=64)
+        finally:
+            for k in env:
+                del os.environ[k]
     G = ca.Problem(14, 14, 14, 4, 16).plan()
     for tail in (0, 2, 4):
         G.program_check_opts(follow_tail=tail, workers=16)
