@@ -383,7 +383,7 @@ static int launch_phase(cholamd_device *d, const level_dev &l, const chol_phase 
   else if (ph.kind == 1) HIPCHK((hipError_t)chol_launch_trsm(d_arena, d->ws, l.trsm + ph.first, ph.n, st));
   else if (ph.kind == 4) HIPCHK((hipError_t)chol_launch_trsm_w(d_arena, d->ws, l.trsm + ph.first, ph.n, st));
   else if (ph.kind == 2) HIPCHK((hipError_t)chol_launch_update(d_arena, l.task + ph.first, l.src, ph.n, st));
-  else if (ph.kind == 3) HIPCHK((hipError_t)chol_launch_update_mt(d_arena, l.task_mt + ph.first, l.src, ph.n, st));
+  else if (ph.kind == 3) HIPCHK((hipError_t)chol_launch_update_mt(d_arena, l.task_mt + ph.first, l.src, ph.n, (int64_t)d->plan->arena, st));
   return 0;
 }
 struct cholamd_comm;

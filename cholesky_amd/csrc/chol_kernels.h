@@ -21,7 +21,7 @@ int chol_launch_trsm_big(double *base, const double *ws, const chol_trsm_desc *d
 int chol_launch_dinv(const double *L, int n, int ldl, double *W, hipStream_t st);
 int chol_launch_trsm(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st);
 int chol_launch_update(double *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st);
-int chol_launch_update_mt(double *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st);
+int chol_launch_update_mt(double *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, int64_t arena_elems, hipStream_t st);
 int chol_launch_permute(const double *in, const int *perm, double *out, int n, int inverse, hipStream_t st);
 int chol_launch_solve_dinv(const double *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st);
 int chol_launch_solve_trsv(const double *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, hipStream_t st);

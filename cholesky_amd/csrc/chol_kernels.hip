@@ -344,7 +344,7 @@ __device__ __forceinline__ void mt_chunk(d4 (&acc)[RM][RN], const double *sa, co
 // The chunk sequence runs across the sources of the task (the ring is not drained between sources).  Edge tiles and the last
 // partial chunk of a source (K not a multiple of 16) take the register-staged path (masked loads).
 template <int TM, int TN, int WR, int WC>
-__device__ __forceinline__ void update_mt_body(double *__restrict__ base, const chol_upd_task t, const chol_upd_src *__restrict__ srcs)
+__device__ __forceinline__ void update_mt_body(double *__restrict__ base, const chol_upd_task t, const chol_upd_src *__restrict__ srcs, int64_t arena_elems = 0)
 {
   constexpr int NW = WR * WC, NT = 64 * NW, RM = TM / WR / 16, RN = TN / WC / 16;
   constexpr int QA = MKB * TM / 128 / NW, QB = MKB * TN / 128 / NW; // LDS-DMA instructions per wave, chunk and operand
@@ -361,7 +361,23 @@ __device__ __forceinline__ void update_mt_body(double *__restrict__ base, const 
   for (int i = 0; i < RM; ++i)
 #pragma unroll
     for (int j = 0; j < RN; ++j) acc[i][j] = (d4){ 0.0, 0.0, 0.0, 0.0 };
-  const bool full = t.mv == TM && t.nv == TN;
+  // An edge tile (fewer than TM rows or TN columns: on the generated problems a quarter of the tiles, most of them a row or two short of
+  // 64) takes the DMA path all the same when the rows it does not own are inside the arena (`arena_elems` doubles behind `base`): they
+  // are other panels' data, their products land in accumulator rows / columns that the epilogue does not store
+  bool full = t.mv == TM && t.nv == TN;
+  if (!full && arena_elems > 0) {
+    __shared__ int sOk;
+    if (tt == 0) sOk = 1;
+    __builtin_amdgcn_s_barrier();
+    for (int s = t.src_begin + tt; s < t.src_end; s += NT) {
+      const chol_upd_src sd = srcs[s];
+      const int kf = (sd.k / MKB) * MKB;
+      if (kf > 0 && (sd.a_off + t.ar + (TM - 1) + (int64_t)(kf - 1) * sd.lda >= arena_elems || sd.b_off + t.br + (TN - 1) + (int64_t)(kf - 1) * sd.ldb >= arena_elems)) sOk = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    full = sOk != 0;
+  }
   if (full) {
     // ---- LDS-DMA ring.  Chunk list = the full 16-deep chunks of every source, in order; (is, ik) = next chunk to issue.
     // Instruction q of an operand's chunk moves the doubles [128 q, 128 q + 128) of the [k][rows] image: lane l the pair at 128 q + 2 l.
@@ -466,11 +482,11 @@ __device__ __forceinline__ void update_mt_body(double *__restrict__ base, const 
     }
 }
 __global__ __launch_bounds__(256) void k_update_mt(double *__restrict__ base, const chol_upd_task *__restrict__ tasks,
-                                                   const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd)
+                                                   const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd, int64_t arena_elems)
 {
   const int tid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if ((blockIdx.x >> 3) >= per_xcd || tid >= ntask) return;
-  update_mt_body<MT, MT, 2, 2>(base, tasks[tid], srcs);
+  update_mt_body<MT, MT, 2, 2>(base, tasks[tid], srcs, arena_elems);
 }
 
 // ================================================================================================
@@ -2582,11 +2598,11 @@ int chol_launch_update(double *base, const chol_upd_task *tasks, const chol_upd_
   hipLaunchKernelGGL(k_update, dim3(per_xcd * 8), dim3(256), 0, st, base, tasks, srcs, ntask, per_xcd);
   return (int)hipGetLastError();
 }
-int chol_launch_update_mt(double *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st)
-{
+int chol_launch_update_mt(double *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, int64_t arena_elems, hipStream_t st)
+{ // arena_elems: doubles in the arena behind `base` (0: unknown -- edge tiles then stage their operands through registers)
   if (ntask <= 0) return 0;
   const int per_xcd = (ntask + 7) / 8;
-  hipLaunchKernelGGL(k_update_mt, dim3(per_xcd * 8), dim3(256), 0, st, base, tasks, srcs, ntask, per_xcd);
+  hipLaunchKernelGGL(k_update_mt, dim3(per_xcd * 8), dim3(256), 0, st, base, tasks, srcs, ntask, per_xcd, arena_elems);
   return (int)hipGetLastError();
 }
 int chol_launch_permute(const double *in, const int *perm, double *out, int n, int inverse, hipStream_t st)

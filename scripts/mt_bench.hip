@@ -73,7 +73,7 @@ int main(int argc, char **argv)
   float best = 1e9f;
   for (int rep = 0; rep < 5; rep++) {
     hipEventRecord(e0);
-    if (TSZ == 128) chol_launch_update_mt128(nullptr, dt, ds, (int)tasks.size(), 0); else if (TSZ == 12864) chol_launch_update_mt128x64(nullptr, dt, ds, (int)tasks.size(), 0); else chol_launch_update_mt(nullptr, dt, ds, (int)tasks.size(), 0);
+    if (TSZ == 128) chol_launch_update_mt128(nullptr, dt, ds, (int)tasks.size(), 0); else if (TSZ == 12864) chol_launch_update_mt128x64(nullptr, dt, ds, (int)tasks.size(), 0); else chol_launch_update_mt(nullptr, dt, ds, (int)tasks.size(), 0, 0);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
