@@ -250,6 +250,7 @@ extern "C" int cholamd_device_set_option(cholamd_device *d, const char *name, in
   else if (n == "staged") d->opt.staged = value != 0;
   else if (n == "fine_upd") d->opt.fine_upd = value != 0;
   else if (n == "skyline") d->opt.skyline = value != 0;
+  else if (n == "trsm_wt_min") d->opt.trsm_wt_min = value < 0 ? 0 : value;
   else if (n == "stage_chunk") d->opt.stage_chunk = value < 0 ? 0 : value;
   else if (n == "dist_top") d->opt.dist_top = value;
   else if (n == "solve_reference_shape") { d->solve_reference_shape = value != 0; rebuild = false; }
@@ -382,6 +383,7 @@ static int launch_phase(cholamd_device *d, const level_dev &l, const chol_phase 
   } else if (ph.kind == 0) HIPCHK((hipError_t)chol_launch_potrf(d_arena, d->ws, l.potrf + ph.first, ph.n, d->info, st));
   else if (ph.kind == 1) HIPCHK((hipError_t)chol_launch_trsm(d_arena, d->ws, l.trsm + ph.first, ph.n, st));
   else if (ph.kind == 4) HIPCHK((hipError_t)chol_launch_trsm_w(d_arena, d->ws, l.trsm + ph.first, ph.n, st));
+  else if (ph.kind == 7) HIPCHK((hipError_t)chol_launch_trsm_wt(d_arena, d->ws, l.trsm + ph.first, ph.n, st));
   else if (ph.kind == 2) HIPCHK((hipError_t)chol_launch_update(d_arena, l.task + ph.first, l.src, ph.n, st));
   else if (ph.kind == 3) HIPCHK((hipError_t)chol_launch_update_mt(d_arena, l.task_mt + ph.first, l.src, ph.n, (int64_t)d->plan->arena, st));
   return 0;
@@ -404,7 +406,7 @@ static int factor_levels_comm(cholamd_device *d, double *d_arena, int level_hi, 
         if (rc) return rc;
         continue;
       }
-      scoped_timer t(d, st, ph.kind == 3 ? 2 : ph.kind == 4 ? 1 : ph.kind == 5 ? 0 : ph.kind, ph.n > 0);
+      scoped_timer t(d, st, ph.kind == 3 ? 2 : (ph.kind == 4 || ph.kind == 7) ? 1 : ph.kind == 5 ? 0 : ph.kind, ph.n > 0);
       int rc = launch_phase(d, l, ph, d_arena, st);
       if (rc) return rc;
     }

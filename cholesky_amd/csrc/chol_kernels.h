@@ -17,6 +17,7 @@ int chol_launch_program(double *base, double *ws, const chol_job *jobs, int njob
                         const chol_upd_task *tasks, const chol_upd_src *srcs, const chol_ext *exts, int *ctr, const int *ctr_total, int epoch, int *head, int head_base,
                         int grid, int *info, unsigned long long *trace, hipStream_t st);
 int chol_launch_trsm_w(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st);
+int chol_launch_trsm_wt(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st);
 int chol_launch_trsm_big(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st);
 int chol_launch_dinv(const double *L, int n, int ldl, double *W, hipStream_t st);
 int chol_launch_trsm(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st);

@@ -1897,7 +1897,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ bas
 // ------------------------------------------------------------------------------------------------
 #define TW_MAXT ((CHOL_TRSM_W_MAXN + TS - 1) / TS)
 // the solve of one strip of T tiles: tiles in registers, operands out of the staged LDS image (s0 = slot 0 + lane)
-template <int T> __device__ __forceinline__ void trsm_w_solve(d4 (&tile)[TW_MAXT], const double *s0, double *__restrict__ B, int n, int ldb,
+template <int T, int NT> __device__ __forceinline__ void trsm_w_solve(d4 (&tile)[NT], const double *s0, double *__restrict__ B, int n, int ldb,
                                                               bool vrow, int r15, int g)
 {
 #pragma unroll
@@ -2026,6 +2026,102 @@ __global__ __launch_bounds__(256) void k_trsm_w(double *__restrict__ base, const
   }
   STAMP(4);
   if (blockIdx.x == 0 && wave == 0) { STAMP_FLUSH; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TRSM, throughput form (level schedule, steps with thousands of strips: the wide fronts of the generated problems): the same
+// one-wave-per-strip solve for pivot blocks up to CHOL_TRSM_WT_MAXN = 144 columns, TWELVE strips per 768-thread workgroup (168 registers a wave: the nine column tiles of a strip stay in registers) sharing
+// one staged image of the block (45 L tiles + 9 inverses = 92 KB of LDS).  No barrier after the staging, no LDS traffic but operand
+// reads: twelve independent MFMA chains per CU keep the matrix pipe busy, where the fused launch's four-waves-per-strip solve is a
+// latency design (three strips per CU at a time, a barrier per column tile): 20 000 strips of a 60^3 front step take 6 800
+// workgroups x 20 us there.  The POTRF of such a step is launched on its own ahead of this kernel.
+// ------------------------------------------------------------------------------------------------
+#define TT_MAXT ((CHOL_TRSM_WT_MAXN + TS - 1) / TS)
+#define TT_WAVES CHOL_TRSM_WT_GROUP
+__global__ __launch_bounds__(64 * TT_WAVES) void k_trsm_wt(double *__restrict__ base, const double *__restrict__ ws,
+                                                           const chol_trsm_desc *__restrict__ descs, int ndesc)
+{
+  __shared__ double sT[TT_MAXT * (TT_MAXT + 1) / 2][TS * TS]; // slots as in k_trsm_w
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int id0 = blockIdx.x * TT_WAVES;
+  const chol_trsm_desc d0 = descs[id0];
+  const double *Lm = base + d0.l_off;
+  const double *W = ws + d0.dinv_off;
+  const int n = d0.n, ldl = d0.ldl;
+  const int T = (n + TS - 1) / TS;
+  const int r15 = lane & 15, g = lane >> 4, lp = lane;
+  int64_t b_off = d0.b_off;
+  int m = 0, ldb = d0.ldb;
+  if (id0 + wave < ndesc) {
+    const chol_trsm_desc d = descs[id0 + wave];
+    b_off = d.b_off; m = d.m; ldb = d.ldb;
+  }
+  double *B = base + b_off;
+  const bool vrow = r15 < m;
+  // the LDS-DMA pairs rows (r, r + 1): with n odd the pair (n - 1, n) is fetched from (n - 2, n - 1) and row n - 1 of the last row
+  // tile is patched afterwards from this register (k_trsm_w)
+  const bool needfix = (n & 1) && tid < TS * (T - 1);
+  double fix = 0.0;
+  if (needfix) fix = Lm[(n - 1) + (int64_t)tid * ldl];
+  { // stage: half-tile h = 2 slot + half goes to wave h mod 16
+    const int nslots = T * (T + 1) / 2;
+    for (int h = wave; h < 2 * nslots; h += TT_WAVES) {
+      const int slot = h >> 1, half = h & 1;
+      int J = 0, rem = slot;
+      while (rem >= T - J) { rem -= T - J; ++J; }
+      const int J2 = J + rem;
+      const int pi = half * 64 + lane; // element pair (2 pi, 2 pi + 1) of the tile image
+      const int st = pi >> 5, gg = (pi >> 3) & 3, re = (pi & 7) * 2;
+      const double *src;
+      if (J2 == J) src = W + (int64_t)J * TS * TS + 2 * pi;
+      else {
+        const int row = J2 * TS + re;
+        src = Lm + (row + 1 < n ? row : n - 2) + (int64_t)(J * TS + 4 * st + gg) * ldl;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)&sT[slot][half * 128], 16, 0, 0);
+    }
+  }
+  d4 tile[TT_MAXT];
+  {
+    const int rb = min(r15, max(m - 1, 0));
+#pragma unroll
+    for (int J = 0; J < TT_MAXT; ++J) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tile[J][q] = B[rb + (int64_t)min(J * TS + g + 4 * q, n - 1) * ldb];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads(); // every wave's LDS-DMA has landed
+  if (needfix) {
+    const int J = tid >> 4, c = tid & 15, rr = (n - 1) & 15;
+    sT[J * T - J * (J - 1) / 2 + (T - 1 - J)][(c >> 2) * 64 + (c & 3) * TS + rr] = fix;
+  }
+  __syncthreads();
+  if (m <= 0) return;
+#pragma unroll
+  for (int J = 0; J < TT_MAXT; ++J) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double v = tile[J][q];
+      asm volatile("" : "+v"(v));
+      tile[J][q] = (vrow && J * TS + g + 4 * q < n) ? v : 0.0;
+    }
+  }
+  const double *const s0 = &sT[0][lp];
+  switch (T) {
+  case 1: trsm_w_solve<1>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  case 2: trsm_w_solve<2>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  case 3: trsm_w_solve<3>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  case 4: trsm_w_solve<4>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  case 5: trsm_w_solve<5>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  case 6: trsm_w_solve<6>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  case 7: trsm_w_solve<7>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  case 8: trsm_w_solve<8>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  case 9: trsm_w_solve<9>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  default: break;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2583,6 +2679,12 @@ int chol_launch_trsm_w(double *base, const double *ws, const chol_trsm_desc *des
 { // strips of pivot blocks up to CHOL_TRSM_W_MAXN columns, one wave each; every aligned group of four descriptors shares one block
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k_trsm_w, dim3((n + 3) / 4), dim3(256), 0, st, base, ws, descs, n);
+  return (int)hipGetLastError();
+}
+int chol_launch_trsm_wt(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st)
+{ // strips of pivot blocks up to CHOL_TRSM_WT_MAXN columns, one wave each; every aligned group of CHOL_TRSM_WT_GROUP descriptors shares one block
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_trsm_wt, dim3((n + TT_WAVES - 1) / TT_WAVES), dim3(64 * TT_WAVES), 0, st, base, ws, descs, n);
   return (int)hipGetLastError();
 }
 int chol_launch_trsm_big(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st)

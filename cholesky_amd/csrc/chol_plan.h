@@ -68,6 +68,9 @@ typedef struct {
 } chol_trsm_desc;
 
 #define CHOL_TRSM_W_MAXN 64 /* widest pivot block the one-wave-per-strip TRSM kernel takes (4 tiles); measured against k_trsm_rr: 6.6 vs 8.0 us at 32, 8.4 vs 9.6 at 64, 12.6 vs 11.1 at 128 */
+#define CHOL_TRSM_WT_MAXN 144 /* widest pivot block of the throughput TRSM kernel (k_trsm_wt: one wave per strip, 12 strips per workgroup sharing the block's LDS image) */
+#define CHOL_TRSM_WT_GROUP 12
+#define CHOL_TRSM_WT_MIN 2048 /* strips (estimated from the panel heights) from which a step of the level schedule solves them with k_trsm_wt after a POTRF launch of its own */
 #define CHOL_FUSE_MAXN 192 /* widest pivot block of a fused POTRF+TRSM launch (12 column tiles: three per wave of a strip) */
 #define CHOL_FUSE_UPDATE_MAX 0 /* most 16x16 update tasks a fused launch carries (chol_schedule.c); measured on lapl_3375: 0/64/256 within noise (227 us), 900 -> 239, all -> 248: the role exists, a launch of its own is as fast */
 #define CHOL_TRSM_ROWS 16
@@ -125,7 +128,7 @@ typedef struct {
 
 /* one batched launch: descriptors [first, first + n) of the level's array of that kind */
 typedef struct {
-  int kind;  /* 0 potrf, 1 trsm, 2 update (16x16 tasks), 3 update (64x64 macro-tile tasks), 4 trsm (every strip's pivot block <= CHOL_TRSM_W_MAXN wide),
+  int kind;  /* 0 potrf, 1 trsm, 2 update (16x16 tasks), 3 update (64x64 macro-tile tasks), 4 trsm (every strip's pivot block <= CHOL_TRSM_W_MAXN wide), 7 trsm (throughput form, k_trsm_wt),
               * 5 fused potrf (first, n) + trsm (first2, n2) + 16x16 update tasks (first3, n3) */
   int first, n, first2, n2, first3, n3;
 } chol_phase;
@@ -141,6 +144,7 @@ typedef struct {
   int fuse;                 /* POTRF + TRSM of a column-block step in one launch */
   int fuse_update_max;      /* most 16x16 update tasks such a launch carries */
   int mt_min_tiles;
+  int trsm_wt_min;          /* level schedule: steps with at least this many TRSM strips take the throughput TRSM (0: never) */
   int cells;                /* extend-add of small phases by 16x16 grid cells of the target blocks */
   int program;              /* small problems: the whole factorisation as one launch (chol_build_program) */
   int follow;               /* ... in which pivot blocks follow their children's / predecessor's TRSM strips */

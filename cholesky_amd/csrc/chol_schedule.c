@@ -88,7 +88,7 @@ static int env_int(const char *name, int dflt) { const char *e = getenv(name); r
 void chol_sched_opts_default(chol_sched_opts *o)
 {
   o->split_min = CHOL_SPLIT_MIN; o->split_nb = CHOL_SPLIT_NB; o->fuse = 1; o->fuse_update_max = CHOL_FUSE_UPDATE_MAX;
-  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL; o->follow_tail_split = CHOL_FOLLOW_TAIL; o->staged = 1; o->fine_upd = 1; o->skyline = 1; o->stage_chunk = CHOL_STAGE_CHUNK;
+  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->trsm_wt_min = CHOL_TRSM_WT_MIN; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL; o->follow_tail_split = CHOL_FOLLOW_TAIL; o->staged = 1; o->fine_upd = 1; o->skyline = 1; o->stage_chunk = CHOL_STAGE_CHUNK;
 }
 void chol_sched_opts_from_env(chol_sched_opts *o)
 {
@@ -98,6 +98,7 @@ void chol_sched_opts_from_env(chol_sched_opts *o)
   o->fuse = !env_int("CHOLAMD_NO_FUSE", 0);
   o->fuse_update_max = env_int("CHOLAMD_FUSE_UPDATE_MAX", o->fuse_update_max);
   o->mt_min_tiles = env_int("CHOLAMD_MT_MIN_TILES", o->mt_min_tiles);
+  o->trsm_wt_min = env_int("CHOLAMD_TRSM_WT_MIN", o->trsm_wt_min);
   o->cells = !env_int("CHOLAMD_NO_CELLS", 0);
   o->program = !env_int("CHOLAMD_NO_PROGRAM", 0);
   o->follow = !env_int("CHOLAMD_NO_FOLLOW", 0);
@@ -420,6 +421,20 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
    * alike), rank-nb update of the remaining columns of those rows */
   for (int st = 0; st < steps; st++) {
     const int p0 = w->n_potrf, t0 = w->n_trsm, k0 = w->n_task, km0 = w->n_task_mt, b0 = w->n_bcast;
+    /* a step with thousands of strips (the wide fronts of a large problem) is a throughput problem: POTRF launch, then the
+     * one-wave-per-strip TRSM with twelve strips per workgroup, instead of the fused launch's latency design */
+    int thru = 0;
+    if (fuse && !dist && opts->trsm_wt_min > 0) {
+      int64_t est = 0; int fits = 1;
+      for (int q = 0; q < nh; q++) {
+        const int s = p->tree[hs[q]], n = p->sep_size[s], bw = pivot_block_width(opts, n), c0 = st * bw;
+        if (c0 >= n) continue;
+        const int nb = n - c0 < bw ? n - c0 : bw;
+        if (nb > CHOL_TRSM_WT_MAXN) fits = 0;
+        est += (p->panel_rows[s] - c0 - nb + CHOL_TRSM_ROWS - 1) / CHOL_TRSM_ROWS;
+      }
+      thru = fits && est >= opts->trsm_wt_min;
+    }
     for (int q = 0; q < nh; q++) {
       const int h = hs[q], s = p->tree[h], n = p->sep_size[s], ld = p->panel_ld[s];
       const int bw = pivot_block_width(opts, n);
@@ -444,7 +459,8 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
         const int flag = w->n_potrf - 1 - p0; /* this block's POTRF descriptor within the step */
         if (below > 0) push_trsm_run(B, diag, dinv, p->panel_off[s] + (c0 + nb) + colbase, nb, ld, below, flag);
         for (int r = 0; r < nr; r++) push_trsm_run(B, diag, dinv, runs[r].off + colbase, nb, ld, runs[r].m, flag);
-        if (fuse) pad_trsm_group(B, t0, 3, diag, dinv, diag, nb, ld, flag);
+        if (thru) pad_trsm_group(B, t0, CHOL_TRSM_WT_GROUP, diag, dinv, diag, nb, ld, flag);
+        else if (fuse) pad_trsm_group(B, t0, 3, diag, dinv, diag, nb, ld, flag);
         else if (nb <= CHOL_TRSM_W_MAXN) pad_trsm_group(B, t0, 4, diag, dinv, diag, nb, ld, flag);
       }
       if (below > 0) {
@@ -512,7 +528,12 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
       push_phase(B, 3, km0, w->n_task_mt - km0);
       continue;
     }
-    if (fuse) { /* one launch: the strips follow their pivot's POTRF column by column, the 16x16 update tasks of the
+    if (thru) {
+      push_phase(B, 0, p0, w->n_potrf - p0);
+      push_phase(B, 7, t0, w->n_trsm - t0);
+      push_phase(B, 2, k0, w->n_task - k0);
+      fused_last = -1;
+    } else if (fuse) { /* one launch: the strips follow their pivot's POTRF column by column, the 16x16 update tasks of the
                  * step (trailing columns of a split pivot) wait for the strips inside the same launch */
       if (w->n_phase == B->cap_ph) { B->cap_ph = B->cap_ph ? 2 * B->cap_ph : 16; w->phase = realloc(w->phase, B->cap_ph * sizeof(chol_phase)); }
       const int ride = w->n_task - k0 <= opts->fuse_update_max;

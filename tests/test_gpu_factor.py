@@ -222,6 +222,8 @@ def _ntiles_table(case):
     {"split_min": 96, "split_nb": 96, "follow_tail": 1}, # three / four column blocks per leaf: chains of followers with early jobs
     {"program": 0},                                    # level by level: fused POTRF+TRSM launches + update launches
     {"program": 0, "fuse": 0},                         # separate POTRF / TRSM launches (k_potrf_rr, k_trsm_rr, k_trsm_w)
+    {"program": 0, "trsm_wt_min": 1},                  # every step's strips through the throughput TRSM (k_trsm_wt, after a POTRF launch of its own)
+    {"program": 0, "trsm_wt_min": 1, "split_min": 64, "split_nb": 48}, # ... with three-tile pivot blocks
     {"program": 0, "fuse_update_max": 100000},         # update tasks inside the fused launch
     {"program": 0, "split_min": 272, "split_nb": 256}, # pivots factored whole (k_potrf_rr up to 17 tiles)
     {"split_min": 64, "split_nb": 64},                 # many column-block steps per pivot (program: chains of followers)

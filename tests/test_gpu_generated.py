@@ -57,6 +57,28 @@ def test_generated_problem_matches_oracle(dims, tmp_path):
     assert np.abs(x - xo).max() <= 1e-9 * max(1.0, np.abs(xo).max())
 
 
+@pytest.mark.parametrize("dims", [(18, 18, 18, 3, 48), (24, 24, 12, 2, 64), (12, 12, 12, 4, 16)])
+def test_throughput_trsm_matches_the_fused_path(dims):
+    """Level schedule with every step's strips through k_trsm_wt (option trsm_wt_min = 1: POTRF launch, then one wave per strip,
+    twelve strips per workgroup sharing the pivot block's LDS image) against the default fused launches: the same factor."""
+    import cholesky_amd as ca
+    prob = ca.Problem(*dims)
+    plan = prob.plan()
+    res = []
+    for wt in (0, 1):
+        dev = ca.Device(plan, 0)
+        dev.set_option("program", 0)
+        dev.set_option("trsm_wt_min", wt)
+        arena = dev.new_arena()
+        dev.fill(arena)
+        dev.factor(arena)
+        dev.sync()
+        assert dev.info() == (0, 0)
+        res.append(np.tril(plan.arena_to_dense(arena.cpu().numpy())))
+    scale = np.abs(res[0]).max()
+    assert np.abs(res[0] - res[1]).max() <= 1e-12 * scale
+
+
 def test_big_pivot_info_is_pivot_relative():
     """A non-positive pivot inside a later 256-column block of a big pivot reports its column within the pivot."""
     import torch
