@@ -288,6 +288,8 @@ int cholamd_factor_info(cholamd_device *d, int *sep_out);
  * column block of a split pivot), "staged" (the extend-add jobs of the
  * program launch take their sources pivot block by pivot block as those are solved instead of waiting for all of them;
  * CHOLAMD_NO_STAGED), "fine_upd" (followed strips wait for the update jobs into their own rows' block only; CHOLAMD_NO_FINE_UPD),
+ * "trsm_wt_min" (level schedule: a column-block step with at least this many TRSM strips launches its POTRFs on their own and solves
+ * the strips with the throughput kernel, one wave per strip; 0 = never; CHOLAMD_TRSM_WT_MIN),
  * "skyline" (program launch: the tile-level skyline of the leaf pivots -- the envelope of A inside the block -- is used: tile updates and
  * panel tiles left of it are skipped, banded leaves up to 272 columns are factored as one block; CHOLAMD_NO_SKYLINE), "stage_chunk" (such a
  * leaf's columns reach the extend-add jobs in chunks of this many column tiles; 0 = the whole block at once, the default;
