@@ -296,6 +296,17 @@ __device__ __forceinline__ void lds_dma16(const double *g, double *lds)
 #endif
 /* MT_STAGES: LDS ring of the full-tile path: stages of one 16-deep chunk of both operands */
 #define MT_SRC_BATCH 32 /* source descriptors held in LDS at a time */
+/* timing diagnostics of scripts/mt_bench.hip (wrong results): -DMT_NODMA leaves the operand transfers out, -DMT_NOBAR the ring's barriers */
+#ifdef MT_NODMA
+#define MT_DIAG_DMA(x_) ((void)0)
+#else
+#define MT_DIAG_DMA(x_) x_
+#endif
+#ifdef MT_NOBAR
+#define MT_DIAG_BAR(x_) ((void)0)
+#else
+#define MT_DIAG_BAR(x_) x_
+#endif
 // One macro tile of TM x TN per workgroup of WR x WC waves, each wave a (TM / WR) x (TN / WC) block of 16x16 accumulators.
 //   64 x 64, 2 x 2 waves (k_update_mt): 2 x 2 accumulators per wave, 8 flop per byte staged into LDS.
 //   Measured against it (scripts/mt_bench.hip 8192^2 SYRK, TF/s at K = 144 / 432 / 512): 128 x 128 tiles, 4 x 2 waves of
@@ -401,11 +412,11 @@ __device__ __forceinline__ void update_mt_body(double *__restrict__ base, const 
         const int st_ = issued % MT_STAGES;                                                                           \
         _Pragma("unroll") for (int pp = 0; pp < QA; ++pp) {                                                           \
           const int e_ = 128 * (QA * wave + pp) + 2 * lane;                                                           \
-          lds_dma16(base + ao_ + t.ar + e_ % TM + (int64_t)(ik + e_ / TM) * lda_, &sA[st_][0][0] + 128 * (QA * wave + pp)); \
+          MT_DIAG_DMA(lds_dma16(base + ao_ + t.ar + e_ % TM + (int64_t)(ik + e_ / TM) * lda_, &sA[st_][0][0] + 128 * (QA * wave + pp))); \
         }                                                                                                             \
         _Pragma("unroll") for (int pp = 0; pp < QB; ++pp) {                                                           \
           const int e_ = 128 * (QB * wave + pp) + 2 * lane;                                                           \
-          lds_dma16(base + bo_ + t.br + e_ % TN + (int64_t)(ik + e_ / TN) * ldb_, &sB[st_][0][0] + 128 * (QB * wave + pp)); \
+          MT_DIAG_DMA(lds_dma16(base + bo_ + t.br + e_ % TN + (int64_t)(ik + e_ / TN) * ldb_, &sB[st_][0][0] + 128 * (QB * wave + pp))); \
         }                                                                                                             \
         ++issued; ik += MKB;                                                                                          \
       }
@@ -414,7 +425,7 @@ __device__ __forceinline__ void update_mt_body(double *__restrict__ base, const 
         // this wave's DMA instructions of chunk c have landed when at most the later chunks' remain outstanding
         if (issued - c - 1 >= MT_STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((QA + QB) * (MT_STAGES - 2)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier(); // every wave's part of chunk c is in LDS; every wave has left chunk c - 1
+        MT_DIAG_BAR(__builtin_amdgcn_s_barrier()); // every wave's part of chunk c is in LDS; every wave has left chunk c - 1
         if (issued < total) MT_ISSUE(); // into the stage chunk c - 1 occupied
         mt_chunk<TM, TN, RM, RN>(acc, &sA[c % MT_STAGES][0][0], &sB[c % MT_STAGES][0][0], g, xo, yo);
       }
