@@ -37,6 +37,7 @@ CASES = {
     "lapl_3375x3375": ("lapl_15_3.mtx", "lapl_15_3_ord_5.txt", "lapl_15_3_clust_5.txt"),
 }
 PEAK_FP64_TFLOPS = 78.6   # MI355X dense fp64 (vector = matrix) peak, public spec; the microarch guide lists no fp64 row
+SUSTAINED_FP64_MFMA_TFLOPS = 50.0  # measured on this pool (scripts/mfma_peak.hip, profiles/r2/mfma_peak.txt): v_mfma_f64_16x16x4_f64 out of registers, 16 waves per CU, 54 ms: 48-50 TF/s
 PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = the fp32 vector rate
 PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r2", "summary.json")  # scripts/profile_summary.py over the rocprofv3 passes of this command
@@ -377,6 +378,8 @@ def main():
                          "launches_per_step": launches_per_factor,
                          "alg_flops_per_launch": flops_per_launch,
                          "whole_step_frac_of_peak": round(value * 1e-3 / peak, 6),
+                         "fp64_mfma_sustained_measured": None if mixed else SUSTAINED_FP64_MFMA_TFLOPS,
+                         "fp64_mfma_sustained_note": None if mixed else "what a register-operand v_mfma_f64_16x16x4_f64 loop on all 256 CUs sustains here (scripts/mfma_peak.hip; profiles/r2/mfma_peak.txt): 64 % of `peak`; `frac` stays against `peak`",
                          "whole_step_alg_GBs": round(plan.alg_bytes * K / dt * 1e-9, 3), "hbm_peak_GBs": PEAK_HBM_GBS,
                          "kernel_ms_per_step_events_raw": {k: round(timing[k][0] / reps, 5) for k in ("potrf", "trsm", "update", "other")},
                          "launch_structure": "one program launch per factorisation (resident workgroups, job queue, followers)" if program else "per level and column-block step: fused POTRF+TRSM launch + update launch(es)"},
