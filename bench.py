@@ -37,7 +37,7 @@ CASES = {
     "lapl_3375x3375": ("lapl_15_3.mtx", "lapl_15_3_ord_5.txt", "lapl_15_3_clust_5.txt"),
 }
 PEAK_FP64_TFLOPS = 78.6   # MI355X dense fp64 (vector = matrix) peak, public spec; the microarch guide lists no fp64 row
-SUSTAINED_FP64_MFMA_TFLOPS = 50.0  # measured on this pool (scripts/mfma_peak.hip, profiles/r2/mfma_peak.txt): v_mfma_f64_16x16x4_f64 out of registers, 16 waves per CU, 54 ms: 48-50 TF/s
+SUSTAINED_FP64_MFMA_TFLOPS = 50.0  # measured on this pool (scripts/mfma_peak.hip, profiles/r2/mfma_peak.txt): v_mfma_f64_16x16x4_f64 out of registers, 16 waves per CU, 54 ms: 48-50 TF/s (the f32 loop of the same script reaches 147-156 of 157.3: not a clock limit)
 PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = the fp32 vector rate
 PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r2", "summary.json")  # scripts/profile_summary.py over the rocprofv3 passes of this command

@@ -32,6 +32,20 @@ __global__ __launch_bounds__(256) void k_peak8(double *out, int iters, double a0
   out[blockIdx.x * 256 + threadIdx.x] = sum;
   if (blockIdx.x == 0 && threadIdx.x == 0) clk[0] = t1 - t0;
 }
+typedef float f16v __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void k_peak32(float *out, int iters, float a0)
+{ // v_mfma_f32_32x32x2_f32: 4096 flop each, four accumulators per wave
+  f16v c0, c1, c2, c3;
+  for (int q = 0; q < 16; ++q) { c0[q] = 0.f; c1[q] = 0.f; c2[q] = 0.f; c3[q] = 0.f; }
+  float a = a0 + threadIdx.x * 1e-6f, b = 1.0f - a;
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, b, c3, 0, 0, 0);
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+}
 int main(int argc, char **argv)
 {
   const int wgs = argc > 1 ? atoi(argv[1]) : 1024 * 4, iters = argc > 2 ? atoi(argv[2]) : 20000;
@@ -44,6 +58,14 @@ int main(int argc, char **argv)
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double flops = (double)wgs * 4 * iters * 4 * 2048.0;
     printf("%d workgroups x 4 waves x %d x 4 MFMA: %.3f ms, %.1f TF/s fp64\n", wgs, iters, ms, flops / ms * 1e-9);
+  }
+  for (int rep = 0; rep < 2; rep++) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_peak32, dim3(wgs), dim3(256), 0, 0, (float *)d, iters, 0.25f);
+    hipEventRecord(e1); hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)wgs * 4 * iters * 4 * 4096.0;
+    printf("fp32 v_mfma_f32_32x32x2_f32, 4 accumulators: %.3f ms, %.1f TF/s\n", ms, flops / ms * 1e-9);
   }
   unsigned long long *dc; hipMalloc(&dc, 8);
   for (int rep = 0; rep < 2; rep++) {
