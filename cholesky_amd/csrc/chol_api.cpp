@@ -622,7 +622,7 @@ extern "C" int cholamd_factor_levels_f32(cholamd_device *d, float *d_arena32, in
       if (ph.kind == 0) HIPCHK((hipError_t)chol32_launch_potrf(d_arena32, d->ws32, l.potrf + ph.first, ph.n, d->info, st));
       else if (ph.kind == 1 || ph.kind == 4) HIPCHK((hipError_t)chol32_launch_trsm(d_arena32, d->ws32, l.trsm + ph.first, ph.n, st));
       else if (ph.kind == 2) HIPCHK((hipError_t)chol32_launch_update(d_arena32, l.task + ph.first, l.src, ph.n, st));
-      else if (ph.kind == 3) HIPCHK((hipError_t)chol32_launch_update_mt(d_arena32, l.task_mt + ph.first, l.src, ph.n, st));
+      else if (ph.kind == 3) HIPCHK((hipError_t)chol32_launch_update_mt(d_arena32, l.task_mt + ph.first, l.src, ph.n, (int64_t)d->plan->arena, st));
       else { chol_set_error("internal: phase kind %d in the fp32 schedule", ph.kind); return CHOLAMD_ERR_ARG; }
     }
   }

@@ -252,74 +252,175 @@ __global__ __launch_bounds__(256) void k32_update(float *__restrict__ base, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// UPDATE, macro tiles: one workgroup per 64x64 block of a target, the four waves own its 32x32 quadrants, one
-// v_mfma_f32_32x32x2 accumulator (16 registers) each.  Source panels staged through LDS in 16-deep K chunks ([k][row]
-// images: an operand read is 32 consecutive floats per k), double buffered, the next chunk's global loads in flight
-// during the MFMAs.  32x32x2 maps: lane l supplies A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31]; result register i
-// of lane l is D[(i & 3) + 8 (i >> 2) + 4 (l >> 5)][l & 31]; with Y as "A" and X as "B": row = l & 31, column = that.
+// UPDATE, macro tiles: one workgroup of four waves per 64x64 block of a target, every wave a 32x32 quadrant = 2 x 2 accumulators of
+// v_mfma_f32_16x16x4_f32.  Source panels go through LDS as [k][row] images in 16-deep chunks: by LDS-DMA (global_load_lds_dwordx4,
+// 1 KiB per wave instruction = four k-rows of 64 floats, no registers) into a ring of M32_STAGES stages behind a counted vmcnt, the
+// chunk sequence running across the sources of the task -- the structure of the fp64 k_update_mt; 8 KB of LDS and ~60 registers let
+// eight workgroups share a CU.  An edge tile takes the DMA path too when the rows it does not own lie inside the arena (their
+// products are neither computed -- 16-blocks outside the tile are skipped -- nor stored); otherwise, and for the K tails (K mod 16),
+// masked loads through registers.  Same task / source lists as the fp64 kernel, same program-order accumulation.
+// (Round 2's first version staged 4-byte loads through registers into one 32x32x2 accumulator per wave: 67 TF/s on the 100^3 task
+// lists.  A 128x128 tile -- 87 TF/s on one big SYRK -- lost on them: a third of the flops sit in partial tiles there.)
 // ------------------------------------------------------------------------------------------------
-#define MT 64
-#define MKB 16
-__global__ __launch_bounds__(256) void k32_update_mt(float *__restrict__ base, const chol_upd_task *__restrict__ tasks, const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd)
+#define M32 64
+#define M32_KB 16
+#ifndef M32_STAGES
+#define M32_STAGES 2
+#endif
+#define M32_SRC_BATCH 32
+__device__ __forceinline__ void lds_dma16_f32(const float *g, float *lds)
+{ // lane l's 16 bytes at g land at lds + 16 l bytes; M0 saved and restored inside the statement (see lds_dma16, chol_kernels.hip)
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
+// one 16-deep chunk out of the LDS images into the wave's 2 x 2 accumulators; the operands of k-step kk + 1 are requested before the
+// MFMAs of k-step kk are issued.  ni / nj: 16-row / 16-column blocks of the quadrant inside the tile (wave uniform)
+__device__ __forceinline__ void m32_chunk(f4 (&acc)[2][2], const float *sa, const float *sb, int g, int xo, int yo, int ni, int nj)
 {
-  __shared__ float sA[2][MKB][MT];
-  __shared__ float sB[2][MKB][MT];
+  float x[2], y[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { x[i] = sa[g * M32 + xo + 16 * i]; y[i] = sb[g * M32 + yo + 16 * i]; }
+#pragma unroll
+  for (int kk = 0; kk < M32_KB / 4; ++kk) {
+    float nx[2] = { 0.f, 0.f }, ny[2] = { 0.f, 0.f };
+    if (kk + 1 < M32_KB / 4) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { nx[i] = sa[(4 * (kk + 1) + g) * M32 + xo + 16 * i]; ny[i] = sb[(4 * (kk + 1) + g) * M32 + yo + 16 * i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (i < ni && j < nj) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[j], x[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { x[i] = nx[i]; y[i] = ny[i]; }
+  }
+}
+__global__ __launch_bounds__(256) void k32_update_mt(float *__restrict__ base, const chol_upd_task *__restrict__ tasks, const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd, int64_t arena_elems)
+{
+  __shared__ float sA[M32_STAGES][M32_KB][M32];
+  __shared__ float sB[M32_STAGES][M32_KB][M32];
+  __shared__ chol_upd_src sS[M32_SRC_BATCH];
+  __shared__ int sOk;
   const int tt = threadIdx.x, lane = tt & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tt >> 6);
   const int tid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= per_xcd || tid >= ntask) return;
   const chol_upd_task t = tasks[tid];
-  const int l31 = lane & 31, h = lane >> 5;
+  const int r15 = lane & 15, g = lane >> 4;
   const int wr = wave & 1, wc = wave >> 1;
-  const int srow = tt & 63, skq = tt >> 6;
-  const bool sva = srow < t.mv, svb = srow < t.nv;
-  f16 acc;
+  const int xo = 32 * wr + r15, yo = 32 * wc + r15;
+  f4 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  int buf = 0;
-  for (int s = t.src_begin; s < t.src_end; ++s) {
-    const chol_upd_src sd = srcs[s];
-    const float *A = base + sd.a_off + t.ar + srow;
-    const float *Bp = base + sd.b_off + t.br + srow;
-    const int K = sd.k;
-    float ra[4], rb[4];
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = skq + 4 * i;
-      ra[i] = (sva && k < K) ? A[(int64_t)k * sd.lda] : 0.f;
-      rb[i] = (svb && k < K) ? Bp[(int64_t)k * sd.ldb] : 0.f;
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f4){ 0.f, 0.f, 0.f, 0.f };
+  const int ni = max(0, min(2, (t.mv - 32 * wr + 15) >> 4)), nj = max(0, min(2, (t.nv - 32 * wc + 15) >> 4));
+  bool full = t.mv == M32 && t.nv == M32;
+  if (!full && arena_elems > 0) { // an edge tile: may the DMA read 64 rows of every source?
+    if (tt == 0) sOk = 1;
+    __syncthreads();
+    for (int s = t.src_begin + tt; s < t.src_end; s += 256) {
+      const chol_upd_src sd = srcs[s];
+      const int kf = (sd.k / M32_KB) * M32_KB;
+      if (kf > 0 && (sd.a_off + t.ar + (M32 - 1) + (int64_t)(kf - 1) * sd.lda >= arena_elems || sd.b_off + t.br + (M32 - 1) + (int64_t)(kf - 1) * sd.ldb >= arena_elems)) sOk = 0;
     }
-    for (int k0 = 0; k0 < K; k0 += MKB) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { sA[buf][skq + 4 * i][srow] = ra[i]; sB[buf][skq + 4 * i][srow] = rb[i]; }
-      if (k0 + MKB < K) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int k = k0 + MKB + skq + 4 * i;
-          ra[i] = (sva && k < K) ? A[(int64_t)k * sd.lda] : 0.f;
-          rb[i] = (svb && k < K) ? Bp[(int64_t)k * sd.ldb] : 0.f;
-        }
+    __syncthreads();
+    full = sOk != 0;
+  }
+  if (full) {
+    for (int sb = t.src_begin; sb < t.src_end; sb += M32_SRC_BATCH) {
+      const int ns = min(M32_SRC_BATCH, t.src_end - sb);
+      __builtin_amdgcn_s_barrier(); // the previous batch is done with sS and with the ring
+      if (tt < ns) sS[tt] = srcs[sb + tt];
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      int total = 0;
+      for (int s = 0; s < ns; ++s) total += sS[s].k / M32_KB;
+      int is = 0, ik = 0, issued = 0; // issue cursor
+      // one DMA instruction per wave, chunk and operand: wave w moves k-rows 4 w .. 4 w + 3 (256 floats), lane l the four floats at 4 l
+#define M32_ISSUE()                                                                                                   \
+      {                                                                                                               \
+        while (is < ns && ik + M32_KB > sS[is].k) { ++is; ik = 0; }                                                   \
+        const int e_ = 256 * wave + 4 * lane;                                                                         \
+        const int st_ = issued % M32_STAGES;                                                                          \
+        lds_dma16_f32(base + sS[is].a_off + t.ar + e_ % M32 + (int64_t)(ik + e_ / M32) * sS[is].lda, &sA[st_][0][0] + 256 * wave); \
+        lds_dma16_f32(base + sS[is].b_off + t.br + e_ % M32 + (int64_t)(ik + e_ / M32) * sS[is].ldb, &sB[st_][0][0] + 256 * wave); \
+        ++issued; ik += M32_KB;                                                                                       \
       }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // LDS-only barrier: the prefetch stays in flight
+      for (int i = 0; i < M32_STAGES - 1 && issued < total; ++i) M32_ISSUE();
+      for (int c = 0; c < total; ++c) {
+        if (issued - c - 1 >= M32_STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (M32_STAGES - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier(); // every wave's part of chunk c is in LDS; every wave has left chunk c - 1
+        if (issued < total) M32_ISSUE(); // into the stage chunk c - 1 occupied
+        m32_chunk(acc, &sA[c % M32_STAGES][0][0], &sB[c % M32_STAGES][0][0], g, xo, yo, ni, nj);
+      }
+#undef M32_ISSUE
+    }
+    __builtin_amdgcn_s_barrier(); // the tail path below re-uses the stages
+  }
+  // ---- register-staged path: everything for edge tiles the DMA may not serve, the K tails (K mod 16 columns) of the sources otherwise.
+  //      Thread tt stages row tt & 63 of both operands, k-columns (tt >> 6) + 4 i of the chunk
+  {
+    const int srow = tt & (M32 - 1), skq = tt >> 6;
+    const bool sva = srow < t.mv, svb = srow < t.nv;
+    int buf = 0;
+    for (int s = t.src_begin; s < t.src_end; ++s) {
+      const chol_upd_src sd = srcs[s];
+      const int K = sd.k, kbeg = full ? (K / M32_KB) * M32_KB : 0;
+      if (kbeg >= K) continue;
+      const float *A = base + sd.a_off + t.ar + srow;
+      const float *Bp = base + sd.b_off + t.br + srow;
+      float ra[4], rb[4];
 #pragma unroll
-      for (int kk = 0; kk < MKB / 2; ++kk)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sB[buf][2 * kk + h][32 * wc + l31], sA[buf][2 * kk + h][32 * wr + l31], acc, 0, 0, 0);
-      buf ^= 1;
+      for (int i = 0; i < 4; ++i) {
+        const int k = kbeg + skq + 4 * i;
+        ra[i] = (sva && k < K) ? A[(int64_t)k * sd.lda] : 0.f;
+        rb[i] = (svb && k < K) ? Bp[(int64_t)k * sd.ldb] : 0.f;
+      }
+      for (int k0 = kbeg; k0 < K; k0 += M32_KB) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sA[buf][skq + 4 * i][srow] = ra[i]; sB[buf][skq + 4 * i][srow] = rb[i]; }
+        if (k0 + M32_KB < K) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int k = k0 + M32_KB + skq + 4 * i;
+            ra[i] = (sva && k < K) ? A[(int64_t)k * sd.lda] : 0.f;
+            rb[i] = (svb && k < K) ? Bp[(int64_t)k * sd.ldb] : 0.f;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // LDS-only barrier: the prefetch stays in flight
+        m32_chunk(acc, &sA[buf][0][0], &sB[buf][0][0], g, xo, yo, ni, nj);
+        buf ^= 1;
+      }
     }
   }
-  const int r = 32 * wr + l31;
-  float *C = base + t.c_off + r;
-  float cv[16];
+  // epilogue: every C value of the lane requested before the first is used (clamped addresses, masked stores); register q of lane
+  // (r15, g) is C(row 16 i + r15, column 16 j + 4 g + q) of the wave's quadrant
+  float cv[2][2][4];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = min(32 * wc + (i & 3) + 8 * (i >> 2) + 4 * h, t.nv - 1);
-    cv[i] = *(const volatile float *)(base + t.c_off + min(r, t.mv - 1) + (int64_t)c * t.ldc);
-  }
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = 32 * wc + (i & 3) + 8 * (i >> 2) + 4 * h;
-    if (r < t.mv && c < t.nv && (!t.lower || r >= c)) C[(int64_t)c * t.ldc] = cv[i] - acc[i];
-  }
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = min(32 * wr + 16 * i + r15, t.mv - 1), c = min(32 * wc + 16 * j + 4 * g + q, t.nv - 1);
+        cv[i][j][q] = *(const volatile float *)(base + t.c_off + r + (int64_t)c * t.ldc);
+      }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = 32 * wr + 16 * i + r15;
+      float *C = base + t.c_off + r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 32 * wc + 16 * j + 4 * g + q;
+        if (r < t.mv && c < t.nv && (!t.lower || t.ar + r >= t.br + c)) C[(int64_t)c * t.ldc] = cv[i][j][q] - acc[i][j][q];
+      }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -385,11 +486,11 @@ int chol32_launch_update(float *base, const chol_upd_task *tasks, const chol_upd
   hipLaunchKernelGGL(k32_update, dim3(per_xcd * 8), dim3(256), 0, st, base, tasks, srcs, ntask, per_xcd);
   return (int)hipGetLastError();
 }
-int chol32_launch_update_mt(float *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st)
-{
+int chol32_launch_update_mt(float *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, int64_t arena_elems, hipStream_t st)
+{ // arena_elems: floats in the arena behind `base` (0: unknown -- edge tiles then stage their operands through registers)
   if (ntask <= 0) return 0;
   const int per_xcd = (ntask + 7) / 8;
-  hipLaunchKernelGGL(k32_update_mt, dim3(per_xcd * 8), dim3(256), 0, st, base, tasks, srcs, ntask, per_xcd);
+  hipLaunchKernelGGL(k32_update_mt, dim3(per_xcd * 8), dim3(256), 0, st, base, tasks, srcs, ntask, per_xcd, arena_elems);
   return (int)hipGetLastError();
 }
 int chol_launch_residual(const int64_t *ptr, const int *col, const double *val, const double *b, const double *x, double *r, int n, double *partial, hipStream_t st)
