@@ -578,7 +578,7 @@ static int ensure_f32(cholamd_device *d)
   if (!d->lv32.empty()) return 0;
   const int L = d->plan->levels;
   chol_sched_opts o = d->opt;
-  o.split_min = CHOL32_MAXN; o.split_nb = CHOL32_MAXN; o.fuse = 0; o.fuse_update_max = 0; o.dist_top = 0; // pivot blocks the LDS-resident fp32 POTRF takes, one launch per phase
+  o.split_min = CHOL32_MAXN; o.split_nb = CHOL32_MAXN; o.fuse = 0; o.fuse_update_max = 0; o.dist_top = 0; o.trsm_group = CHOL32_TRSM_GROUP; // pivot blocks the LDS-resident fp32 POTRF takes, one launch per phase
   d->lv32.resize(L);
   for (int lvl = 0; lvl < L; lvl++) {
     chol_level_work w;
@@ -618,8 +618,9 @@ extern "C" int cholamd_factor_levels_f32(cholamd_device *d, float *d_arena32, in
   for (int lvl = level_hi; lvl >= level_lo; lvl--) {
     const level_dev &l = d->lv32[lvl];
     for (const chol_phase &ph : l.phase) {
-      scoped_timer t(d, st, ph.kind == 3 ? 2 : ph.kind == 4 ? 1 : ph.kind, ph.n > 0);
+      scoped_timer t(d, st, ph.kind == 3 ? 2 : (ph.kind == 4 || ph.kind == 7) ? 1 : ph.kind, ph.n > 0);
       if (ph.kind == 0) HIPCHK((hipError_t)chol32_launch_potrf(d_arena32, d->ws32, l.potrf + ph.first, ph.n, d->info, st));
+      else if (ph.kind == 7) HIPCHK((hipError_t)chol32_launch_trsm_wt(d_arena32, d->ws32, l.trsm + ph.first, ph.n, st));
       else if (ph.kind == 1 || ph.kind == 4) HIPCHK((hipError_t)chol32_launch_trsm(d_arena32, d->ws32, l.trsm + ph.first, ph.n, st));
       else if (ph.kind == 2) HIPCHK((hipError_t)chol32_launch_update(d_arena32, l.task + ph.first, l.src, ph.n, st));
       else if (ph.kind == 3) HIPCHK((hipError_t)chol32_launch_update_mt(d_arena32, l.task_mt + ph.first, l.src, ph.n, (int64_t)d->plan->arena, st));

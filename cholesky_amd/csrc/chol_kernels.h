@@ -34,6 +34,7 @@ int chol_launch_bwd(const double *base, const chol_trsv_desc *descs, const chol_
 int chol32_launch_scatter(float *arena, const int64_t *dst, const double *val, int64_t nnz, hipStream_t st);
 int chol32_launch_potrf(float *base, float *ws, const chol_potrf_desc *descs, int n, int *info, hipStream_t st);
 int chol32_launch_trsm(float *base, const float *ws, const chol_trsm_desc *descs, int n, hipStream_t st);
+int chol32_launch_trsm_wt(float *base, const float *ws, const chol_trsm_desc *descs, int n, hipStream_t st);
 int chol32_launch_update(float *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st);
 int chol32_launch_update_mt(float *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, int64_t arena_elems, hipStream_t st);
 int chol32_launch_solve_dinv(const float *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st);

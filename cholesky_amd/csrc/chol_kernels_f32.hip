@@ -424,6 +424,111 @@ __global__ __launch_bounds__(256) void k32_update_mt(float *__restrict__ base, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// TRSM, throughput form (the fp32 schedule's only TRSM phases: large problems): the fp64 k_trsm_wt at fp32.  One wave per 16-row
+// strip, SIXTEEN strips per 1024-thread workgroup sharing one staged image of the pivot block (up to 128 columns: 36 L tiles + 8
+// inverses, one LDS-DMA instruction per tile -- lane l moves rows 4 (l & 3) .. + 3 of column l >> 2, which is the [k][c] image the
+// MFMA operand reads want, and the workspace layout of the inverses verbatim); the strip's column tiles stay in registers and are
+// the next MFMA's operand straight out of their accumulators (k = 4 g + s on both operands, as in k32_trsm).  k32_trsm reads L from
+// global memory inside its MFMA loop: 25.7 of the 333 ms of the 100^3 factorisation.
+// ------------------------------------------------------------------------------------------------
+#define T32_MAXT ((CHOL32_MAXN + TS - 1) / TS)
+#define T32_WAVES CHOL32_TRSM_GROUP
+template <int T> __device__ __forceinline__ void trsm32_solve(f4 (&tile)[T32_MAXT], const float *simg, float *__restrict__ B, int n, int ldb, bool vrow, int r15, int g)
+{
+#pragma unroll
+  for (int J = 0; J < T; ++J) {
+    const float *sd = simg + (J * T - J * (J - 1) / 2) * (TS * TS); // slot (J, J): the inverse
+    f4 x = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int s = 0; s < 4; ++s) x = __builtin_amdgcn_mfma_f32_16x16x4f32(sd[(4 * g + s) * TS + r15], tile[J][s], x, 0, 0, 0);
+    if (vrow) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = J * TS + 4 * g + q;
+        if (col < n) B[r15 + (int64_t)col * ldb] = x[q];
+      }
+    }
+    float nx[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { nx[s] = -x[s]; asm volatile("" : "+v"(nx[s])); } // negated once per step, not once per MFMA
+#pragma unroll
+    for (int j = J + 1; j < T; ++j) {
+      const float *sl = sd + (j - J) * (TS * TS);
+      f4 acc = tile[j];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sl[(4 * g + s) * TS + r15], nx[s], acc, 0, 0, 0);
+      tile[j] = acc;
+    }
+  }
+}
+__global__ __launch_bounds__(64 * T32_WAVES) void k32_trsm_wt(float *__restrict__ base, const float *__restrict__ ws, const chol_trsm_desc *__restrict__ descs, int ndesc)
+{
+  __shared__ float sT[T32_MAXT * (T32_MAXT + 1) / 2][TS * TS]; // slot(J2, J) = J T - J (J - 1) / 2 + (J2 - J): tile L(J2, J) as [k][c]; diagonal slots: Linv(J, J)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int id0 = blockIdx.x * T32_WAVES;
+  const chol_trsm_desc d0 = descs[id0];
+  const float *Lm = base + d0.l_off;
+  const float *W = ws + d0.dinv_off;
+  const int n = d0.n, ldl = d0.ldl;
+  const int T = (n + TS - 1) / TS;
+  const int r15 = lane & 15, g = lane >> 4;
+  int64_t b_off = d0.b_off;
+  int m = 0, ldb = d0.ldb;
+  if (id0 + wave < ndesc) {
+    const chol_trsm_desc d = descs[id0 + wave];
+    b_off = d.b_off; m = d.m; ldb = d.ldb;
+  }
+  float *B = base + b_off;
+  const bool vrow = r15 < m;
+  { // stage: slot h goes to wave h mod 16.  Rows past n of the last row tile are whatever follows in the panel (finite): they only
+    // reach output columns >= n, which are never stored, and meet the zeros of the padded inverse
+    const int nslots = T * (T + 1) / 2;
+    for (int h = wave; h < nslots; h += T32_WAVES) {
+      int J = 0, rem = h;
+      while (rem >= T - J) { rem -= T - J; ++J; }
+      const int J2 = J + rem;
+      const float *src = J2 == J ? W + (int64_t)J * TS * TS + 4 * lane
+                                 : Lm + (J2 * TS + 4 * (lane & 3)) + (int64_t)(J * TS + (lane >> 2)) * ldl;
+      lds_dma16_f32(src, &sT[h][0]);
+    }
+  }
+  f4 tile[T32_MAXT];
+  {
+    const int rb = min(r15, max(m - 1, 0));
+#pragma unroll
+    for (int J = 0; J < T32_MAXT; ++J) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tile[J][q] = B[rb + (int64_t)min(J * TS + 4 * g + q, n - 1) * ldb];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads(); // every wave's LDS-DMA has landed
+  if (m <= 0) return;
+#pragma unroll
+  for (int J = 0; J < T32_MAXT; ++J) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v = tile[J][q];
+      asm volatile("" : "+v"(v));
+      tile[J][q] = (vrow && J * TS + 4 * g + q < n) ? v : 0.f;
+    }
+  }
+  const float *const s0 = &sT[0][0];
+  switch (T) {
+  case 1: trsm32_solve<1>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  case 2: trsm32_solve<2>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  case 3: trsm32_solve<3>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  case 4: trsm32_solve<4>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  case 5: trsm32_solve<5>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  case 6: trsm32_solve<6>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  case 7: trsm32_solve<7>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  case 8: trsm32_solve<8>(tile, s0, B, n, ldb, vrow, r15, g); break;
+  default: break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Iterative refinement helpers (fp64): r = b - A x with A as a symmetric CSR in original dof order, per-workgroup
 // partial sums of r^2 and b^2 (added on the host: deterministic), x += dx.
 // ------------------------------------------------------------------------------------------------
@@ -477,6 +582,12 @@ int chol32_launch_trsm(float *base, const float *ws, const chol_trsm_desc *descs
 {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k32_trsm, dim3((n + 3) / 4), dim3(256), 0, st, base, ws, descs, n);
+  return (int)hipGetLastError();
+}
+int chol32_launch_trsm_wt(float *base, const float *ws, const chol_trsm_desc *descs, int n, hipStream_t st)
+{ // every aligned group of CHOL32_TRSM_GROUP descriptors shares one pivot block (m = 0: placeholder)
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k32_trsm_wt, dim3((n + T32_WAVES - 1) / T32_WAVES), dim3(64 * T32_WAVES), 0, st, base, ws, descs, n);
   return (int)hipGetLastError();
 }
 int chol32_launch_update(float *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st)

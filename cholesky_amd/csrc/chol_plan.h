@@ -27,6 +27,7 @@ extern "C" {
 // /* followers of at most this many column tiles take every column of their sources themselves */
 #define CHOL_FOLLOW_TAIL 3     /* default of option follow_tail */
 #define CHOL_FOLLOW_MAXT 10 /* most column tiles of a pivot block that follows its sources inside the program launch (chol_kernels.hip, follow_external) */
+#define CHOL32_TRSM_GROUP 16 /* strips per workgroup of the fp32 throughput TRSM (k32_trsm_wt): the fp32 schedule pads every pivot block's strips to it */
 #define CHOL32_MAXN 128   /* widest pivot block of the fp32 path: its lower triangle is factored out of LDS (chol_kernels_f32.hip) */
 
 typedef struct {
@@ -144,6 +145,7 @@ typedef struct {
   int fuse;                 /* POTRF + TRSM of a column-block step in one launch */
   int fuse_update_max;      /* most 16x16 update tasks such a launch carries */
   int mt_min_tiles;
+  int trsm_group;           /* unfused schedule: every pivot block's strips padded to this many, TRSM phases of kind 7 (the fp32 schedule: CHOL32_TRSM_GROUP); 0: off */
   int trsm_wt_min;          /* level schedule: steps with at least this many TRSM strips take the throughput TRSM (0: never) */
   int cells;                /* extend-add of small phases by 16x16 grid cells of the target blocks */
   int program;              /* small problems: the whole factorisation as one launch (chol_build_program) */

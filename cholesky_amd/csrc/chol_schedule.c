@@ -88,7 +88,7 @@ static int env_int(const char *name, int dflt) { const char *e = getenv(name); r
 void chol_sched_opts_default(chol_sched_opts *o)
 {
   o->split_min = CHOL_SPLIT_MIN; o->split_nb = CHOL_SPLIT_NB; o->fuse = 1; o->fuse_update_max = CHOL_FUSE_UPDATE_MAX;
-  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->trsm_wt_min = CHOL_TRSM_WT_MIN; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL; o->follow_tail_split = CHOL_FOLLOW_TAIL; o->staged = 1; o->fine_upd = 1; o->skyline = 1; o->stage_chunk = CHOL_STAGE_CHUNK;
+  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->trsm_wt_min = CHOL_TRSM_WT_MIN; o->trsm_group = 0; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL; o->follow_tail_split = CHOL_FOLLOW_TAIL; o->staged = 1; o->fine_upd = 1; o->skyline = 1; o->stage_chunk = CHOL_STAGE_CHUNK;
 }
 void chol_sched_opts_from_env(chol_sched_opts *o)
 {
@@ -461,6 +461,7 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
         for (int r = 0; r < nr; r++) push_trsm_run(B, diag, dinv, runs[r].off + colbase, nb, ld, runs[r].m, flag);
         if (thru) pad_trsm_group(B, t0, CHOL_TRSM_WT_GROUP, diag, dinv, diag, nb, ld, flag);
         else if (fuse) pad_trsm_group(B, t0, 3, diag, dinv, diag, nb, ld, flag);
+        else if (opts->trsm_group > 0) pad_trsm_group(B, t0, opts->trsm_group, diag, dinv, diag, nb, ld, flag);
         else if (nb <= CHOL_TRSM_W_MAXN) pad_trsm_group(B, t0, 4, diag, dinv, diag, nb, ld, flag);
       }
       if (below > 0) {
@@ -546,7 +547,7 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
       /* strips whose pivot block is narrow enough take the one-wave-per-strip kernel */
       int wide = 0;
       for (int i = t0; i < w->n_trsm; i++) if (w->trsm[i].n > CHOL_TRSM_W_MAXN) wide = 1;
-      push_phase(B, wide ? 1 : 4, t0, w->n_trsm - t0);
+      push_phase(B, opts->trsm_group > 0 ? 7 : wide ? 1 : 4, t0, w->n_trsm - t0);
       push_phase(B, 2, k0, w->n_task - k0);
     }
     push_phase(B, 3, km0, w->n_task_mt - km0);
