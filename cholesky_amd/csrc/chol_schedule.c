@@ -424,7 +424,7 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
     /* a step with thousands of strips (the wide fronts of a large problem) is a throughput problem: POTRF launch, then the
      * one-wave-per-strip TRSM with twelve strips per workgroup, instead of the fused launch's latency design */
     int thru = 0;
-    if (fuse && !dist && opts->trsm_wt_min > 0) {
+    if (fuse && opts->trsm_wt_min > 0) { /* (distributed top levels too: the owner's strips) */
       int64_t est = 0; int fits = 1;
       for (int q = 0; q < nh; q++) {
         const int s = p->tree[hs[q]], n = p->sep_size[s], bw = pivot_block_width(opts, n), c0 = st * bw;
@@ -514,7 +514,10 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
     flush_targets(B);
     if (dist) { /* owner's POTRF + TRSM, the broadcast of the step's column blocks (collective: the same list on every rank),
                  * then this rank's share of the trailing update */
-      if (fuse) {
+      if (thru) {
+        push_phase(B, 0, p0, w->n_potrf - p0);
+        push_phase(B, 7, t0, w->n_trsm - t0);
+      } else if (fuse) {
         if (w->n_phase == B->cap_ph) { B->cap_ph = B->cap_ph ? 2 * B->cap_ph : 16; w->phase = realloc(w->phase, B->cap_ph * sizeof(chol_phase)); }
         chol_phase ph = { 5, p0, w->n_potrf - p0, t0, w->n_trsm - t0, k0, 0 };
         if (ph.n > 0) w->phase[w->n_phase++] = ph;

@@ -230,9 +230,10 @@ def test_sharded_world8_in_one_process():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case,world,dist_top", [("lapl_3375x3375", 2, 1), ("lapl_3375x3375", 8, 1), ("lapl_3375x3375", 4, 0),
-                                                 ((20, 20, 20, 4, 32), 4, 1), ((24, 24, 24, 5, 32), 8, 1), ((36, 36, 30, 3, 64), 2, 2)])
-def test_factor_multi_distributed_top(case, world, dist_top):
+@pytest.mark.parametrize("case,world,dist_top,wt", [("lapl_3375x3375", 2, 1, -1), ("lapl_3375x3375", 8, 1, -1), ("lapl_3375x3375", 4, 0, -1),
+                                                    ((20, 20, 20, 4, 32), 4, 1, -1), ((24, 24, 24, 5, 32), 8, 1, -1), ((36, 36, 30, 3, 64), 2, 2, -1),
+                                                    ((24, 24, 24, 5, 32), 4, 1, 1), ("lapl_3375x3375", 2, 0, 1)])  # wt = 1: every step's strips through k_trsm_wt
+def test_factor_multi_distributed_top(case, world, dist_top, wt):
     """cholamd_factor_multi over a LOCAL communicator (the rank objects share the one GPU): subtree levels, ordered device-side sum
     of the tails, then the top levels distributed by column blocks (owner POTRF + TRSM, broadcast, owned updates) -- or
     replicated (dist_top 0) -- against the single-GPU factor; every rank ends with the same complete top."""
@@ -253,6 +254,8 @@ def test_factor_multi_distributed_top(case, world, dist_top):
     for r in range(world):
         dev = ca.Device(plan, 0)
         dev.set_option("dist_top", dist_top)
+        if wt >= 0:
+            dev.set_option("trsm_wt_min", wt)
         dev.set_partition(r, world)
         a = dev.new_arena()
         dev.fill(a)
