@@ -268,6 +268,20 @@ __global__ __launch_bounds__(256) void k32_update(float *__restrict__ base, cons
 #define M32_STAGES 2
 #endif
 #define M32_SRC_BATCH 32
+/* timing diagnostics of scripts/mt_bench32.hip (wrong results): -DM32_NODMA leaves the operand transfers out, -DM32_NOBAR the ring's barriers */
+#ifdef M32_NODMA
+#define M32_DIAG_DMA(x_) ((void)0)
+#else
+#define M32_DIAG_DMA(x_) x_
+#endif
+#ifdef M32_NOBAR
+#define M32_DIAG_BAR(x_) ((void)0)
+#else
+#define M32_DIAG_BAR(x_) x_
+#endif
+#ifndef M32_WPE
+#define M32_WPE 8 /* waves per SIMD asked of the compiler (60 registers): 81 -> 85 TF/s on one big SYRK against the default's 6 */
+#endif
 __device__ __forceinline__ void lds_dma16_f32(const float *g, float *lds)
 { // lane l's 16 bytes at g land at lds + 16 l bytes; M0 saved and restored inside the statement (see lds_dma16, chol_kernels.hip)
   unsigned keep;
@@ -297,7 +311,7 @@ __device__ __forceinline__ void m32_chunk(f4 (&acc)[2][2], const float *sa, cons
     for (int i = 0; i < 2; ++i) { x[i] = nx[i]; y[i] = ny[i]; }
   }
 }
-__global__ __launch_bounds__(256) void k32_update_mt(float *__restrict__ base, const chol_upd_task *__restrict__ tasks, const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd, int64_t arena_elems)
+__global__ __launch_bounds__(256, M32_WPE) void k32_update_mt(float *__restrict__ base, const chol_upd_task *__restrict__ tasks, const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd, int64_t arena_elems)
 {
   __shared__ float sA[M32_STAGES][M32_KB][M32];
   __shared__ float sB[M32_STAGES][M32_KB][M32];
@@ -345,15 +359,15 @@ __global__ __launch_bounds__(256) void k32_update_mt(float *__restrict__ base, c
         while (is < ns && ik + M32_KB > sS[is].k) { ++is; ik = 0; }                                                   \
         const int e_ = 256 * wave + 4 * lane;                                                                         \
         const int st_ = issued % M32_STAGES;                                                                          \
-        lds_dma16_f32(base + sS[is].a_off + t.ar + e_ % M32 + (int64_t)(ik + e_ / M32) * sS[is].lda, &sA[st_][0][0] + 256 * wave); \
-        lds_dma16_f32(base + sS[is].b_off + t.br + e_ % M32 + (int64_t)(ik + e_ / M32) * sS[is].ldb, &sB[st_][0][0] + 256 * wave); \
+        M32_DIAG_DMA(lds_dma16_f32(base + sS[is].a_off + t.ar + e_ % M32 + (int64_t)(ik + e_ / M32) * sS[is].lda, &sA[st_][0][0] + 256 * wave)); \
+        M32_DIAG_DMA(lds_dma16_f32(base + sS[is].b_off + t.br + e_ % M32 + (int64_t)(ik + e_ / M32) * sS[is].ldb, &sB[st_][0][0] + 256 * wave)); \
         ++issued; ik += M32_KB;                                                                                       \
       }
       for (int i = 0; i < M32_STAGES - 1 && issued < total; ++i) M32_ISSUE();
       for (int c = 0; c < total; ++c) {
         if (issued - c - 1 >= M32_STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (M32_STAGES - 2)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier(); // every wave's part of chunk c is in LDS; every wave has left chunk c - 1
+        M32_DIAG_BAR(__builtin_amdgcn_s_barrier()); // every wave's part of chunk c is in LDS; every wave has left chunk c - 1
         if (issued < total) M32_ISSUE(); // into the stage chunk c - 1 occupied
         m32_chunk(acc, &sA[c % M32_STAGES][0][0], &sB[c % M32_STAGES][0][0], g, xo, yo, ni, nj);
       }
