@@ -51,7 +51,10 @@ struct cholamd_device {
   bool solve_ready = false;
   double *ws = nullptr;
   double *ws_solve = nullptr; // 16x16 inverses of the diagonal blocks of the arena being solved with
-  int *info = nullptr;      // [0] first failing column, [1] separator
+  int *info = nullptr;      // [0] first failing column, [1] separator; two slots of two ints: the program launch alternates between them (each launch clears the other
+                            // one for the next: no memset node per factorisation), every other path uses slot 0
+  int *info_last = nullptr; // the slot of the most recent factorisation (cholamd_factor_info)
+  int info_parity = 0; bool info_foreign = false; // program path: slot of the next launch; slot 0 was used by another path since
   int *progress = nullptr;  // fused launches: columns published per pivot block (epoch * 64 + columns); [nsep + 1] = TRSM workgroups finished
   int epoch = 0, done_total = 0;
   int64_t *a_dst = nullptr; double *a_val = nullptr; int *perm = nullptr; double *ytmp = nullptr;
@@ -193,8 +196,8 @@ extern "C" int cholamd_device_create(const cholamd_plan *plan, int device_id, ch
   int rc = build_levels(d);
   if (!rc) {
     hipError_t e = hipMalloc((void **)&d->ws, (size_t)(plan->ws_doubles > 0 ? plan->ws_doubles : 1) * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&d->info, 2 * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(d->info, 0, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&d->info, 4 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(d->info, 0, 4 * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&d->progress, (size_t)(plan->nsep + 2) * sizeof(int));
     if (e == hipSuccess) e = hipMemset(d->progress, 0, (size_t)(plan->nsep + 2) * sizeof(int));
     if (e != hipSuccess) { chol_set_error("hipMalloc: %s", hipGetErrorString(e)); rc = CHOLAMD_ERR_HIP; }
@@ -398,6 +401,7 @@ static int factor_levels_comm(cholamd_device *d, double *d_arena, int level_hi, 
   if (level_hi >= L) level_hi = L - 1;
   if (level_lo < 0) level_lo = 0;
   if (level_hi == L - 1) HIPCHK(hipMemsetAsync(d->info, 0, 2 * sizeof(int), st));
+  d->info_last = d->info; d->info_foreign = true; // slot 0: the level-by-level paths
   for (int lvl = level_hi; lvl >= level_lo; lvl--) { // mmat.rg:1227
     const level_dev &l = d->lv[lvl];
     for (const chol_phase &ph : l.phase) {
@@ -422,7 +426,9 @@ extern "C" int cholamd_factor(cholamd_device *d, double *d_arena, void *stream)
   if (!d->prog_ready) return cholamd_factor_levels(d, d_arena, d->plan->levels - 1, 0, stream);
   HIPCHK(hipSetDevice(d->dev));
   hipStream_t st = (hipStream_t)stream;
-  HIPCHK(hipMemsetAsync(d->info, 0, 2 * sizeof(int), st));
+  if (d->info_foreign) { HIPCHK(hipMemsetAsync(d->info, 0, 4 * sizeof(int), st)); d->info_foreign = false; } // another path wrote slot 0 since
+  int *const info_cur = d->info + 2 * d->info_parity, *const info_next = d->info + 2 * (d->info_parity ^ 1);
+  d->info_parity ^= 1; d->info_last = info_cur;
   // counters are monotonic across factorisations (no reset between them); they start over, in stream order, long before
   // any of them can wrap
   if (d->prog_epoch >= d->prog_epoch_limit) { HIPCHK(hipMemsetAsync(d->pctr, 0, (size_t)d->n_pctr * sizeof(int), st)); d->prog_epoch = 0; }
@@ -430,7 +436,7 @@ extern "C" int cholamd_factor(cholamd_device *d, double *d_arena, void *stream)
   {
     scoped_timer t(d, st, 3, true);
     HIPCHK((hipError_t)chol_launch_program(d_arena, d->ws, d->jobs, d->n_job, d->pwaits, l.potrf, l.trsm, l.task, l.src, d->exts, d->pctr, d->pctr_total, d->prog_epoch,
-                                           d->pctr + d->n_pctr - 1, d->prog_epoch * (d->n_job + d->prog_grid), d->prog_grid, d->info, d->trace, st));
+                                           d->pctr + d->n_pctr - 1, d->prog_epoch * (d->n_job + d->prog_grid), d->prog_grid, info_cur, info_next, d->trace, st));
   }
   d->prog_epoch++;
   return 0;
@@ -479,7 +485,7 @@ extern "C" int cholamd_factor_info(cholamd_device *d, int *sep_out)
 {
   HIPCHK(hipSetDevice(d->dev));
   int h[2] = { 0, 0 };
-  HIPCHK(hipMemcpy(h, d->info, sizeof h, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(h, d->info_last ? d->info_last : d->info, sizeof h, hipMemcpyDeviceToHost));
   if (sep_out) *sep_out = h[1];
   if (h[0] == CHOLAMD_ERR_STALL)
     chol_set_error("factorisation stalled: a workgroup of a fused launch waited ~50 ms for a progress word of the same launch and gave up; the factor is not valid");
@@ -615,6 +621,7 @@ extern "C" int cholamd_factor_levels_f32(cholamd_device *d, float *d_arena32, in
   if (level_hi >= L) level_hi = L - 1;
   if (level_lo < 0) level_lo = 0;
   if (level_hi == L - 1) HIPCHK(hipMemsetAsync(d->info, 0, 2 * sizeof(int), st));
+  d->info_last = d->info; d->info_foreign = true; // slot 0: the level-by-level paths
   for (int lvl = level_hi; lvl >= level_lo; lvl--) {
     const level_dev &l = d->lv32[lvl];
     for (const chol_phase &ph : l.phase) {
@@ -990,7 +997,7 @@ extern "C" int cholamd_factor_debug(cholamd_device *d, double *d_arena, const ch
       cholamd_region rA = region_of(s, s);
       int rc = cholamd_fused_dpotrf(&rA, F(s, s).data(), (int)F(s, s).size(), lvl, lbl, 1, stream);
       if (rc < 0) return rc;
-      if (rc > 0) { int h2[2] = { rc, s }; HIPCHK(hipMemcpy(d->info, h2, sizeof h2, hipMemcpyHostToDevice)); }
+      if (rc > 0) { int h2[2] = { rc, s }; HIPCHK(hipMemcpy(d->info, h2, sizeof h2, hipMemcpyHostToDevice)); d->info_last = d->info; d->info_foreign = true; }
       if ((rc = debug_dump(d, d_arena, host, dir, lvl, "POTRF", s, s, 0, 0, 0, 0, full_precision))) return rc;
     }
     for (int h = h0; h <= h1; h++) { // TRSM sweep, mmat.rg:1259-1291

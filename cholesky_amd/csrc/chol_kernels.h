@@ -15,7 +15,7 @@ int chol_launch_potrf_trsm(double *base, double *ws, const chol_potrf_desc *pdes
                            int *info, int *progress, int progress_base, int *done, int done_target, hipStream_t st);
 int chol_launch_program(double *base, double *ws, const chol_job *jobs, int njobs, const chol_wait *waits, const chol_potrf_desc *pdescs, const chol_trsm_desc *tdescs,
                         const chol_upd_task *tasks, const chol_upd_src *srcs, const chol_ext *exts, int *ctr, const int *ctr_total, int epoch, int *head, int head_base,
-                        int grid, int *info, unsigned long long *trace, hipStream_t st);
+                        int grid, int *info, int *info_next, unsigned long long *trace, hipStream_t st);
 int chol_launch_trsm_w(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st);
 int chol_launch_trsm_wt(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st);
 int chol_launch_trsm_big(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st);

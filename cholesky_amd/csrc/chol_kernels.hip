@@ -1814,8 +1814,10 @@ __global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ bas
                                                         const chol_trsm_desc *__restrict__ tdescs, const chol_upd_task *__restrict__ tasks,
                                                         const chol_upd_src *__restrict__ srcs, const chol_ext *__restrict__ exts,
                                                         int *__restrict__ ctr, const int *__restrict__ ctr_total, int epoch, int *__restrict__ head, int head_base,
-                                                        int *__restrict__ info, unsigned long long *__restrict__ trace)
-{ // trace (diagnostic runs only, else nullptr): per job the 100 MHz real-time clock when it was drawn, when its waits were over
+                                                        int *__restrict__ info, int *__restrict__ info_next, unsigned long long *__restrict__ trace)
+{
+  // the info words of the NEXT factorisation of this device object (the other of two slots) are cleared here: no memset node per launch
+  if (info_next && blockIdx.x == 0 && threadIdx.x == 0) { info_next[0] = 0; info_next[1] = 0; } // trace (diagnostic runs only, else nullptr): per job the 100 MHz real-time clock when it was drawn, when its waits were over
   // and when it ended, and the workgroup that ran it
   __shared__ double smem[RR_SMEM_DOUBLES];
   __shared__ int s_job;
@@ -2680,10 +2682,10 @@ int chol_launch_potrf_trsm(double *base, double *ws, const chol_potrf_desc *pdes
 }
 int chol_launch_program(double *base, double *ws, const chol_job *jobs, int njobs, const chol_wait *waits, const chol_potrf_desc *pdescs, const chol_trsm_desc *tdescs,
                         const chol_upd_task *tasks, const chol_upd_src *srcs, const chol_ext *exts, int *ctr, const int *ctr_total, int epoch, int *head, int head_base,
-                        int grid, int *info, unsigned long long *trace, hipStream_t st)
+                        int grid, int *info, int *info_next, unsigned long long *trace, hipStream_t st)
 {
   if (njobs <= 0) return 0;
-  hipLaunchKernelGGL(k_program, dim3(grid), dim3(RR_THREADS), 0, st, base, ws, jobs, njobs, waits, pdescs, tdescs, tasks, srcs, exts, ctr, ctr_total, epoch, head, head_base, info, trace);
+  hipLaunchKernelGGL(k_program, dim3(grid), dim3(RR_THREADS), 0, st, base, ws, jobs, njobs, waits, pdescs, tdescs, tasks, srcs, exts, ctr, ctr_total, epoch, head, head_base, info, info_next, trace);
   return (int)hipGetLastError();
 }
 int chol_launch_trsm_w(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st)

@@ -128,6 +128,27 @@ def test_non_spd_matrix_reports_separator_and_column(ca, runs):
     dev.sync()
     info, sep = dev.info()
     assert sep == plan.nsep and info == 2
+    # the info words alternate between two slots from one program launch to the next (each launch clears the other slot: no memset
+    # per factorisation): good and failing factorisations in any order report their own outcome
+    good = dev.new_arena()
+    for bad_turn in (False, False, True, False, True, True, False):
+        if bad_turn:
+            a = torch.from_numpy(host).cuda()
+        else:
+            dev.fill(good)
+            a = good
+        dev.factor(a)
+        dev.sync()
+        assert dev.info() == ((2, plan.nsep) if bad_turn else (0, 0))
+    dev.set_option("program", 0)  # the level-by-level path in between (slot 0, cleared by a memset)
+    dev.factor(torch.from_numpy(host).cuda())
+    dev.sync()
+    assert dev.info() == (2, plan.nsep)
+    dev.set_option("program", 1)
+    dev.fill(good)
+    dev.factor(good)
+    dev.sync()
+    assert dev.info() == (0, 0)
 
 
 # ------------------------------------------------------------------------------------------------
