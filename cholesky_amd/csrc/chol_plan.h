@@ -170,6 +170,11 @@ void chol_sched_opts_default(chol_sched_opts *o);
 void chol_sched_opts_from_env(chol_sched_opts *o);
 
 #define CHOL_SPLIT_MIN 144 /* pivots wider than this are factored in column blocks (chol_schedule.c); measured on lapl_3375: 258 us unsplit, 240 us at 144/144 */
+#ifndef CHOL_PROG_SPLIT_MIN
+#define CHOL_PROG_SPLIT_MIN 176
+#endif
+/* CHOL_PROG_SPLIT_MIN: the program launch factors pivots up to this width whole when split_min is at its default (lapl_3375: its 161 / 163 / 174-column leaves
+                                * as one 11-tile block, 177.9 -> 176.4 us; the level-by-level schedule is better off at 144: 215 against 220 us) */
 #define CHOL_SPLIT_NB 144  /* ... of at most this many columns */
 
 typedef struct {

@@ -916,13 +916,21 @@ static void emit_early_cells(pbuild *P, builder *B, const plan_t *p, int64_t c_o
   free(sc); free(sn); free(sq); free(sch);
 }
 
+/* the options as the program launch sees them: pivots up to CHOL_PROG_SPLIT_MIN columns whole unless split_min was set by the caller */
+static chol_sched_opts chol_program_opts(const chol_sched_opts *o)
+{
+  chol_sched_opts r = *o;
+  if (r.split_min == CHOL_SPLIT_MIN && r.split_nb == CHOL_SPLIT_NB) r.split_min = CHOL_PROG_SPLIT_MIN;
+  return r;
+}
 int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_work *w, chol_program *pg)
 {
   memset(w, 0, sizeof *w);
   memset(pg, 0, sizeof *pg);
   w->level = -1;
-  chol_sched_opts dflt;
+  chol_sched_opts dflt, prog;
   if (!opts) { chol_sched_opts_default(&dflt); opts = &dflt; }
+  prog = chol_program_opts(opts); opts = &prog;
   builder Bd; memset(&Bd, 0, sizeof Bd); Bd.w = w; Bd.o = opts; Bd.force_fine = 1;
   builder *B = &Bd;
   pbuild Pd; memset(&Pd, 0, sizeof Pd); Pd.pg = pg;
