@@ -288,6 +288,7 @@ int cholamd_factor_info(cholamd_device *d, int *sep_out);
  * column block of a split pivot), "staged" (the extend-add jobs of the
  * program launch take their sources pivot block by pivot block as those are solved instead of waiting for all of them;
  * CHOLAMD_NO_STAGED), "fine_upd" (followed strips wait for the update jobs into their own rows' block only; CHOLAMD_NO_FINE_UPD),
+ * (the program launch factors pivots up to 176 columns whole while "split_min" / "split_nb" are at their defaults: CHOL_PROG_SPLIT_MIN),
  * "trsm_wt_min" (level schedule: a column-block step with at least this many TRSM strips launches its POTRFs on their own and solves
  * the strips with the throughput kernel, one wave per strip; 0 = never; CHOLAMD_TRSM_WT_MIN),
  * "skyline" (program launch: the tile-level skyline of the leaf pivots -- the envelope of A inside the block -- is used: tile updates and
