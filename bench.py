@@ -36,10 +36,9 @@ CASES = {
     "lapl_400x400": ("lapl_20_2.mtx", "lapl_20_2_ord_5.txt", "lapl_20_2_clust_5.txt"),
     "lapl_3375x3375": ("lapl_15_3.mtx", "lapl_15_3_ord_5.txt", "lapl_15_3_clust_5.txt"),
 }
-PEAK_FP64_TFLOPS = 78.6   # MI355X dense fp64 (vector = matrix) peak, public spec; the microarch guide lists no fp64 row
-SUSTAINED_FP64_MFMA_TFLOPS = 50.0  # measured on this pool (scripts/mfma_peak.hip, profiles/r2/mfma_peak.txt): v_mfma_f64_16x16x4_f64 out of registers, 16 waves per CU, 54 ms: 48-50 TF/s (the f32 loop of the same script reaches 147-156 of 157.3: not a clock limit)
-PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = the fp32 vector rate
+SUSTAINED_FP64_MFMA_TFLOPS = 50.0  # measured on this pool (scripts/mfma_peak.hip): v_mfma_f64_16x16x4_f64 out of registers on all 256 CUs: 48-50 TF/s
+SUSTAINED_NOTE = ("what a register-operand v_mfma_f64_16x16x4_f64 loop on all 256 CUs sustains here (scripts/mfma_peak.hip; profiles/r3/mfma_peak/): "
+                  "64 % of `peak`; `frac` stays against `peak`")
 PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r2", "summary.json")  # scripts/profile_summary.py over the rocprofv3 passes of this command
 
 
@@ -137,6 +136,7 @@ def main():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="cholamd_device_set_option switch for this run (e.g. program=0: level-by-level launches), repeatable; recorded in config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustained", type=int, default=2000, help="extra figure beside the metric: the same step for this many factorisations (0 = skip)")
     ap.add_argument("--in-flight", type=int, default=4, help="extra figure (not the metric): independent factorisations kept this many at a time on device objects / streams of their own; 0 or 1 = skip")
     args = ap.parse_args()
     if args.gpus < 1 or args.gpus & (args.gpus - 1):
@@ -149,7 +149,7 @@ def main():
     import torch.distributed as dist
 
     import cholesky_amd as ca
-    from cholesky_amd import parallel
+    from cholesky_amd import benchline, parallel
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -306,91 +306,71 @@ def main():
                           "factors_identical": same,
                           "note": f"K independent factorisations, {NF} at a time ({NF} device objects, {NF} HIP streams); throughput of a batch, not the latency of one factorisation"}
         del devs[1:]
+    # sustained rate: the same step back to back for >= 2 000 steps (the 20-step figure of the driver's command is a 3.5 ms
+    # burst; clocks and caches settle differently over seconds).  Single GPU, the metric's configuration only.
+    sustained = None
+    NS = args.sustained
+    if world == 1 and not mixed and not generated and NS > 0:
+        pool = arenas + [dev.new_arena() for _ in range(max(0, min(NS, int(8e9 // per_arena)) - n_arenas))]  # bursts as long as 8 GB of pre-filled arenas allow
+        t_s, n_s = 0.0, 0
+        while n_s < NS:
+            for a in pool:
+                fill(a, stream)
+            fence()
+            k = min(len(pool), NS - n_s)
+            t0 = time.perf_counter()
+            for i in range(k):
+                step(pool[i])
+            fence()
+            t_s += time.perf_counter() - t0
+            n_s += k
+        sustained = {"steps": n_s, "value": round(plan.flops * n_s / t_s * 1e-9, 3), "unit": "GF/s", "ms_per_step": round(t_s / n_s * 1e3, 5),
+                     "note": f"{n_s} factorisations back to back in bursts of {len(pool)} pre-filled arenas (re-fills between bursts outside the timed regions)"}
+        del pool
+    # dominant-kernel roofline: HIP events recorded by the library around every launch (and, sharded, around the RCCL exchange and
+    # broadcasts), on the stream they run on, in a separate pass over pre-filled arenas -- the SAME call as the timed step
     refill()
+    fence()
     dev.set_timing(1)
     reps = min(n_arenas, 20)
     for a in arenas[:reps]:
-        if mixed:
-            dev.factor_f32(a, stream)
-        else:
-            dev.factor(a, stream) if world == 1 else dev.factor_levels(a, plan.levels - 1, split, stream)
+        step(a)
     dev.sync(stream)
-    timing = dev.get_timing()
+    timing = dev.get_timing_ex()
     dev.set_timing(0)
     ev_ms = dev.event_overhead_ms(stream)  # what an empty (record, record) pair reads on this stream
+    rccl_ranks = comm.count() if comm is not None else None
+    timing_all = [timing]
+    if world > 1:
+        timing_all = [None] * world
+        dist.all_gather_object(timing_all, timing)
 
     if rank == 0:
         calls, flops = plan.counts()
-        kinds = {"potrf": float(flops[0]), "trsm": float(flops[1]), "update": float(flops[2] + flops[3]), "other": float(plan.flops)}
-        # the fp64 library fuses the POTRF and TRSM of a column-block step into one launch (k_potrf_trsm), timed as
-        # "potrf"; separate TRSM launches exist in the fp32 schedule (and with option fuse = 0)
-        program = timing["other"][1] > 0  # the whole factorisation as ONE launch (k_program), timed as "other"
-        fused = timing["trsm"][1] == 0
-        if fused:
-            kinds["potrf"] += kinds["trsm"]
-        # dense-panel bytes of those launches: every pivot block and every filled ancestor row of its panel read and
-        # written once, the pivot once more by the strips solving against it
-        eb = 4.0 if mixed else 8.0
         blocks = plan.blocks
         sizes = {int(b[1]): int(b[4] - b[2] + 1) for b in blocks if b[0] == b[1]}
-        piv_entries = sum(n * (n + 1) // 2 for n in sizes.values())
-        anc_entries = sum(int(b[4] - b[2] + 1) * sizes[int(b[1])] for b in blocks if b[0] != b[1])
-        panel_bytes = {"potrf": 2 * eb * piv_entries + (2 * eb * anc_entries + eb * piv_entries if fused else 0.0),
-                       "trsm": 2 * eb * anc_entries + eb * piv_entries, "update": None, "other": 2 * eb * (piv_entries + anc_entries)}
-        dom = max(("potrf", "trsm", "update", "other"), key=lambda k: timing[k][0])
-        ms, n_launch = timing[dom]
-        launches_per_factor = n_launch / reps
-        # launch duration: HIP events around every launch on the launch stream, minus the empty-pair reading (the event
-        # commands themselves); the committed rocprofv3 --kernel-trace --stats of this command is the cross-check
-        avg_s_raw = ms / max(n_launch, 1) * 1e-3
-        avg_s = max(avg_s_raw - ev_ms * 1e-3, 1e-9)
-        flops_per_launch = kinds[dom] / max(launches_per_factor, 1) if world == 1 else None
-        achieved = (flops_per_launch / avg_s * 1e-12) if flops_per_launch else None
-        peak = PEAK_FP32_TFLOPS if mixed else PEAK_FP64_TFLOPS
-        value = plan.flops * K / dt * 1e-9
-        if mixed:
-            names = {"potrf": "k32_potrf", "trsm": "k32_trsm", "update": "k32_update_mt + k32_update"}
-        else:
-            names = {"potrf": "k_potrf_trsm" if fused else "k_potrf_rr", "trsm": "k_trsm_rr", "update": "k_update_mt + k_update" if generated else "k_update", "other": "k_program"}
-        prof = profile_numbers(names[dom].split(" + ")[0], args.case, mixed, args.option)
-        out = {
-            "metric": "fp64 factorization GF/s (numeric level loop, F_ref flops) on 3-D Laplacian" if not mixed else
-                      "fp32 factorization GF/s (numeric level loop, F_ref flops) on 3-D Laplacian; solution refined to fp64 accuracy",
-            "value": round(value, 3), "unit": "GF/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32 factor + f64 iterative refinement" if mixed else "f64",
+        kernel0 = benchline.kernel_names(mixed, generated, all(t["trsm"][1] == 0 for t in timing_all))[benchline.dominant(timing_all)[0]].split(" + ")[0]
+        rec = {
+            "world": world, "steps": K, "warmup": W, "dt_s": dt, "case": args.case, "generated": generated, "mixed": mixed,
+            "options": args.option, "info": list(info),
+            "plan": {"n": plan.n, "levels": plan.levels, "nsep": plan.nsep, "flops": plan.flops, "alg_bytes": plan.alg_bytes,
+                     "flops_by_kind": {"potrf": float(flops[0]), "trsm": float(flops[1]), "update": float(flops[2] + flops[3])},
+                     "piv_entries": sum(n * (n + 1) // 2 for n in sizes.values()),
+                     "anc_entries": sum(int(b[4] - b[2] + 1) * sizes[int(b[1])] for b in blocks if b[0] != b[1])},
+            "workload": (f"generated {gn}^3 7-point Laplacian, geometric nested dissection ({glv} levels, tile {gtile}), cholamd_generate_laplacian" if generated else
+                         f"tests/{args.case} (reference fixture: 7-point Laplacian, nested-dissection ordering from the fixture files)"),
             "data": "synthetic (generated Laplacian, ordering and clusters)" if generated else "reference fixture (matrix, ordering and cluster files from the reference's tests/, copied as data); no random data anywhere",
-            "config": {"workload": (f"generated {gn}^3 7-point Laplacian, geometric nested dissection ({glv} levels, tile {gtile}), cholamd_generate_laplacian" if generated else
-                                    f"tests/{args.case} (reference fixture: 7-point Laplacian, nested-dissection ordering from the fixture files)"),
-                       "n": plan.n, "levels": plan.levels, "separators": plan.nsep, "F_ref_flops": plan.flops,
-                       "B_alg_bytes": plan.alg_bytes, "parallelism": f"subtree-sharded x{world}, one RCCL all-reduce of the arena tail (cholamd_factor_sharded)" if world > 1 else "single GPU",
-                       "precision": args.precision, "options": args.option, "factor_info": list(info)},
-            "roofline": {"bound": "mfma", "kernel": names[dom], "achieved": None if achieved is None else round(achieved, 5),
-                         "peak": peak, "unit": "TFLOP/s",
-                         "frac": None if achieved is None else round(achieved / peak, 6),
-                         "traffic": prof.get("hbm_bytes_per_launch") if world == 1 else None,
-                         "traffic_note": "HBM bytes per launch of that kernel, (2*FETCH_SIZE + WRITE_SIZE)*1024 from the committed rocprofv3 --pmc passes of this command (" + prof.get("source", "no profile committed for this case") + "); to compare with alg_bytes_per_launch",
-                         "alg_bytes_per_launch": plan.alg_bytes / max(launches_per_factor, 1),
-                         "alg_bytes_note": "SURVEY 8(d): B_alg = 8 (nnz(tril A) + nnz(L)) per factorisation / launches of the kernel per factorisation; dense_panel_bytes_per_launch = what the dense panels (structural zeros included) make those launches move",
-                         "dense_panel_bytes_per_launch": (panel_bytes[dom] / max(launches_per_factor, 1)) if panel_bytes[dom] else None,
-                         "avg_launch_us": round(avg_s * 1e6, 2), "avg_launch_us_events_raw": round(avg_s_raw * 1e6, 2), "event_pair_overhead_us": round(ev_ms * 1e3, 2),
-                         "avg_launch_us_rocprof": prof.get("avg_launch_us"), "mfma_busy_frac_rocprof": prof.get("mfma_busy_frac"),
-                         "launches_per_step": launches_per_factor,
-                         "alg_flops_per_launch": flops_per_launch,
-                         "whole_step_frac_of_peak": round(value * 1e-3 / peak, 6),
-                         "fp64_mfma_sustained_measured": None if mixed else SUSTAINED_FP64_MFMA_TFLOPS,
-                         "fp64_mfma_sustained_note": None if mixed else "what a register-operand v_mfma_f64_16x16x4_f64 loop on all 256 CUs sustains here (scripts/mfma_peak.hip; profiles/r2/mfma_peak.txt): 64 % of `peak`; `frac` stays against `peak`",
-                         "whole_step_alg_GBs": round(plan.alg_bytes * K / dt * 1e-9, 3), "hbm_peak_GBs": PEAK_HBM_GBS,
-                         "kernel_ms_per_step_events_raw": {k: round(timing[k][0] / reps, 5) for k in ("potrf", "trsm", "update", "other")},
-                         "launch_structure": "one program launch per factorisation (resident workgroups, job queue, followers)" if program else "per level and column-block step: fused POTRF+TRSM launch + update launch(es)"},
+            "timing": [{k: list(v) for k, v in t.items()} for t in timing_all], "reps": reps, "event_pair_ms": ev_ms,
+            "rccl_ranks": rccl_ranks,
+            "exchange": ("one ncclReduce per owned column-block piece of the arena tail + ncclAllReduce of the replicated top (cholamd_factor_sharded)" if world > 1 else None),
+            "profile": profile_numbers(kernel0, args.case, mixed, args.option) if world == 1 else {},
+            "refinement": refine, "concurrent": concurrent, "sustained": sustained,
+            "fp64_mfma_sustained_measured": SUSTAINED_FP64_MFMA_TFLOPS,
+            "fp64_mfma_sustained_note": SUSTAINED_NOTE,
         }
-        if refine is not None:
-            out["config"]["refinement"] = refine
-        if concurrent is not None:
-            out["concurrent"] = concurrent
-        if world == 1 and not args.no_cpu_baseline and not generated:
-            out["cpu_baseline"] = cpu_baseline(files, plan.flops)
-        print(json.dumps(out))
+        if not args.no_cpu_baseline and not generated:  # rank 0's host, at every world size
+            rec["cpu_baseline"] = cpu_baseline(files, plan.flops)
+        print(json.dumps(benchline.assemble(rec)))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

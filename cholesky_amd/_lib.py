@@ -135,6 +135,8 @@ def load():
     L.cholamd_residual.argtypes = [vp, vp, vp, vp, C.POINTER(cd), vp]
     L.cholamd_device_set_timing.argtypes = [vp, ci]
     L.cholamd_device_get_timing.argtypes = [vp, vp, vp]
+    L.cholamd_device_get_timing_ex.argtypes = [vp, vp, vp]
+    L.cholamd_comm_count.argtypes = [vp, C.POINTER(ci)]
     L.cholamd_device_event_overhead.argtypes = [vp, vp, C.POINTER(C.c_float)]
     RP, FP = C.POINTER(Region), C.POINTER(Filled)
     L.cholamd_fused_dpotrf.argtypes = [RP, FP, ci, ci, ci, ci, vp]

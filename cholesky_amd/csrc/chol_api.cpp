@@ -340,10 +340,14 @@ extern "C" int cholamd_device_set_timing(cholamd_device *d, int on)
   d->tl.clear();
   return 0;
 }
-extern "C" int cholamd_device_get_timing(cholamd_device *d, float ms_by_kind[4], int launches_by_kind[4])
+// kinds: 0 potrf (+ fused trsm), 1 trsm, 2 update, 3 program launch, 4 extend-add exchange (RCCL), 5 broadcasts of the distributed top levels
+#define CHOL_TIMING_KINDS 8
+#define CHOL_TK_EXCHANGE 4
+#define CHOL_TK_BCAST 5
+extern "C" int cholamd_device_get_timing_ex(cholamd_device *d, float ms_by_kind[CHOL_TIMING_KINDS], int launches_by_kind[CHOL_TIMING_KINDS])
 {
   HIPCHK(hipSetDevice(d->dev));
-  for (int k = 0; k < 4; k++) { ms_by_kind[k] = 0.f; launches_by_kind[k] = 0; }
+  for (int k = 0; k < CHOL_TIMING_KINDS; k++) { ms_by_kind[k] = 0.f; launches_by_kind[k] = 0; }
   for (auto &t : d->tl) {
     HIPCHK(hipEventSynchronize(t.b));
     float ms = 0.f;
@@ -352,6 +356,14 @@ extern "C" int cholamd_device_get_timing(cholamd_device *d, float ms_by_kind[4],
     d->pool.push_back(t.a); d->pool.push_back(t.b);
   }
   d->tl.clear();
+  return 0;
+}
+extern "C" int cholamd_device_get_timing(cholamd_device *d, float ms_by_kind[4], int launches_by_kind[4])
+{ // the four compute kinds (the exchange kinds of a sharded run: cholamd_device_get_timing_ex)
+  float ms[CHOL_TIMING_KINDS]; int n[CHOL_TIMING_KINDS];
+  const int rc = cholamd_device_get_timing_ex(d, ms, n);
+  if (rc) return rc;
+  for (int k = 0; k < 4; k++) { ms_by_kind[k] = ms[k]; launches_by_kind[k] = n[k]; }
   return 0;
 }
 
@@ -406,6 +418,7 @@ static int factor_levels_comm(cholamd_device *d, double *d_arena, int level_hi, 
     const level_dev &l = d->lv[lvl];
     for (const chol_phase &ph : l.phase) {
       if (ph.kind == 6) {
+        scoped_timer t(d, st, CHOL_TK_BCAST, ph.n > 0);
         int rc = bcast_rank(d, l, ph, d_arena, c, st);
         if (rc) return rc;
         continue;
@@ -448,11 +461,12 @@ extern "C" int cholamd_device_program_trace(cholamd_device *d, double *d_arena, 
   if (!d->prog_ready) { chol_set_error("no program launch for this problem / these options"); return CHOLAMD_ERR_ARG; }
   *njobs_out = d->n_job;
   if (cap < (int64_t)5 * d->n_job) return 0;
-  // 4 stamps per job, then 48 per job for the followers (own tiles in, items, the time each item's round began)
-  HIPCHK(hipMalloc((void **)&d->trace, (size_t)52 * d->n_job * sizeof(unsigned long long)));
-  HIPCHK(hipMemset(d->trace, 0, (size_t)52 * d->n_job * sizeof(unsigned long long)));
+  // 4 stamps per job, then CHOL_TRACE_X per job (chol_kernels.h)
+  const size_t nst = (size_t)(4 + CHOL_TRACE_X) * d->n_job;
+  HIPCHK(hipMalloc((void **)&d->trace, nst * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(d->trace, 0, nst * sizeof(unsigned long long)));
   int rc = cholamd_factor(d, d_arena, stream);
-  std::vector<unsigned long long> h((size_t)52 * d->n_job);
+  std::vector<unsigned long long> h(nst);
   if (!rc) {
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     HIPCHK(hipMemcpy(h.data(), d->trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -470,10 +484,20 @@ extern "C" int cholamd_device_program_trace(cholamd_device *d, double *d_arena, 
   if (const char *path = getenv("CHOLAMD_TRACE_FOLLOW")) { // diagnostic: the followers' per-item stamps as text (us since the first job was drawn)
     if (FILE *fp = fopen(path, "w")) {
       for (int j = 0; j < d->n_job; j++) {
-        const unsigned long long *x = &h[(size_t)4 * d->n_job + (size_t)48 * j];
-        if (d->jobs_host[j].kind != 0 || x[1] == 0) continue;
-        fprintf(fp, "job %d items %llu own-tiles-wait-over %.1f rounds:", j, x[1], x[0] ? (double)(x[0] - t0) * 0.01 : -1.0);
-        for (unsigned long long i = 0; i < x[1] && i < 44; i++) if (x[2 + i]) fprintf(fp, " %llu:%.1f", i, (double)(x[2 + i] - t0) * 0.01);
+        const unsigned long long *x = &h[(size_t)4 * d->n_job + (size_t)CHOL_TRACE_X * j];
+        const int kind = d->jobs_host[j].kind;
+        bool any = false;
+        for (int i = 0; i < CHOL_TRACE_X; i++) any = any || x[i] != 0;
+        if (kind == 2 || !any) continue;
+        fprintf(fp, "job %d kind %d", j, kind);
+        if (kind == 0 && x[1]) {
+          fprintf(fp, " items %llu own-tiles-wait-over %.1f rounds:", x[1], x[0] ? (double)(x[0] - t0) * 0.01 : -1.0);
+          for (unsigned long long i = 0; i < x[1] && i < 44; i++) if (x[2 + i]) fprintf(fp, " %llu:%.1f", i, (double)(x[2 + i] - t0) * 0.01);
+        }
+        fprintf(fp, kind == 0 ? " | column started:" : " | POTRF column seen:");
+        for (int k = 0; k < 24; k++) if (x[72 + k]) fprintf(fp, " %d:%.1f", k, (double)(x[72 + k] - t0) * 0.01);
+        fprintf(fp, kind == 0 ? " | column published:" : " | column tile on the channel:");
+        for (int k = 0; k < 24; k++) if (x[48 + k]) fprintf(fp, " %d:%.1f", k, (double)(x[48 + k] - t0) * 0.01);
         fprintf(fp, "\n");
       }
       fclose(fp);
@@ -1351,6 +1375,15 @@ extern "C" int cholamd_comm_adopt(void *nccl_comm, int world, int rank, cholamd_
   *out = c;
   return 0;
 }
+extern "C" int cholamd_comm_count(const cholamd_comm *c, int *ranks_out)
+{ // ncclCommCount of the RCCL communicator behind the handle (a local communicator: its rank objects)
+  if (!c) { chol_set_error("null communicator"); return CHOLAMD_ERR_ARG; }
+  if (!c->comm) { *ranks_out = c->local ? c->local->n : 0; return 0; }
+  int n = 0;
+  NCCLCHK(ncclCommCount(c->comm, &n));
+  *ranks_out = n;
+  return 0;
+}
 extern "C" void cholamd_comm_destroy(cholamd_comm *c)
 {
   if (!c) return;
@@ -1416,7 +1449,10 @@ extern "C" int cholamd_factor_sharded(cholamd_device *d, double *d_arena, cholam
   const int L = d->plan->levels, split = chol_split_level(d->world);
   if (d->world == 1) return cholamd_factor(d, d_arena, stream);
   int rc = cholamd_factor_levels(d, d_arena, L - 1, split, stream);
-  if (!rc) rc = cholamd_exchange_tail(d, d_arena, c, stream);
+  if (!rc) {
+    scoped_timer t(d, (hipStream_t)stream, CHOL_TK_EXCHANGE, true);
+    rc = cholamd_exchange_tail(d, d_arena, c, stream);
+  }
   if (!rc) rc = factor_levels_comm(d, d_arena, split - 1, 0, c, (hipStream_t)stream);
   return rc;
 }

@@ -42,6 +42,10 @@ int chol32_launch_solve_trsv(const float *base, const chol_trsv_desc *descs, int
 int chol32_launch_solve_offdiag(const float *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st);
 int chol_launch_residual(const int64_t *ptr, const int *col, const double *val, const double *b, const double *x, double *r, int n, double *partial, hipStream_t st);
 int chol_launch_axpy1(double *x, const double *dx, int n, hipStream_t st);
+/* diagnostic instance of the program launch (k_program<true>): 4 stamps per job, then CHOL_TRACE_X per job -- [0] follower: own tiles' wait over,
+ * [1] its items, [2 + i] round of item i begun; [48 + k] POTRF job: column k published / TRSM job (first strip): column tile k on its channel;
+ * [72 + k] POTRF job: the factor wave starts column k / TRSM job: the POTRF's column k seen */
+#define CHOL_TRACE_X 96
 #ifdef __cplusplus
 }
 #endif

@@ -915,7 +915,7 @@ __device__ __forceinline__ int ext_ready(const follow_args &f, int from, int lan
   const int lead = notok ? __builtin_ctzll(notok) : 64;
   return min(from + lead, f.n_ext);
 }
-template <bool UPD, bool PUB>
+template <bool UPD, bool PUB, bool TR = false>
 __device__ __forceinline__ void follow_external(const double *__restrict__ base, const follow_args f, int T, int n, double *sE, d4 (&tile)[11], d4 (&stage)[3],
                                                 const int (&ijp)[12], int w, int lane, int tid, int *info, const double *A, int lda, int r15, int g, int *sReady)
 { // sReady: LDS word (0 at entry): leading items the factor wave has seen published
@@ -980,7 +980,7 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
   {                                                                                                                  \
  /* the follower's own tiles, before the last two followed column tiles (their round trip hides behind the wait for those) */ \
       if (!UPD) wait_list<FOLLOW_OWN_SLEEP>(f.wl, f.n_wl, f.ctr, f.ctr_total, f.epoch, lane, info); /* the factor wave polls: a follower waiting for its own tiles IS on the critical path */ \
-      if (!UPD && f.xstamp && lane == 0) f.xstamp[0] = __builtin_amdgcn_s_memrealtime(); \
+      if (TR && !UPD && f.xstamp && lane == 0) f.xstamp[0] = __builtin_amdgcn_s_memrealtime(); \
       lds_barrier(); \
       if (UPD) { \
         int rx = r15, gx = g; /* opaque here: the addresses of these loads are invariant in the loop around them, and hoisting them spills */ \
@@ -1029,7 +1029,7 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
       EXT_LOAD_ROUND(i);
     }
     const int G = ng;
-    if (!UPD && f.xstamp && lane == 0 && i < 44) { f.xstamp[1] = f.n_ext; f.xstamp[2 + i] = __builtin_amdgcn_s_memrealtime(); }
+    if (TR && !UPD && f.xstamp && lane == 0 && i < 44) { f.xstamp[1] = f.n_ext; f.xstamp[2 + i] = __builtin_amdgcn_s_memrealtime(); }
     double *sB = sE + buf * (RR_MAXT * TS * TS), *sB2 = sB + T * TS * TS;
 #pragma unroll
     for (int it = 0; it < FOLLOW_LOADS; ++it) {
@@ -1075,7 +1075,7 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
 #undef EXT_LOAD
 }
 
-template <bool PUB, bool FOLLOW = false>
+template <bool PUB, bool FOLLOW = false, bool TR = false>
 __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double *__restrict__ ws, const chol_potrf_desc d, int *__restrict__ info,
                                               int *__restrict__ progress, int progress_base, double *smem, const unsigned char *__restrict__ sky, const follow_args fa = follow_args(), const int tid = threadIdx.x)
 { // sky: the descriptor's skyline in global memory (indexed per tile: a by-value copy would go to scratch)
@@ -1150,9 +1150,9 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
     if (FOLLOW && fa.n_ext > 0) { // loads and barriers of the external panel steps (it owns no tile)
       d4 tdummy[RR_RSLOTS], sdummy[3];
       int idummy[RR_SLOTS];
-      follow_external<false, PUB>(base, fa, T, n, smem + RR_OFF_SOL, tdummy, sdummy, idummy, 0, lane, tid, info, A, lda, r15, g, &sFlag[5]);
+      follow_external<false, PUB, TR>(base, fa, T, n, smem + RR_OFF_SOL, tdummy, sdummy, idummy, 0, lane, tid, info, A, lda, r15, g, &sFlag[5]);
       lds_barrier(); // the last panel has been read: the prologue may park column 1 in its place
-      if (fa.stamp && lane == 0) *fa.stamp = __builtin_amdgcn_s_memrealtime(); // diagnostic runs: the followed columns are in
+      if (TR && fa.stamp && lane == 0) *fa.stamp = __builtin_amdgcn_s_memrealtime(); // diagnostic build (k_program<true>): the followed columns are in
     }
     __builtin_amdgcn_s_setprio(3);
     lds_wait_ge(cUpd, RR_NW); // prologue of the tile waves done: (0,0), (1,1) are in sDg, column 0 in sRaw
@@ -1172,6 +1172,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
 #pragma unroll
       for (int c = 0; c < TS; ++c) a[c] = sConv[lane & 31][c];
       STAMPK(1);
+      if (TR && fa.xstamp && lane == 0 && k < 24) fa.xstamp[72 + k] = __builtin_amdgcn_s_memrealtime(); // diagnostic build: the factor wave starts column k
       const int bad = chol16_rows(a, unused, r15);
       STAMPK(2);
       if (bad && k * TS + bad <= n && lane == 0) {
@@ -1255,7 +1256,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
         if (early && ijp[s] != 0xffff) v = load_tile<PUB>(A, lda, n, ijp[s] & 0xff, ijp[s] >> 8, r15, g);
         tile[s] = v;
       }
-      follow_external<true, PUB>(base, fa, T, n, smem + RR_OFF_SOL, tile, stage, ijp, w, lane, tid, info, A, lda, r15, g, &sFlag[5]);
+      follow_external<true, PUB, TR>(base, fa, T, n, smem + RR_OFF_SOL, tile, stage, ijp, w, lane, tid, info, A, lda, r15, g, &sFlag[5]);
 #pragma unroll
       for (int s = FOLLOW_SLOTS; s < RR_RSLOTS; ++s) tile[s] = zero4; // not live across the followed columns
       lds_barrier();
@@ -1442,7 +1443,10 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
         int old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(cUpd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         old = __builtin_amdgcn_readfirstlane(old);
-        if (old + 1 == RR_NW * (k + 2) && lane == 0) __hip_atomic_store(progress, progress_base + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == RR_NW * (k + 2) && lane == 0) {
+          __hip_atomic_store(progress, progress_base + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (TR && fa.xstamp && k < 24) fa.xstamp[48 + k] = __builtin_amdgcn_s_memrealtime(); // diagnostic build: column k published
+        }
       } else {
         lds_inc(cUpd, lane);
       }
@@ -1599,10 +1603,10 @@ __global__ __launch_bounds__(64) void k_dinv(const double *__restrict__ Lp, int 
 // BAND (program launch, a banded leaf pivot factored as ONE block of up to CHOL_RR_MAXN columns): tile (J2, J) of the block's L is zero for
 // J2 - J > d.band (<= 4), so step J touches at most one tile per wave (J2 = wave mod 4 within (J, J + band]): the L prefetch ring
 // holds ONE tile per step instead of one per slot -- what lets a strip of seventeen column tiles fit the registers.
-template <bool PUB, int SLOTS, bool BAND = false>
+template <bool PUB, int SLOTS, bool BAND = false, bool TR = false>
 __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const double *__restrict__ ws, const chol_trsm_desc d, double (*sX)[TS * TS],
                                              int wave, int lane, const int *__restrict__ progress, int progress_base, int *__restrict__ info,
-                                             int *__restrict__ chan = nullptr)
+                                             int *__restrict__ chan = nullptr, unsigned long long *xst = nullptr)
 { // chan (program launch): the strip's rows are followed by a POTRF workgroup -- counter chan[J] is raised once column tile J
   // of the strip has been stored (follow_external)
   const double *Lm = base + d.l_off;
@@ -1617,8 +1621,11 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
 #define LS(s_) (BAND ? 0 : (s_))
 
   d4 tile[SLOTS];
-  int64_t voff[SLOTS]; // lane part of the address of L(J2 * 16 + r15, g): rows past n are clamped (their
-                            // products only reach output columns >= n, which are never stored)
+  // lane part of the address of L(J2 * 16 + r15, g): rows past n are clamped (their products only reach output columns >= n, which are
+  // never stored).  Recomputed where it is used (two VALU instructions): kept as a per-slot array the band form's seventeen column
+  // tiles pushed two of these 64-bit values into scratch, reloaded in every step of the leaf strips
+  const int64_t gld = (int64_t)g * ldl;
+#define VOFF(J2_) ((int64_t)min((J2_) * TS + r15, n - 1) + gld)
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     const int J = wave + 4 * s;
@@ -1631,7 +1638,6 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
       }
     }
     tile[s] = v;
-    voff[s] = min(J * TS + r15, n - 1) + (int64_t)g * ldl;
   }
   // L tiles (J2, J) of the updates of step J (uniform branch per slot, one scalar base per step)
 #define LOAD_L(J_, buf_)                                                                                \
@@ -1641,7 +1647,7 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
     _Pragma("unroll") for (int s = 0; s < SLOTS; ++s) {                                            \
       const int J2_ = wave + 4 * s;                                                                     \
       if (J2_ > (J_) && J2_ < T && J2_ <= (J_) + bw) {                                                  \
-        _Pragma("unroll") for (int st = 0; st < 4; ++st) buf_[LS(s)][st] = gload<PUB>(&lb_[voff[s] + (int64_t)(4 * st) * ldl]); \
+        _Pragma("unroll") for (int st = 0; st < 4; ++st) buf_[LS(s)][st] = gload<PUB>(&lb_[VOFF(J2_) + (int64_t)(4 * st) * ldl]); \
       }                                                                                                 \
     }                                                                                                   \
   }
@@ -1660,6 +1666,7 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
     if (PUB && chan && m > 0) { /* this wave stored the whole column tile: tell the follower once it has landed */ \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
       if (lane == 0) __hip_atomic_fetch_add(&chan[J_], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  \
+      if (TR && xst && lane == 0 && (J_) < 24) xst[48 + (J_)] = __builtin_amdgcn_s_memrealtime(); /* diagnostic build: column tile J_ published */ \
     }                                                                                                   \
   }
 #define APPLY_X(JX_, s_)                                                                                \
@@ -1672,22 +1679,25 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
   // operands are fetched two steps ahead; vmcnt retires in order, so the inverse the next solve waits
   // for is issued before the L tiles of the same step
   int seen = 0; // last progress value read (fused launch)
-  double lpre[3][BAND ? 1 : SLOTS][4], wpre[3][4];
+  // the inverse of column tile c is loaded by its owner (wave c mod 4) in step c - 2 and used in step c - 1: ONE buffer per wave (a ring
+  // of three, as for the L tiles, was 16 more registers that the band form's strips spilled -- with a vmcnt(0) behind every prefetch)
+  double lpre[3][BAND ? 1 : SLOTS][4], wpre[4];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) wpre[st] = 0.0;
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      wpre[u][st] = 0.0;
 #pragma unroll
       for (int s = 0; s < (BAND ? 1 : SLOTS); ++s) lpre[u][s][st] = 0.0;
     }
   }
-  if (wave == 0) LOAD_W(0, wpre[0]);
-  if (wave == 1 && 1 < T) LOAD_W(1, wpre[1]);
+  if (wave == 0) LOAD_W(0, wpre);
+  if (wave == 1 && 1 < T) LOAD_W(1, wpre);
   LOAD_L(0, lpre[0]);
   LOAD_L(1, lpre[1]);
   if (wave == 0) { // column tile 0 has no predecessors
-    const d4 x = solve16(tile[0], wpre[0]);
+    const d4 x = solve16(tile[0], wpre);
     PUBLISH_X(0, x);
   }
   STAMP_DECL;
@@ -1704,7 +1714,7 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
         const int s1 = (J + 1) >> 2;
         if (s1 < SLOTS) {
           APPLY_X(J, s1);
-          const d4 x = solve16(tile[s1], wpre[(J + 1) % 3]);
+          const d4 x = solve16(tile[s1], wpre);
           tile[s1] = x;
           PUBLISH_X(J + 1, x);
         }
@@ -1724,7 +1734,7 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
       }
       STAMP(2);
       // prefetch for step J+2: buffer (J+2) % 3 == (J-1) % 3 is free (deferred work uses X_J / lpre[J % 3])
-      if ((J + 2 < T) && (((J + 2) & 3) == wave)) LOAD_W(J + 2, wpre[(J + 2) % 3]);
+      if ((J + 2 < T) && (((J + 2) & 3) == wave)) LOAD_W(J + 2, wpre);
       LOAD_L(J + 2, lpre[(J + 2) % 3]);
       STAMP(3);
     }
@@ -1735,6 +1745,7 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
 #undef PUBLISH_X
 #undef APPLY_X
 #undef LS
+#undef VOFF
 }
 
 __global__ __launch_bounds__(256) void k_trsm_rr(double *__restrict__ base, const double *__restrict__ ws,
@@ -1809,6 +1820,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_potrf_trsm(double *__restrict__ 
 // are ahead of it in the queue or for the strips of a source that the queue places within reach of the resident
 // workgroups (checked on the host: chol_program_check); every spin is bounded and fails the factorisation through info.
 // ------------------------------------------------------------------------------------------------
+template <bool TR>
 __global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ base, double *__restrict__ ws, const chol_job *__restrict__ jobs, int njobs,
                                                         const chol_wait *__restrict__ waits, const chol_potrf_desc *__restrict__ pdescs,
                                                         const chol_trsm_desc *__restrict__ tdescs, const chol_upd_task *__restrict__ tasks,
@@ -1833,7 +1845,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ bas
     const int j = s_job;
     if (j >= njobs) break; // every workgroup draws exactly one job index past the end: head advances by njobs + gridDim.x per launch
     const chol_job jb = jobs[j];
-    if (trace && tid == 0) { trace[4 * j] = __builtin_amdgcn_s_memrealtime(); trace[4 * j + 3] = blockIdx.x; }
+    if (TR && trace && tid == 0) { trace[4 * j] = __builtin_amdgcn_s_memrealtime(); trace[4 * j + 3] = blockIdx.x; }
     // ONE wave polls (hundreds of blocked workgroups are resident at a time: twelve polling waves each would sit on the L2 the
     // working jobs hand their data through); the others park at the barrier
     // A job is usually drawn long before it may run: what does not depend on the wait is fetched ahead of it -- the first
@@ -1850,20 +1862,22 @@ __global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ bas
       if (wave == 0) wait_list(waits + jb.wait_first, jb.n_pre, ctr, ctr_total, epoch, lane, info);
       lds_barrier();
     }
-    if (trace && tid == 0) trace[4 * j + 1] = __builtin_amdgcn_s_memrealtime(); // a follower overwrites it when its followed columns are in
+    if (TR && trace && tid == 0) trace[4 * j + 1] = __builtin_amdgcn_s_memrealtime(); // a follower overwrites it when its followed columns are in
     if (jb.kind == 0) {
       const chol_potrf_desc pd = pdescs[jb.first];
       follow_args fa;
-      fa.ext = exts + jb.ext_first; fa.n_ext = jb.n_ext; fa.ctr = ctr; fa.ctr_total = ctr_total; fa.epoch = epoch; fa.wl = waits + jb.wait_first; fa.n_wl = jb.n_wait; fa.stamp = trace ? &trace[4 * j + 1] : nullptr; fa.xstamp = trace ? &trace[4 * njobs + 48 * j] : nullptr;
-      potrf_rr_body<true, true>(base, ws, pd, info, ctr + pd.ctr, epoch * ctr_total[pd.ctr], smem, pdescs[jb.first].sky, fa, tid);
+      fa.ext = exts + jb.ext_first; fa.n_ext = jb.n_ext; fa.ctr = ctr; fa.ctr_total = ctr_total; fa.epoch = epoch; fa.wl = waits + jb.wait_first; fa.n_wl = jb.n_wait; fa.stamp = TR && trace ? &trace[4 * j + 1] : nullptr; fa.xstamp = TR && trace ? &trace[4 * njobs + CHOL_TRACE_X * j] : nullptr;
+      potrf_rr_body<true, true, TR>(base, ws, pd, info, ctr + pd.ctr, epoch * ctr_total[pd.ctr], smem, pdescs[jb.first].sky, fa, tid);
     } else if (jb.kind == 1) {
       double (*sX)[3][TS * TS] = (double (*)[3][TS * TS])smem;
       chol_trsm_desc d = tdescs[jb.first + min(grp, jb.n - 1)];
       if (grp >= jb.n) d.m = 0; // every group runs the same number of barriers: the strips of a job share one pivot block
       if (d.band > 0) // a banded leaf pivot factored as one block (up to CHOL_RR_MAXN columns: (CHOL_RR_MAXN / 16 + 3) / 4 column tiles per wave)
-        trsm_rr_body<true, (CHOL_RR_MAXN / TS + 3) / 4, true>(base, ws, d, sX[grp], wave & 3, lane, ctr + d.flag, epoch * ctr_total[d.flag], info, d.chan >= 0 ? ctr + d.chan : nullptr);
+        trsm_rr_body<true, (CHOL_RR_MAXN / TS + 3) / 4, true, TR>(base, ws, d, sX[grp], wave & 3, lane, ctr + d.flag, epoch * ctr_total[d.flag], info, d.chan >= 0 ? ctr + d.chan : nullptr,
+                                                                   TR && trace && grp == 0 ? &trace[4 * njobs + CHOL_TRACE_X * j] : nullptr);
       else
-        trsm_rr_body<true, FUSED_SLOTS>(base, ws, d, sX[grp], wave & 3, lane, ctr + d.flag, epoch * ctr_total[d.flag], info, d.chan >= 0 ? ctr + d.chan : nullptr);
+        trsm_rr_body<true, FUSED_SLOTS, false, TR>(base, ws, d, sX[grp], wave & 3, lane, ctr + d.flag, epoch * ctr_total[d.flag], info, d.chan >= 0 ? ctr + d.chan : nullptr,
+                                                   TR && trace && grp == 0 ? &trace[4 * njobs + CHOL_TRACE_X * j] : nullptr);
     } else {
       stage_waits sw;
       sw.w = waits + jb.wait_first + jb.n_pre; sw.n = jb.n_wait - jb.n_pre; sw.ctr = ctr; sw.ctr_total = ctr_total; sw.epoch = epoch; sw.info = info;
@@ -1890,7 +1904,7 @@ __global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ bas
         if (jb.sig[1] >= 0) __hip_atomic_fetch_add(&ctr[jb.sig[1]], jb.sig_add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    if (trace && tid == 0) trace[4 * j + 2] = __builtin_amdgcn_s_memrealtime();
+    if (TR && trace && tid == 0) trace[4 * j + 2] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -2685,7 +2699,9 @@ int chol_launch_program(double *base, double *ws, const chol_job *jobs, int njob
                         int grid, int *info, int *info_next, unsigned long long *trace, hipStream_t st)
 {
   if (njobs <= 0) return 0;
-  hipLaunchKernelGGL(k_program, dim3(grid), dim3(RR_THREADS), 0, st, base, ws, jobs, njobs, waits, pdescs, tdescs, tasks, srcs, exts, ctr, ctr_total, epoch, head, head_base, info, info_next, trace);
+  // the product kernel carries no stamp code (k_program<false>); the per-job stamps of cholamd_device_program_trace run the diagnostic instance
+  if (trace) hipLaunchKernelGGL(k_program<true>, dim3(grid), dim3(RR_THREADS), 0, st, base, ws, jobs, njobs, waits, pdescs, tdescs, tasks, srcs, exts, ctr, ctr_total, epoch, head, head_base, info, info_next, trace);
+  else hipLaunchKernelGGL(k_program<false>, dim3(grid), dim3(RR_THREADS), 0, st, base, ws, jobs, njobs, waits, pdescs, tdescs, tasks, srcs, exts, ctr, ctr_total, epoch, head, head_base, info, info_next, trace);
   return (int)hipGetLastError();
 }
 int chol_launch_trsm_w(double *base, const double *ws, const chol_trsm_desc *descs, int n, hipStream_t st)

@@ -158,6 +158,13 @@ class Device:
         check(self.L.cholamd_device_get_timing(self.h, ms.ctypes.data, cnt.ctypes.data), "get_timing")
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KINDS)}
 
+    def get_timing_ex(self):
+        """The compute kinds plus the exchange kinds of a sharded run (cholamd_device_get_timing_ex)."""
+        ms = np.zeros(8, dtype=np.float32)
+        cnt = np.zeros(8, dtype=np.int32)
+        check(self.L.cholamd_device_get_timing_ex(self.h, ms.ctypes.data, cnt.ctypes.data), "get_timing_ex")
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KINDS + ("exchange", "bcast"))}
+
 
 class Comm:
     """An RCCL communicator owned by libcholamd (cholamd_comm_create: ncclCommInitRank on the device's GPU)."""
@@ -174,6 +181,12 @@ class Comm:
         buf = C.create_string_buffer(128)
         check(load().cholamd_comm_unique_id(buf), "cholamd_comm_unique_id")
         return bytes(buf.raw)
+
+    def count(self):
+        """ncclCommCount of the communicator behind the handle."""
+        n = C.c_int(0)
+        check(self.L.cholamd_comm_count(self.h, C.byref(n)), "cholamd_comm_count")
+        return int(n.value)
 
     def allreduce(self, t, stream=None):
         """In-place fp64 sum of a CUDA tensor over the ranks (cholamd_comm_allreduce)."""

@@ -322,6 +322,9 @@ int cholamd_residual(cholamd_device *d, const double *d_b, const double *d_x, do
  * with HIP events on its stream; valid after cholamd_device_sync.  Enable with set_timing(1). */
 int cholamd_device_set_timing(cholamd_device *d, int on);
 int cholamd_device_get_timing(cholamd_device *d, float ms_by_kind[4], int launches_by_kind[4]);
+/* the same with the kinds of a sharded run: [0..3] as above (POTRF (+ fused TRSM), TRSM, update, program launch), [4] the RCCL
+ * extend-add exchange, [5] the grouped ncclBroadcasts of the distributed top levels, [6..7] unused */
+int cholamd_device_get_timing_ex(cholamd_device *d, float ms_by_kind[8], int launches_by_kind[8]);
 /* mean elapsed time (ms) of an event pair with nothing between them on `stream`: the part of every timed launch
  * above that is the event commands, not the kernel */
 int cholamd_device_event_overhead(cholamd_device *d, void *stream, float *ms_out);
@@ -349,6 +352,7 @@ int cholamd_comm_create_all(cholamd_device *const *devs, int n, cholamd_comm **o
  * The ranks may share a device (the one-GPU test box runs world 2 ... 8 this way).  For cholamd_factor_multi only. */
 int cholamd_comm_create_local(cholamd_device *const *devs, int n, cholamd_comm **out /* n handles */);
 int cholamd_comm_adopt(void *nccl_comm /* ncclComm_t */, int world, int rank, cholamd_comm **out);  /* the caller keeps ownership of the ncclComm_t */
+int cholamd_comm_count(const cholamd_comm *c, int *ranks_out); /* ncclCommCount: the ranks the communicator really joins */
 void cholamd_comm_destroy(cholamd_comm *c);
 int cholamd_comm_allreduce(cholamd_comm *c, double *d_buf, int64_t count, void *stream); /* in-place fp64 sum (ncclAllReduce), asynchronous on `stream` */
 int64_t cholamd_device_tail_offset(const cholamd_device *d);    /* first double of the shared top of the tree in the arena (arena size if world == 1) */

@@ -22,15 +22,17 @@ __global__ __launch_bounds__(256) void k_peak8(double *out, int iters, double a0
   d4 c[8];
   for (int q = 0; q < 8; ++q) c[q] = (d4){0, 0, 0, 0};
   double a = a0 + threadIdx.x * 1e-9, b = 1.0 - a;
-  const unsigned long long t0 = __builtin_readcyclecounter();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int i = 0; i < iters; ++i) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) c[q] = __builtin_amdgcn_mfma_f64_16x16x4f64((q & 1) ? a : b, (q & 2) ? a : b, c[q], 0, 0, 0);
   }
-  const unsigned long long t1 = __builtin_readcyclecounter();
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   double sum = 0; for (int q = 0; q < 8; ++q) sum += c[q][q & 3];
   out[blockIdx.x * 256 + threadIdx.x] = sum;
-  if (blockIdx.x == 0 && threadIdx.x == 0) clk[0] = t1 - t0;
+  // stamps of one wave of a workgroup in the MIDDLE of the grid (it runs beside a full chip): shader cycles (s_memtime) and the
+  // 100 MHz real-time clock (s_memrealtime) over the loop: in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz
+  if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
 typedef float f16v __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void k_peak32(float *out, int iters, float a0)
@@ -67,15 +69,20 @@ int main(int argc, char **argv)
     const double flops = (double)wgs * 4 * iters * 4 * 4096.0;
     printf("fp32 v_mfma_f32_32x32x2_f32, 4 accumulators: %.3f ms, %.1f TF/s\n", ms, flops / ms * 1e-9);
   }
-  unsigned long long *dc; hipMalloc(&dc, 8);
+  unsigned long long *dc; hipMalloc(&dc, 16);
+  int occ = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_peak8, 256, 0);
+  printf("k_peak8: %d workgroups of 4 waves resident per CU (occupancy API) = %d waves per SIMD\n", occ, occ);
   for (int rep = 0; rep < 2; rep++) {
     hipEventRecord(e0);
     hipLaunchKernelGGL(k_peak8, dim3(wgs), dim3(256), 0, 0, d, iters / 2, 0.25, dc);
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    unsigned long long c; hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
-    const double flops = (double)wgs * 4 * (iters / 2) * 8 * 2048.0;
-    printf("8 accumulators: %.3f ms, %.1f TF/s fp64; wave 0 of workgroup 0: %.1f s_memtime ticks per MFMA of its own (x 4 waves per SIMD)\n", ms, flops / ms * 1e-9, (double)c / ((double)(iters / 2) * 8));
+    unsigned long long c[2]; hipMemcpy(c, dc, 16, hipMemcpyDeviceToHost);
+    const double flops = (double)wgs * 4 * (iters / 2) * 8 * 2048.0, nm = (double)(iters / 2) * 8;
+    const double ghz = (double)c[0] / (double)c[1] * 0.1; // shader cycles per 10 ns tick
+    const double per_simd_ns = 1024.0 * 2048.0 / (flops / ms * 1e-6) * 1e0; // ns per MFMA and SIMD at the measured chip rate (1024 SIMDs)
+    printf("8 accumulators: %.3f ms, %.1f TF/s fp64; one wave mid-grid: %.1f shader cycles (s_memtime) = %.1f ns (s_memrealtime) per MFMA of its own -> in-kernel clock %.3f GHz; "
+           "chip rate = one MFMA per %.1f ns and SIMD = %.1f cycles at that clock\n", ms, flops / ms * 1e-9, (double)c[0] / nm, (double)c[1] * 10.0 / nm, ghz, per_simd_ns, per_simd_ns * ghz);
   }
   return 0;
 }
