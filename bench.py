@@ -189,8 +189,6 @@ def main():
         comm = parallel.make_comm(dev, world, rank)  # libcholamd's own RCCL communicator (unique id broadcast by the process group)
 
     mixed = args.precision == "mixed"
-    if mixed and world > 1:
-        sys.exit("bench.py: --precision mixed is a single-GPU path")
     K, W = args.steps, args.warmup
     stream = torch.cuda.current_stream()
     per_arena = plan.arena_doubles * (4 if mixed else 8)
@@ -206,7 +204,9 @@ def main():
     def step(a):
         # world > 1: local subtree levels, ONE RCCL all-reduce of the arena tail (extend-add
         # contributions to the shared ancestors), then the top levels
-        if mixed:
+        if mixed and world > 1:
+            dev.factor_sharded_f32(a, comm, stream)  # fp32 schedule sharded like the fp64 one; exchange and broadcasts on floats
+        elif mixed:
             dev.factor_f32(a, stream)
         else:
             parallel.factor_sharded(dev, a, world, tail_off, stream, comm=comm)
@@ -264,7 +264,11 @@ def main():
     # dominant-kernel roofline: HIP events recorded by the library around every launch, on the
     # stream the kernels run on, in a separate pass over pre-filled arenas
     refine = None
-    if mixed:  # the other half of the configuration: one right-hand side solved to fp64 accuracy with the fp32 factor
+    if mixed and world > 1:  # the complete fp32 factor on rank 0 (the subtree panels of the other ranks travel there), refined there
+        last = arenas[(done + K - 1) % n_arenas] if K <= n_arenas else arenas[(K - 1) % n_arenas]
+        dev.gather_to_root(last, comm, stream)
+        fence()
+    if mixed and rank == 0:  # the other half of the configuration: one right-hand side solved to fp64 accuracy with the fp32 factor
         if generated:
             bvec = torch.from_numpy(ca.Problem(gn, gn, gn, glv, gtile).rhs()).cuda()
         else:
@@ -340,6 +344,7 @@ def main():
     dev.set_timing(0)
     ev_ms = dev.event_overhead_ms(stream)  # what an empty (record, record) pair reads on this stream
     rccl_ranks = comm.count() if comm is not None else None
+    xvol, eb_x = dev.exchange_volume(), (4 if mixed else 8)
     timing_all = [timing]
     if world > 1:
         timing_all = [None] * world
@@ -362,7 +367,10 @@ def main():
             "data": "synthetic (generated Laplacian, ordering and clusters)" if generated else "reference fixture (matrix, ordering and cluster files from the reference's tests/, copied as data); no random data anywhere",
             "timing": [{k: list(v) for k, v in t.items()} for t in timing_all], "reps": reps, "event_pair_ms": ev_ms,
             "rccl_ranks": rccl_ranks,
-            "exchange": ("one ncclReduce per owned column-block piece of the arena tail + ncclAllReduce of the replicated top (cholamd_factor_sharded)" if world > 1 else None),
+            "exchange": (None if world == 1 else
+                         f"owner-directed exchange of the arena tail: {xvol[3]} column blocks, grouped ncclSend / ncclRecv to their owners + rank-ordered sum "
+                         f"(rank 0 receives {xvol[0] * eb_x / 1e6:.2f} MB, sends {xvol[1] * eb_x / 1e6:.2f} MB of a {xvol[2] * eb_x / 1e6:.2f} MB tail)" if xvol[3] > 0 else
+                         f"one in-place ncclAllReduce of the {xvol[2] * eb_x / 1e6:.2f} MB arena tail (top levels replicated)"),
             "profile": profile_numbers(kernel0, args.case, mixed, args.option) if world == 1 else {},
             "refinement": refine, "concurrent": concurrent, "sustained": sustained,
             "fp64_mfma_sustained_measured": SUSTAINED_FP64_MFMA_TFLOPS,

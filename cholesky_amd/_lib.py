@@ -116,6 +116,12 @@ def load():
     L.cholamd_device_tail_offset.restype = i64
     L.cholamd_exchange_tail.argtypes = [vp, vp, vp, vp]
     L.cholamd_factor_sharded.argtypes = [vp, vp, vp, vp]
+    L.cholamd_factor_sharded_f32.argtypes = [vp, vp, vp, vp]
+    L.cholamd_gather_to_root.argtypes = [vp, vp, ci, vp, vp]
+    L.cholamd_exchange_volume.argtypes = [vp, vp]
+    L.cholamd_plan_exchange_volume.argtypes = [vp, ci, ci, ci, vp]
+    L.cholamd_factor_multi_f32.argtypes = [vp, vp, vp, ci, vp]
+    L.cholamd_gather_factor_f32.argtypes = [vp, vp, ci, vp]
     L.cholamd_device_alloc.argtypes = [vp, i64, C.POINTER(vp)]
     L.cholamd_device_free.argtypes = [vp, vp]
     L.cholamd_device_upload.argtypes = [vp, vp, vp, i64, vp]
@@ -136,6 +142,7 @@ def load():
     L.cholamd_device_set_timing.argtypes = [vp, ci]
     L.cholamd_device_get_timing.argtypes = [vp, vp, vp]
     L.cholamd_device_get_timing_ex.argtypes = [vp, vp, vp]
+    L.cholamd_device_bcast_phases.argtypes = [vp]
     L.cholamd_comm_count.argtypes = [vp, C.POINTER(ci)]
     L.cholamd_device_event_overhead.argtypes = [vp, vp, C.POINTER(C.c_float)]
     RP, FP = C.POINTER(Region), C.POINTER(Filled)

@@ -74,6 +74,8 @@ struct cholamd_device {
   float *ws32 = nullptr;
   int64_t *csr_ptr = nullptr; int *csr_col = nullptr; double *csr_val = nullptr;
   double *rvec = nullptr, *dxvec = nullptr, *partial = nullptr;
+  // extend-add exchange under the distributed top levels: staging of the copies received for the owned column blocks, descriptors of the sum
+  void *xstage = nullptr; size_t xstage_bytes = 0; void *xdesc = nullptr; int xdesc_gen = -1, xdesc_elem = 0, sched_gen = 0;
   // switches, read from the environment once at cholamd_device_create (cholamd_device_set_option changes them later)
   chol_sched_opts opt;
   bool solve_reference_shape = false; // cholamd_solve with the per-call (deterministic) kernels of the BLAS-level entry points
@@ -133,6 +135,7 @@ static int upload_level(level_dev &l, const chol_level_work &w)
 static int build_levels(cholamd_device *d)
 {
   free_levels(d);
+  d->sched_gen++;
   const int L = d->plan->levels;
   d->lv.resize(L);
   for (int lvl = 0; lvl < L; lvl++) {
@@ -148,7 +151,12 @@ static int build_levels(cholamd_device *d)
   if (d->world == 1 && d->opt.program) {
     chol_level_work w;
     chol_program g;
-    if (chol_build_program(d->plan, &d->opt, &w, &g) == 0) {
+    // Liveness is a property of the job list: a follower is queued ahead of some strips it follows, so progress needs a minimum of
+    // co-resident workgroups.  The list is simulated here, for every plan and option set, with FOUR resident workgroups and counters
+    // raised only on job completion (stricter than the device): a program that cannot make progress that way is not used -- the
+    // level-by-level lists below are.  (A GPU shared with other kernels or streams only delays jobs: every wait is bounded by ~2 s.)
+    const bool live = chol_program_check(d->plan, &d->opt, 4) == 0;
+    if (live && chol_build_program(d->plan, &d->opt, &w, &g) == 0) {
       int rc = upload_level(d->prog, w);
       std::vector<int> tot(g.ctr_total, g.ctr_total + g.n_ctr);
       int ncu = 256;
@@ -217,6 +225,7 @@ extern "C" void cholamd_device_destroy(cholamd_device *d)
   free_levels(d);
   for (auto &s : d->sv) { (void)hipFree(s.trsv); (void)hipFree(s.fw); (void)hipFree(s.bw); (void)hipFree(s.grp_start); (void)hipFree(s.grp_rows); (void)hipFree(s.bw_start); (void)hipFree(s.ifw); (void)hipFree(s.ibw); }
   (void)hipFree(d->ws32); (void)hipFree(d->csr_ptr); (void)hipFree(d->csr_col); (void)hipFree(d->csr_val); (void)hipFree(d->rvec); (void)hipFree(d->dxvec); (void)hipFree(d->partial);
+  (void)hipFree(d->xstage); (void)hipFree(d->xdesc);
   (void)hipFree(d->ws); (void)hipFree(d->ws_solve); (void)hipFree(d->info); (void)hipFree(d->progress); (void)hipFree(d->a_dst); (void)hipFree(d->a_val); (void)hipFree(d->perm); (void)hipFree(d->ytmp);
   for (auto &t : d->tl) { d->pool.push_back(t.a); d->pool.push_back(t.b); }
   for (auto e : d->pool) (void)hipEventDestroy(e);
@@ -234,6 +243,13 @@ extern "C" int cholamd_device_set_partition(cholamd_device *d, int rank, int wor
   return build_levels(d);
 }
 
+extern "C" int cholamd_device_bcast_phases(const cholamd_device *d)
+{ // broadcast phases (kind 6: top levels distributed by column blocks, option dist_top) in the device's per-level lists; > 0: the
+  // factorisation needs a communicator (cholamd_factor_sharded / cholamd_factor_multi)
+  int n = 0;
+  for (const level_dev &l : d->lv) for (const chol_phase &ph : l.phase) n += ph.kind == 6;
+  return n;
+}
 extern "C" int cholamd_device_set_option(cholamd_device *d, const char *name, int value)
 {
   HIPCHK(hipSetDevice(d->dev));
@@ -608,7 +624,7 @@ static int ensure_f32(cholamd_device *d)
   if (!d->lv32.empty()) return 0;
   const int L = d->plan->levels;
   chol_sched_opts o = d->opt;
-  o.split_min = CHOL32_MAXN; o.split_nb = CHOL32_MAXN; o.fuse = 0; o.fuse_update_max = 0; o.dist_top = 0; o.trsm_group = CHOL32_TRSM_GROUP; // pivot blocks the LDS-resident fp32 POTRF takes, one launch per phase
+  o.split_min = CHOL32_MAXN; o.split_nb = CHOL32_MAXN; o.fuse = 0; o.fuse_update_max = 0; o.trsm_group = CHOL32_TRSM_GROUP; // pivot blocks the LDS-resident fp32 POTRF takes, one launch per phase
   d->lv32.resize(L);
   for (int lvl = 0; lvl < L; lvl++) {
     chol_level_work w;
@@ -635,12 +651,27 @@ extern "C" int cholamd_device_fill_f32(cholamd_device *d, float *d_arena32, void
   HIPCHK((hipError_t)chol32_launch_scatter(d_arena32, d->a_dst, d->a_val, nnz, st));
   return 0;
 }
+static int launch_phase_f32(cholamd_device *d, const level_dev &l, const chol_phase &ph, float *d_arena32, hipStream_t st)
+{
+  if (ph.kind == 0) HIPCHK((hipError_t)chol32_launch_potrf(d_arena32, d->ws32, l.potrf + ph.first, ph.n, d->info, st));
+  else if (ph.kind == 7) HIPCHK((hipError_t)chol32_launch_trsm_wt(d_arena32, d->ws32, l.trsm + ph.first, ph.n, st));
+  else if (ph.kind == 1 || ph.kind == 4) HIPCHK((hipError_t)chol32_launch_trsm(d_arena32, d->ws32, l.trsm + ph.first, ph.n, st));
+  else if (ph.kind == 2) HIPCHK((hipError_t)chol32_launch_update(d_arena32, l.task + ph.first, l.src, ph.n, st));
+  else if (ph.kind == 3) HIPCHK((hipError_t)chol32_launch_update_mt(d_arena32, l.task_mt + ph.first, l.src, ph.n, (int64_t)d->plan->arena, st));
+  else { chol_set_error("internal: phase kind %d in the fp32 schedule", ph.kind); return CHOLAMD_ERR_ARG; }
+  return 0;
+}
+template <class T> static int bcast_rank_t(cholamd_device *d, const level_dev &l, const chol_phase &ph, T *d_arena, cholamd_comm *c, hipStream_t st);
+static int factor_levels_f32_comm(cholamd_device *d, float *d_arena32, int level_hi, int level_lo, cholamd_comm *c, hipStream_t st);
 extern "C" int cholamd_factor_levels_f32(cholamd_device *d, float *d_arena32, int level_hi, int level_lo, void *stream)
+{
+  return factor_levels_f32_comm(d, d_arena32, level_hi, level_lo, nullptr, (hipStream_t)stream);
+}
+static int factor_levels_f32_comm(cholamd_device *d, float *d_arena32, int level_hi, int level_lo, cholamd_comm *c, hipStream_t st)
 {
   HIPCHK(hipSetDevice(d->dev));
   int rc = ensure_f32(d);
   if (rc) return rc;
-  hipStream_t st = (hipStream_t)stream;
   const int L = d->plan->levels;
   if (level_hi >= L) level_hi = L - 1;
   if (level_lo < 0) level_lo = 0;
@@ -649,13 +680,13 @@ extern "C" int cholamd_factor_levels_f32(cholamd_device *d, float *d_arena32, in
   for (int lvl = level_hi; lvl >= level_lo; lvl--) {
     const level_dev &l = d->lv32[lvl];
     for (const chol_phase &ph : l.phase) {
+      if (ph.kind == 6) { // distributed top levels: the step's column blocks travel from their owners to every rank
+        scoped_timer t(d, st, CHOL_TK_BCAST, ph.n > 0);
+        if ((rc = bcast_rank_t<float>(d, l, ph, d_arena32, c, st))) return rc;
+        continue;
+      }
       scoped_timer t(d, st, ph.kind == 3 ? 2 : (ph.kind == 4 || ph.kind == 7) ? 1 : ph.kind, ph.n > 0);
-      if (ph.kind == 0) HIPCHK((hipError_t)chol32_launch_potrf(d_arena32, d->ws32, l.potrf + ph.first, ph.n, d->info, st));
-      else if (ph.kind == 7) HIPCHK((hipError_t)chol32_launch_trsm_wt(d_arena32, d->ws32, l.trsm + ph.first, ph.n, st));
-      else if (ph.kind == 1 || ph.kind == 4) HIPCHK((hipError_t)chol32_launch_trsm(d_arena32, d->ws32, l.trsm + ph.first, ph.n, st));
-      else if (ph.kind == 2) HIPCHK((hipError_t)chol32_launch_update(d_arena32, l.task + ph.first, l.src, ph.n, st));
-      else if (ph.kind == 3) HIPCHK((hipError_t)chol32_launch_update_mt(d_arena32, l.task_mt + ph.first, l.src, ph.n, (int64_t)d->plan->arena, st));
-      else { chol_set_error("internal: phase kind %d in the fp32 schedule", ph.kind); return CHOLAMD_ERR_ARG; }
+      if ((rc = launch_phase_f32(d, l, ph, d_arena32, st))) return rc;
     }
   }
   return 0;
@@ -1420,17 +1451,109 @@ static int comm_matches(const cholamd_device *d, const cholamd_comm *c)
   chol_set_error("communicator (rank %d of %d) does not match the device partition (rank %d of %d)", c ? c->rank : -1, c ? c->world : -1, d->rank, d->world);
   return CHOLAMD_ERR_ARG;
 }
-extern "C" int cholamd_exchange_tail(cholamd_device *d, double *d_arena, cholamd_comm *c, void *stream)
+// ---- the extend-add exchange ------------------------------------------------------------------
+// Replicated top levels: every rank needs the whole summed tail -> ONE in-place all-reduce.
+// Top levels distributed by column blocks (option dist_top): after the exchange a rank works only on the column blocks it OWNS (it
+// factors and solves them, applies the updates into them); every other block reaches it factored, by broadcast.  So the sum of a
+// block is needed on its owner alone: every rank SENDS its partial copy of each block it does not own straight to the owner
+// (grouped ncclSend / ncclRecv: point-to-point, all seven xGMI links of a GPU at once instead of a ring's one per direction), the
+// owner adds the world - 1 copies it received to its own in RANK ORDER (deterministic: the same sum in every run).  A rank receives
+// (world - 1) x (its owned blocks) and sends the blocks it does not own once: (world - 1) / world of the tail each way, against
+// 2 (world - 1) / world of it each way for the ring all-reduce -- and nothing is added twice on the way.
+struct xpiece { int64_t off, count, stage; int owner; };
+// the column blocks of the levels above the cut, with their owners (the broadcast lists of the distributed top levels); empty: replicated
+static void exchange_pieces(const cholamd_device *d, const std::vector<level_dev> &lv, std::vector<xpiece> &out)
+{
+  out.clear();
+  const int split = chol_split_level(d->world);
+  for (int lvl = split - 1; lvl >= 0 && lvl < (int)lv.size(); lvl--)
+    for (const chol_bcast &b : lv[lvl].bcast) out.push_back({ b.off, b.count, 0, b.owner });
+  int64_t st = 0; // staging slots of the pieces this rank owns: world - 1 copies each, senders in rank order
+  for (xpiece &x : out) if (x.owner == d->rank) { x.stage = st; st += x.count * (d->world - 1); }
+}
+struct sum_desc { int64_t off, count, stage; };
+template <class T> __global__ void k_sum_owned(T *arena, const T *stage, const sum_desc *desc, int world, int rank)
+{ // arena[off + i] = sum over the ranks in rank order; rank r's copy: this rank's own arena for r == rank, else staging slot (r < rank ? r : r - 1)
+  const sum_desc d = desc[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.count; i += (int64_t)gridDim.x * blockDim.x) {
+    T s = 0;
+    for (int r = 0; r < world; r++) s += r == rank ? arena[d.off + i] : stage[d.stage + (int64_t)(r < rank ? r : r - 1) * d.count + i];
+    arena[d.off + i] = s;
+  }
+}
+template <class T> static int exchange_owned(cholamd_device *d, T *arena, const std::vector<xpiece> &px, cholamd_comm *c, hipStream_t st)
+{
+  const ncclDataType_t ty = sizeof(T) == 8 ? ncclDouble : ncclFloat;
+  int64_t need = 0; std::vector<sum_desc> mine;
+  for (const xpiece &x : px) if (x.owner == d->rank) { need += x.count * (d->world - 1); mine.push_back({ x.off, x.count, x.stage }); }
+  if ((size_t)need * sizeof(T) > d->xstage_bytes) {
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(d->xstage); d->xstage = nullptr; d->xstage_bytes = 0;
+    HIPCHK(hipMalloc(&d->xstage, (size_t)need * sizeof(T)));
+    d->xstage_bytes = (size_t)need * sizeof(T);
+  }
+  if (d->xdesc_gen != d->sched_gen || d->xdesc_elem != (int)sizeof(T)) { // the descriptors of the sum kernel, once per schedule
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(d->xdesc); d->xdesc = nullptr;
+    if (!mine.empty()) { int rc = upload_vec((sum_desc **)&d->xdesc, mine.data(), mine.size()); if (rc) return rc; }
+    d->xdesc_gen = d->sched_gen; d->xdesc_elem = (int)sizeof(T);
+  }
+  T *stage = (T *)d->xstage;
+  NCCLCHK(ncclGroupStart());
+  for (const xpiece &x : px) {
+    ncclResult_t r = ncclSuccess;
+    if (x.owner == d->rank) {
+      for (int q = 0, slot = 0; q < d->world && r == ncclSuccess; q++) {
+        if (q == d->rank) continue;
+        r = ncclRecv(stage + x.stage + (int64_t)slot * x.count, (size_t)x.count, ty, q, c->comm, st);
+        slot++;
+      }
+    } else r = ncclSend(arena + x.off, (size_t)x.count, ty, x.owner, c->comm, st);
+    if (r != ncclSuccess) { (void)ncclGroupEnd(); chol_set_error("ncclSend/ncclRecv failed: %s", ncclGetErrorString(r)); return CHOLAMD_ERR_COMM; }
+  }
+  NCCLCHK(ncclGroupEnd());
+  if (!mine.empty()) {
+    int64_t mx = 0;
+    for (const sum_desc &m : mine) mx = m.count > mx ? m.count : mx;
+    const int64_t bx = (mx + 255) / 256;
+    hipLaunchKernelGGL(k_sum_owned<T>, dim3((unsigned)(bx < 1024 ? bx : 1024), (unsigned)mine.size()), dim3(256), 0, st, arena, (const T *)stage, (const sum_desc *)d->xdesc, d->world, d->rank);
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+template <class T> static int exchange_tail_t(cholamd_device *d, T *arena, const std::vector<level_dev> &lv, cholamd_comm *c, hipStream_t st)
 {
   HIPCHK(hipSetDevice(d->dev));
   if (comm_matches(d, c)) return CHOLAMD_ERR_ARG;
+  if (!c->comm) { chol_set_error("a local communicator exchanges through cholamd_factor_multi only"); return CHOLAMD_ERR_ARG; }
+  std::vector<xpiece> px;
+  exchange_pieces(d, lv, px);
+  if (!px.empty()) return exchange_owned<T>(d, arena, px, c, st);
   int64_t tail, count;
   tail_of(d, &tail, &count);
-  return cholamd_comm_allreduce(c, d_arena + tail, count, stream);
+  if (count <= 0) return 0;
+  NCCLCHK(ncclAllReduce(arena + tail, arena + tail, (size_t)count, sizeof(T) == 8 ? ncclDouble : ncclFloat, ncclSum, c->comm, st));
+  return 0;
+}
+extern "C" int cholamd_exchange_tail(cholamd_device *d, double *d_arena, cholamd_comm *c, void *stream)
+{
+  return exchange_tail_t<double>(d, d_arena, d->lv, c, (hipStream_t)stream);
+}
+extern "C" int cholamd_exchange_volume(const cholamd_device *d, int64_t out[4])
+{ // elements this rank receives / sends in the exchange of its partition, elements of the tail, pieces (0: one all-reduce of the tail:
+  // a ring moves 2 (world - 1) / world of it each way)
+  std::vector<xpiece> px;
+  exchange_pieces(d, d->lv, px);
+  int64_t tail, count;
+  tail_of(d, &tail, &count);
+  out[0] = out[1] = 0; out[2] = count; out[3] = (int64_t)px.size();
+  for (const xpiece &x : px) { if (x.owner == d->rank) out[0] += x.count * (d->world - 1); else out[1] += x.count; }
+  if (px.empty() && d->world > 1) out[0] = out[1] = 2 * count * (d->world - 1) / d->world;
+  return 0;
 }
 // one rank's broadcasts of a phase of kind 6 (distributed top levels): every column block of the step travels from its owner to all
 // ranks, in place at the same arena offset; one RCCL group
-static int bcast_rank(cholamd_device *d, const level_dev &l, const chol_phase &ph, double *d_arena, cholamd_comm *c, hipStream_t st)
+template <class T> static int bcast_rank_t(cholamd_device *d, const level_dev &l, const chol_phase &ph, T *d_arena, cholamd_comm *c, hipStream_t st)
 {
   if (!c) { chol_set_error("the distributed top levels (option dist_top) need a communicator: cholamd_factor_sharded / cholamd_factor_multi"); return CHOLAMD_ERR_ARG; }
   if (comm_matches(d, c)) return CHOLAMD_ERR_ARG;
@@ -1438,12 +1561,17 @@ static int bcast_rank(cholamd_device *d, const level_dev &l, const chol_phase &p
   NCCLCHK(ncclGroupStart());
   for (int i = ph.first; i < ph.first + ph.n; i++) {
     const chol_bcast &b = l.bcast[i];
-    ncclResult_t r = ncclBroadcast(d_arena + b.off, d_arena + b.off, (size_t)b.count, ncclDouble, b.owner, c->comm, st);
+    ncclResult_t r = ncclBroadcast(d_arena + b.off, d_arena + b.off, (size_t)b.count, sizeof(T) == 8 ? ncclDouble : ncclFloat, b.owner, c->comm, st);
     if (r != ncclSuccess) { (void)ncclGroupEnd(); chol_set_error("ncclBroadcast failed: %s", ncclGetErrorString(r)); return CHOLAMD_ERR_COMM; }
   }
   NCCLCHK(ncclGroupEnd());
   return 0;
 }
+static int bcast_rank(cholamd_device *d, const level_dev &l, const chol_phase &ph, double *d_arena, cholamd_comm *c, hipStream_t st)
+{
+  return bcast_rank_t<double>(d, l, ph, d_arena, c, st);
+}
+static int factor_levels_f32_comm(cholamd_device *d, float *d_arena32, int level_hi, int level_lo, cholamd_comm *c, hipStream_t st);
 extern "C" int cholamd_factor_sharded(cholamd_device *d, double *d_arena, cholamd_comm *c, void *stream)
 {
   const int L = d->plan->levels, split = chol_split_level(d->world);
@@ -1456,42 +1584,81 @@ extern "C" int cholamd_factor_sharded(cholamd_device *d, double *d_arena, cholam
   if (!rc) rc = factor_levels_comm(d, d_arena, split - 1, 0, c, (hipStream_t)stream);
   return rc;
 }
+// the same with the fp32 factor (BASELINE config 5: mixed precision x multi-GPU): fp32 arena of the fp64 arena's element layout, the
+// fp32 schedule partitioned like the fp64 one, the exchange and the broadcasts on floats
+extern "C" int cholamd_factor_sharded_f32(cholamd_device *d, float *d_arena32, cholamd_comm *c, void *stream)
+{
+  const int L = d->plan->levels, split = chol_split_level(d->world);
+  if (d->world == 1) return cholamd_factor_f32(d, d_arena32, stream);
+  int rc = ensure_f32(d);
+  if (!rc) rc = factor_levels_f32_comm(d, d_arena32, L - 1, split, nullptr, (hipStream_t)stream);
+  if (!rc) {
+    scoped_timer t(d, (hipStream_t)stream, CHOL_TK_EXCHANGE, true);
+    rc = exchange_tail_t<float>(d, d_arena32, d->lv32, c, (hipStream_t)stream);
+  }
+  if (!rc) rc = factor_levels_f32_comm(d, d_arena32, split - 1, 0, c, (hipStream_t)stream);
+  return rc;
+}
 
 // ---- one process driving n ranks ----
-struct ptr_pack { double *p[CHOL_LOCAL_MAX]; };
-__global__ void k_sum_tails(ptr_pack P, int n, int64_t count)
-{ // P.p[0][i] = sum over the ranks in rank order (a fixed order: run-to-run identical)
+struct ptr_pack { void *p[CHOL_LOCAL_MAX]; };
+template <class T> __global__ void k_sum_ranks(ptr_pack P, int n, int dst, int64_t count)
+{ // P.p[dst][i] = sum over the ranks in rank order (a fixed order: run-to-run identical)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
-    double s = P.p[0][i];
-    for (int r = 1; r < n; r++) s += P.p[r][i];
-    P.p[0][i] = s;
+    T s = ((const T *)P.p[0])[i];
+    for (int r = 1; r < n; r++) s += ((const T *)P.p[r])[i];
+    ((T *)P.p[dst])[i] = s;
   }
 }
 static hipStream_t stream_of(void *const *streams, int g) { return streams ? (hipStream_t)streams[g] : nullptr; }
-static int local_allreduce_tails(cholamd_device *const *devs, double *const *arenas, local_group *G, int n, void *const *streams)
+template <class T> static int local_exchange(cholamd_device *const *devs, T *const *arenas, const std::vector<level_dev> &lv0, local_group *G, int n, void *const *streams)
 {
+  std::vector<xpiece> px;
+  exchange_pieces(devs[0], lv0, px);
   int64_t tail, count;
   tail_of(devs[0], &tail, &count);
   if (count <= 0) return 0;
-  for (int g = 0; g < n; g++) { HIPCHK(hipSetDevice(devs[g]->dev)); HIPCHK(hipEventRecord(G->ev[g], stream_of(streams, g))); }
-  HIPCHK(hipSetDevice(devs[0]->dev));
-  ptr_pack P;
-  for (int g = 0; g < n; g++) { P.p[g] = arenas[g] + tail; if (g) HIPCHK(hipStreamWaitEvent(stream_of(streams, 0), G->ev[g], 0)); }
-  const int64_t blocks = (count + 255) / 256;
-  hipLaunchKernelGGL(k_sum_tails, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream_of(streams, 0), P, n, count);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(G->ev[n], stream_of(streams, 0)));
-  for (int g = 1; g < n; g++) {
-    HIPCHK(hipSetDevice(devs[g]->dev));
-    HIPCHK(hipStreamWaitEvent(stream_of(streams, g), G->ev[n], 0));
-    HIPCHK(hipMemcpyPeerAsync(arenas[g] + tail, devs[g]->dev, arenas[0] + tail, devs[0]->dev, (size_t)count * sizeof(double), stream_of(streams, g)));
-    HIPCHK(hipEventRecord(G->ev[n + g], stream_of(streams, g)));
+  for (int g = 0; g < n; g++) { HIPCHK(hipSetDevice(devs[g]->dev)); HIPCHK(hipEventRecord(G->ev[g], stream_of(streams, g))); } // every rank's subtree levels are in its stream
+  if (px.empty()) { // replicated top: the ordered sum on rank 0, peer copies to the others
+    HIPCHK(hipSetDevice(devs[0]->dev));
+    ptr_pack P;
+    for (int g = 0; g < n; g++) { P.p[g] = arenas[g] + tail; if (g) HIPCHK(hipStreamWaitEvent(stream_of(streams, 0), G->ev[g], 0)); }
+    const int64_t blocks = (count + 255) / 256;
+    hipLaunchKernelGGL(k_sum_ranks<T>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream_of(streams, 0), P, n, 0, count);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(G->ev[n], stream_of(streams, 0)));
+    for (int g = 1; g < n; g++) {
+      HIPCHK(hipSetDevice(devs[g]->dev));
+      HIPCHK(hipStreamWaitEvent(stream_of(streams, g), G->ev[n], 0));
+      HIPCHK(hipMemcpyPeerAsync(arenas[g] + tail, devs[g]->dev, arenas[0] + tail, devs[0]->dev, (size_t)count * sizeof(T), stream_of(streams, g)));
+      HIPCHK(hipEventRecord(G->ev[n + g], stream_of(streams, g)));
+    }
+    HIPCHK(hipSetDevice(devs[0]->dev));
+    for (int g = 1; g < n; g++) HIPCHK(hipStreamWaitEvent(stream_of(streams, 0), G->ev[n + g], 0)); // rank 0 goes on writing its tail
+    return 0;
   }
-  HIPCHK(hipSetDevice(devs[0]->dev));
-  for (int g = 1; g < n; g++) HIPCHK(hipStreamWaitEvent(stream_of(streams, 0), G->ev[n + g], 0)); // rank 0 goes on writing its tail
+  // distributed top: every column block is summed (rank order) into its OWNER's arena by the owner's stream; the other ranks' copies of
+  // it are read, not written.  Nobody goes on before every owner has read what it needs (the broadcasts overwrite those copies)
+  for (int o = 0; o < n; o++) {
+    HIPCHK(hipSetDevice(devs[o]->dev));
+    for (int g = 0; g < n; g++) if (g != o) HIPCHK(hipStreamWaitEvent(stream_of(streams, o), G->ev[g], 0));
+    for (const xpiece &x : px) {
+      if (x.owner != o) continue;
+      ptr_pack P;
+      for (int g = 0; g < n; g++) P.p[g] = arenas[g] + x.off;
+      const int64_t blocks = (x.count + 255) / 256;
+      hipLaunchKernelGGL(k_sum_ranks<T>, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, stream_of(streams, o), P, n, o, x.count);
+      HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(G->ev[n + o], stream_of(streams, o)));
+  }
+  for (int g = 0; g < n; g++) {
+    HIPCHK(hipSetDevice(devs[g]->dev));
+    for (int o = 0; o < n; o++) if (o != g) HIPCHK(hipStreamWaitEvent(stream_of(streams, g), G->ev[n + o], 0));
+  }
   return 0;
 }
-static int local_bcast(cholamd_device *const *devs, double *const *arenas, local_group *G, int n, void *const *streams, const level_dev &l, const chol_phase &ph)
+template <class T> static int local_bcast(cholamd_device *const *devs, T *const *arenas, local_group *G, int n, void *const *streams, const level_dev &l, const chol_phase &ph)
 {
   std::vector<char> owner_ready(n, 0);
   for (int i = ph.first; i < ph.first + ph.n; i++) {
@@ -1507,29 +1674,34 @@ static int local_bcast(cholamd_device *const *devs, double *const *arenas, local
     for (int i = ph.first; i < ph.first + ph.n; i++) {
       const chol_bcast &b = l.bcast[i];
       if (b.owner == g) continue; // the owner does not touch the block again: the copies may read it while its stream goes on
-      HIPCHK(hipMemcpyPeerAsync(arenas[g] + b.off, devs[g]->dev, arenas[b.owner] + b.off, devs[b.owner]->dev, (size_t)b.count * sizeof(double), stream_of(streams, g)));
+      HIPCHK(hipMemcpyPeerAsync(arenas[g] + b.off, devs[g]->dev, arenas[b.owner] + b.off, devs[b.owner]->dev, (size_t)b.count * sizeof(T), stream_of(streams, g)));
     }
   }
   return 0;
 }
-extern "C" int cholamd_factor_multi(cholamd_device *const *devs, double *const *arenas, cholamd_comm *const *comms, int n, void *const *streams)
+static int launch_phase_f32(cholamd_device *d, const level_dev &l, const chol_phase &ph, float *d_arena32, hipStream_t st);
+// T = double: the fp64 schedule (devs[g]->lv); T = float: the fp32 one (lv32)
+template <class T> static int factor_multi_t(cholamd_device *const *devs, T *const *arenas, cholamd_comm *const *comms, int n, void *const *streams)
 { // one process, n ranks: everything is asynchronous on each rank's stream
+  constexpr bool F32 = sizeof(T) == 4;
   if (n < 1) { chol_set_error("no devices"); return CHOLAMD_ERR_ARG; }
-  if (n == 1) return cholamd_factor(devs[0], arenas[0], streams ? streams[0] : nullptr);
   const int L = devs[0]->plan->levels, split = chol_split_level(n);
   local_group *G = comms[0] ? comms[0]->local : nullptr;
   for (int g = 0; g < n; g++) {
     if (devs[g]->world != n || devs[g]->rank != g) { chol_set_error("device %d is not partitioned as rank %d of %d", g, g, n); return CHOLAMD_ERR_ARG; }
     if (comm_matches(devs[g], comms[g])) return CHOLAMD_ERR_ARG;
     if (comms[g]->local != G || (!G && !comms[g]->comm)) { chol_set_error("the %d communicators are not of one kind", n); return CHOLAMD_ERR_ARG; }
-    int rc = cholamd_factor_levels(devs[g], arenas[g], L - 1, split, stream_of(streams, g));
+    int rc;
+    if (F32) { rc = ensure_f32(devs[g]); if (!rc) rc = factor_levels_f32_comm(devs[g], (float *)arenas[g], L - 1, split, nullptr, stream_of(streams, g)); }
+    else rc = cholamd_factor_levels(devs[g], (double *)arenas[g], L - 1, split, stream_of(streams, g));
     if (rc) return rc;
   }
-  if (G) { int rc = local_allreduce_tails(devs, arenas, G, n, streams); if (rc) return rc; }
+  auto levels_of = [&](int g) -> const std::vector<level_dev> & { return F32 ? devs[g]->lv32 : devs[g]->lv; };
+  if (G) { int rc = local_exchange<T>(devs, arenas, levels_of(0), G, n, streams); if (rc) return rc; }
   else {
     NCCLCHK(ncclGroupStart());
     for (int g = 0; g < n; g++) {
-      int rc = cholamd_exchange_tail(devs[g], arenas[g], comms[g], stream_of(streams, g));
+      int rc = exchange_tail_t<T>(devs[g], arenas[g], levels_of(g), comms[g], stream_of(streams, g));
       if (rc) { (void)ncclGroupEnd(); return rc; }
     }
     NCCLCHK(ncclGroupEnd());
@@ -1540,10 +1712,10 @@ extern "C" int cholamd_factor_multi(cholamd_device *const *devs, double *const *
     for (;;) {
       int at_bcast = 0;
       for (int g = 0; g < n; g++) {
-        const level_dev &l = devs[g]->lv[lvl];
+        const level_dev &l = levels_of(g)[lvl];
         HIPCHK(hipSetDevice(devs[g]->dev));
         while (cur[g] < l.phase.size() && l.phase[cur[g]].kind != 6) {
-          int rc = launch_phase(devs[g], l, l.phase[cur[g]], arenas[g], stream_of(streams, g));
+          int rc = F32 ? launch_phase_f32(devs[g], l, l.phase[cur[g]], (float *)arenas[g], stream_of(streams, g)) : launch_phase(devs[g], l, l.phase[cur[g]], (double *)arenas[g], stream_of(streams, g));
           if (rc) return rc;
           cur[g]++;
         }
@@ -1551,15 +1723,15 @@ extern "C" int cholamd_factor_multi(cholamd_device *const *devs, double *const *
       }
       if (at_bcast == 0) break;
       if (at_bcast != n) { chol_set_error("internal: the ranks disagree on the broadcast sequence of level %d", lvl); return CHOLAMD_ERR_ARG; }
-      if (G) { int rc = local_bcast(devs, arenas, G, n, streams, devs[0]->lv[lvl], devs[0]->lv[lvl].phase[cur[0]]); if (rc) return rc; }
+      if (G) { int rc = local_bcast<T>(devs, arenas, G, n, streams, levels_of(0)[lvl], levels_of(0)[lvl].phase[cur[0]]); if (rc) return rc; }
       else {
         NCCLCHK(ncclGroupStart());
         for (int g = 0; g < n; g++) {
-          const level_dev &l = devs[g]->lv[lvl];
+          const level_dev &l = levels_of(g)[lvl];
           const chol_phase &ph = l.phase[cur[g]];
           for (int i = ph.first; i < ph.first + ph.n; i++) {
             const chol_bcast &b = l.bcast[i];
-            ncclResult_t r = ncclBroadcast(arenas[g] + b.off, arenas[g] + b.off, (size_t)b.count, ncclDouble, b.owner, comms[g]->comm, stream_of(streams, g));
+            ncclResult_t r = ncclBroadcast(arenas[g] + b.off, arenas[g] + b.off, (size_t)b.count, F32 ? ncclFloat : ncclDouble, b.owner, comms[g]->comm, stream_of(streams, g));
             if (r != ncclSuccess) { (void)ncclGroupEnd(); chol_set_error("ncclBroadcast failed: %s", ncclGetErrorString(r)); return CHOLAMD_ERR_COMM; }
           }
         }
@@ -1570,7 +1742,49 @@ extern "C" int cholamd_factor_multi(cholamd_device *const *devs, double *const *
   }
   return 0;
 }
+extern "C" int cholamd_factor_multi(cholamd_device *const *devs, double *const *arenas, cholamd_comm *const *comms, int n, void *const *streams)
+{
+  if (n == 1) return cholamd_factor(devs[0], arenas[0], streams ? streams[0] : nullptr);
+  return factor_multi_t<double>(devs, arenas, comms, n, streams);
+}
+extern "C" int cholamd_factor_multi_f32(cholamd_device *const *devs, float *const *arenas32, cholamd_comm *const *comms, int n, void *const *streams)
+{
+  if (n == 1) return cholamd_factor_f32(devs[0], arenas32[0], streams ? streams[0] : nullptr);
+  return factor_multi_t<float>(devs, arenas32, comms, n, streams);
+}
+// one rank's part of the gather: the panels of the subtrees it owns travel to rank 0 (grouped ncclSend / ncclRecv), whose arena then
+// holds the complete factor (for the solve / refinement and the writers).  elem_bytes = 8 (fp64 arena) or 4 (fp32)
+extern "C" int cholamd_gather_to_root(cholamd_device *d, void *d_arena, int elem_bytes, cholamd_comm *c, void *stream)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  if (d->world == 1) return 0;
+  if (comm_matches(d, c)) return CHOLAMD_ERR_ARG;
+  if (!c->comm) { chol_set_error("a local communicator gathers through cholamd_gather_factor only"); return CHOLAMD_ERR_ARG; }
+  if (elem_bytes != 4 && elem_bytes != 8) { chol_set_error("element size %d", elem_bytes); return CHOLAMD_ERR_ARG; }
+  const cholamd_plan *p = d->plan;
+  NCCLCHK(ncclGroupStart());
+  for (int s = 1; s <= p->nsep; s++) {
+    const int g = chol_owner_of(p, s, d->world);
+    if (g <= 0 || (d->rank != 0 && d->rank != g)) continue;
+    const int64_t off = p->panel_off[s], len = (s < p->nsep ? p->panel_off[s + 1] : p->arena) - off;
+    char *ptr = (char *)d_arena + (size_t)off * elem_bytes;
+    ncclResult_t r = d->rank == 0 ? ncclRecv(ptr, (size_t)len, elem_bytes == 8 ? ncclDouble : ncclFloat, g, c->comm, (hipStream_t)stream)
+                                  : ncclSend(ptr, (size_t)len, elem_bytes == 8 ? ncclDouble : ncclFloat, 0, c->comm, (hipStream_t)stream);
+    if (r != ncclSuccess) { (void)ncclGroupEnd(); chol_set_error("gather: %s", ncclGetErrorString(r)); return CHOLAMD_ERR_COMM; }
+  }
+  NCCLCHK(ncclGroupEnd());
+  return 0;
+}
+static int gather_factor_bytes(cholamd_device *const *devs, void *const *arenas, int n, void *const *streams, int elem_bytes);
 extern "C" int cholamd_gather_factor(cholamd_device *const *devs, double *const *arenas, int n, void *const *streams)
+{
+  return gather_factor_bytes(devs, (void *const *)arenas, n, streams, 8);
+}
+extern "C" int cholamd_gather_factor_f32(cholamd_device *const *devs, float *const *arenas32, int n, void *const *streams)
+{
+  return gather_factor_bytes(devs, (void *const *)arenas32, n, streams, 4);
+}
+static int gather_factor_bytes(cholamd_device *const *devs, void *const *arenas, int n, void *const *streams, int elem_bytes)
 { // the panels of the subtrees ranks 1..n-1 own -> device 0's arena (peer copies), so that it holds the complete factor
   const cholamd_plan *p = devs[0]->plan;
   for (int g = 1; g < n; g++) {
@@ -1583,7 +1797,7 @@ extern "C" int cholamd_gather_factor(cholamd_device *const *devs, double *const 
     if (g <= 0) continue;
     const int64_t off = p->panel_off[s];
     const int64_t len = (s < p->nsep ? p->panel_off[s + 1] : p->arena) - off;
-    HIPCHK(hipMemcpyPeerAsync(arenas[0] + off, devs[0]->dev, arenas[g] + off, devs[g]->dev, (size_t)len * sizeof(double), streams ? (hipStream_t)streams[0] : nullptr));
+    HIPCHK(hipMemcpyPeerAsync((char *)arenas[0] + (size_t)off * elem_bytes, devs[0]->dev, (const char *)arenas[g] + (size_t)off * elem_bytes, devs[g]->dev, (size_t)len * elem_bytes, streams ? (hipStream_t)streams[0] : nullptr));
   }
   return 0;
 }

@@ -43,13 +43,15 @@ template <bool PUB> __device__ __forceinline__ double gload(const double *p)
 
 // wait until a progress word written by workgroups of the same launch reaches `target` (columns published by a
 // pivot's POTRF workgroup; TRSM workgroups finished).  Producers have lower block indices than their consumers,
-// are dispatched first and never wait for a consumer; the spin is bounded all the same: after ~50 ms it
-// gives up and reports through info (the factorisation then fails loudly instead of hanging the GPU).
+// are dispatched first and never wait for a consumer; the spin is bounded all the same: after about two seconds
+// (CHOL_SPIN_*: every in-launch wait gives up after ~2 s of polling -- long enough for a GPU shared with other streams or
+// processes, where a producer may simply not be resident yet) it gives up and reports through info (the factorisation then
+// fails loudly, CHOLAMD_ERR_STALL, instead of hanging the GPU).
 __device__ __forceinline__ int wait_progress(const int *progress, int target, int seen, int *info)
 {
   if (seen >= target) return seen;
   int v = 0;
-  for (int it = 0; it < (1 << 16); ++it) {
+  for (int it = 0; it < (1 << 23); ++it) { // x ~0.25 us per poll
     v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (v >= target) return v;
 #ifndef PROG_SLEEP
@@ -155,7 +157,7 @@ __device__ __forceinline__ int wait_stage(const stage_waits &sw, int need, int l
 {
   int have = stages_holding(sw, lane);
   for (int it = 0; have < need; ++it) {
-    if (it >= (1 << 15)) { if (lane == 0) atomicCAS(&sw.info[0], 0, CHOLAMD_ERR_STALL); return sw.n; }
+    if (it >= (1 << 22)) { if (lane == 0) atomicCAS(&sw.info[0], 0, CHOLAMD_ERR_STALL); return sw.n; } // x ~0.5 us per poll
 #ifndef STAGE_SLEEP
 #define STAGE_SLEEP 16
 #endif
@@ -379,7 +381,7 @@ __device__ __forceinline__ void update_mt_body(double *__restrict__ base, const 
   if (!full && arena_elems > 0) {
     __shared__ int sOk;
     if (tt == 0) sOk = 1;
-    __builtin_amdgcn_s_barrier();
+    lds_barrier(); // the initialisation has LANDED before any wave may clear the word (s_barrier alone is no LDS fence: gfx950 has back-off barriers)
     for (int s = t.src_begin + tt; s < t.src_end; s += NT) {
       const chol_upd_src sd = srcs[s];
       const int kf = (sd.k / MKB) * MKB;
@@ -849,10 +851,11 @@ __device__ __forceinline__ void lds_inc(int *cnt, int lane)
 }
 // tile (ti, tj) of the lower triangle of the n x n matrix A in accumulator layout; the last partial diagonal
 // tile is padded with the identity, everything else past n and above the diagonal with zeros
-template <bool PUB> __device__ __forceinline__ d4 load_tile(const double *A, int lda, int n, int ti, int tj, int r15, int g)
-{
+template <bool PUB> __device__ __forceinline__ d4 load_tile(const double *A, int lda, int n, int ti, int tj, int r15, int g, bool live = true)
+{ // live = false: a tile left of a leaf pivot's skyline -- structurally zero, nothing is read (the predicate folds into the lanes' own: no branch
+  // around the loads, so every load of the prologue is still issued before the first wait)
   const int row = ti * TS + r15;
-  const bool rowok = row < n;
+  const bool rowok = live && row < n;
   const double *src = A + row + (int64_t)(tj * TS + g) * lda;
   d4 v;
 #pragma unroll
@@ -886,7 +889,7 @@ __device__ __forceinline__ void wait_list(const chol_wait *__restrict__ wl, int 
     for (int it = 0;; ++it) {
       const bool ok = !mine || __hip_atomic_load(&ctr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
       if (!__ballot(!ok)) break;
-      if (it >= (1 << 15)) { if (lane == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); break; }
+      if (it >= (1 << 21)) { if (lane == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); break; } // x ~1 us per poll
 #ifndef WAIT_SLEEP
 #define WAIT_SLEEP 32
 #endif
@@ -1009,7 +1012,7 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
         if (!UPD) {
           ready = ext_ready(f, i, lane);
           for (int it = 0; ready < need; ++it) { // bounded like wait_progress: a stall fails the factorisation through info
-            if (it >= (1 << 16)) { if (lane == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); ready = f.n_ext; break; }
+            if (it >= (1 << 24)) { if (lane == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); ready = f.n_ext; break; } // x ~0.15 us per poll
 #ifndef EXT_SLEEP
 #define EXT_SLEEP 4
 #endif
@@ -1021,7 +1024,7 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
           for (int it = 0;; ++it) {
             ready = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             if (ready >= need) break;
-            if (it >= (1 << 20)) { if (lane == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); ready = f.n_ext; break; }
+            if (it >= (1 << 25)) { if (lane == 0) atomicCAS(&info[0], 0, CHOLAMD_ERR_STALL); ready = f.n_ext; break; }
             __builtin_amdgcn_s_sleep(2);
           }
         }
@@ -1077,8 +1080,11 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
 
 template <bool PUB, bool FOLLOW = false, bool TR = false>
 __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double *__restrict__ ws, const chol_potrf_desc d, int *__restrict__ info,
-                                              int *__restrict__ progress, int progress_base, double *smem, const unsigned char *__restrict__ sky, const follow_args fa = follow_args(), const int tid = threadIdx.x)
+                                              int *__restrict__ progress, int progress_base, double *smem, const unsigned char *__restrict__ sky, const follow_args fa = follow_args(), const int tid = threadIdx.x,
+                                              int *__restrict__ progress_w = nullptr)
 { // sky: the descriptor's skyline in global memory (indexed per tile: a by-value copy would go to scratch)
+  // progress_w (program launch): a second progress word, the diagonal blocks whose L(k,k) and L(k,k)^-1 are in global memory -- published
+  // right after the block's Cholesky, a step or two ahead of the column's `progress` (the strips solve column tile k with it)
  // tid: the thread index, passed in by k_program as a value the compiler cannot see through (nothing derived from it may be
   // hoisted out of the job loop: that is what would spill)
   // tiles in LDS are stored like accumulator registers: element (r, c) at c * 16 + r, so lane (r15, g)
@@ -1230,6 +1236,9 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
     int kmn[RR_SLOTS]; // per slot: the first step whose update of the tile can be non-zero (skyline of a leaf pivot; 0 otherwise)
 #pragma unroll
     for (int s = 0; s < RR_SLOTS; ++s) kmn[s] = __builtin_amdgcn_readfirstlane((int)sKm[s * RR_NW + w]);
+    int kmn0[RR_SLOTS]; // per slot: the skyline of the tile's ROW (tile (i, j) is structurally zero for j < sky(i)); dead after the prologue
+#pragma unroll
+    for (int s = 0; s < RR_SLOTS; ++s) kmn0[s] = __builtin_amdgcn_readfirstlane((int)sSky[min(ijp[s] & 0xff, 23)]);
     // ---- prologue: columns 0 and 1 go straight to LDS -- (0,0), (1,1) -> sDg, (i,0) -> sRaw[i],
     //      (i,1), i >= 2 -> sSol[1][i] (free until the panel solve of step 1) -- then the register tiles
     //      Every load of the prologue is issued before the first wait: three tiles of columns 0 / 1 per wave at
@@ -1262,14 +1271,17 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       lds_barrier();
     } else {
 #pragma unroll
+    // tiles left of a leaf pivot's skyline are zeros of A (and of L): not read -- the 259-column leaf of lapl_3375 holds 56 non-zero tiles of
+    // 153, and its workgroup's first column used to start 10 us into the launch, most of it this one CU pulling 270 KB out of HBM
     for (int it = 0; it < 3; ++it) {
       const int u = min(w + it * RR_NW, 2 * T - 2);
-      stage[it] = load_tile<PUB>(A, lda, n, u < T ? u : u - T + 1, u < T ? 0 : 1, r15, g);
+      const int ti = u < T ? u : u - T + 1, tj = u < T ? 0 : 1;
+      stage[it] = load_tile<PUB>(A, lda, n, ti, tj, r15, g, tj >= __builtin_amdgcn_readfirstlane((int)sSky[min(ti, 23)]));
     }
 #pragma unroll
     for (int s = 0; s < RR_RSLOTS; ++s) {
       d4 v = { 0.0, 0.0, 0.0, 0.0 };
-      if (ijp[s] != 0xffff) v = load_tile<PUB>(A, lda, n, ijp[s] & 0xff, ijp[s] >> 8, r15, g);
+      if (ijp[s] != 0xffff) v = load_tile<PUB>(A, lda, n, ijp[s] & 0xff, ijp[s] >> 8, r15, g, (ijp[s] >> 8) >= kmn0[s]);
       tile[s] = v;
     }
     }
@@ -1285,7 +1297,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       }
     }
     if (ijp[RR_RSLOTS] != 0xffff) { // heavy waves only (rr_owner)
-      const d4 v = load_tile<PUB>(A, lda, n, ijp[RR_RSLOTS] & 0xff, ijp[RR_RSLOTS] >> 8, r15, g);
+      const d4 v = load_tile<PUB>(A, lda, n, ijp[RR_RSLOTS] & 0xff, ijp[RR_RSLOTS] >> 8, r15, g, (ijp[RR_RSLOTS] >> 8) >= kmn0[RR_RSLOTS]);
 #pragma unroll
       for (int q = 0; q < 4; ++q) sOv[hw][q * 64 + lp0] = v[q];
     }
@@ -1302,6 +1314,26 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       // ---- 1. panel solve out of LDS (needs L(k,k) and every raw tile of column k)
       lds_wait_ge(fL, k + 1);
       STAMPK(1);
+      // ---- the light waves solve no panel tiles: one of them copies L(k,k) and L(k,k)^-1 from LDS to global memory as soon as the
+      //      factor wave has published them (sLW of this parity stays valid until every tile wave has finished step k) and, in the
+      //      program launch, tells the strips (progress_w) once the stores have landed -- it has counted itself into the panel barrier
+      //      before it waits for them, so nobody waits for the drain
+#ifndef EARLY_W_MODE
+#define EARLY_W_MODE 1 /* 0: with the column; 1: early where the light waves own no tile (pivot blocks of at most ten tile columns: every follower); 2: always */
+#endif
+      const bool copier = w == ((k & 1) ? 7 : 3);
+      const bool early_w = EARLY_W_MODE == 2 || (EARLY_W_MODE == 1 && ntl2 <= RR_HEAVY_ONLY);
+      if (copier && early_w) {
+        const int row = k * TS + r15;
+        double *dst = A + row + (int64_t)(k * TS + g) * lda;
+        double *Wb = W + (int64_t)k * TS * TS;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const double lv = sLW[par][r15][g + 4 * b], wv = sLW[par][TS + g + 4 * b][r15];
+          if (row < n && g + 4 * b <= r15) gstore<PUB>(&dst[(int64_t)(4 * b) * lda], lv);
+          gstore<PUB>(&Wb[(g + 4 * b) * TS + r15], wv); // Wb[k * 16 + c] = Linv(c, k): the layout solve16() reads
+        }
+      }
       lds_wait_ge(cRaw, (k + 1) * (T - 1) - k * (k + 1) / 2);
       STAMPK(2);
       if (mk & ((1 << RR_M_SOLVE0) | (1 << RR_M_SOLVE1))) {
@@ -1348,6 +1380,10 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       // ---- 2. the whole panel is solved
       STAMPK(3);
       lds_inc(cSol, lane);
+      if (PUB && copier && early_w && progress_w) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(progress_w, progress_base + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       lds_wait_ge(cSol, RR_NW * (k + 1));
       STAMPK(4);
       if (k + 1 < T) lds_wait_ge(fP, k + 1);
@@ -1417,18 +1453,18 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       }
 #undef RR_UPDATE
       STAMPX(5);
-      // ---- the light waves solve no panel tiles: one of them copies L(k,k) and Linv(k,k) from LDS to global
-      //      memory after its (short) update chain, off every other wave's path (sLW of this parity stays
-      //      valid until every tile wave has finished step k)
-      if (w == ((k & 1) ? 7 : 3)) {
+      // ---- the same light wave copies L(k+1,k) (solved by the factor wave: fP) after its (short) update chain
+      if (copier) {
         const int row = k * TS + r15;
         double *dst = A + row + (int64_t)(k * TS + g) * lda;
-        double *Wb = W + (int64_t)k * TS * TS;
+        if (!early_w) { // a leaf block wider than ten tile columns: the light waves own tiles and share the factor wave's SIMD -- the copy stays behind their updates
+          double *Wb = W + (int64_t)k * TS * TS;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const double lv = sLW[par][r15][g + 4 * b], wv = sLW[par][TS + g + 4 * b][r15];
-          if (row < n && g + 4 * b <= r15) gstore<PUB>(&dst[(int64_t)(4 * b) * lda], lv);
-          gstore<PUB>(&Wb[(g + 4 * b) * TS + r15], wv); // Wb[k * 16 + c] = Linv(c, k): the layout solve16() reads
+          for (int b = 0; b < 4; ++b) {
+            const double lv = sLW[par][r15][g + 4 * b], wv = sLW[par][TS + g + 4 * b][r15];
+            if (row < n && g + 4 * b <= r15) gstore<PUB>(&dst[(int64_t)(4 * b) * lda], lv);
+            gstore<PUB>(&Wb[(g + 4 * b) * TS + r15], wv);
+          }
         }
         if (k + 1 < T && row + TS < n) { // L(k+1, k), solved by the factor wave, is still in LDS
 #pragma unroll
@@ -1444,6 +1480,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
         if (lane == 0) old = __hip_atomic_fetch_add(cUpd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         old = __builtin_amdgcn_readfirstlane(old);
         if (old + 1 == RR_NW * (k + 2) && lane == 0) {
+          if (!early_w && progress_w) __hip_atomic_store(progress_w, progress_base + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(progress, progress_base + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (TR && fa.xstamp && k < 24) fa.xstamp[48 + k] = __builtin_amdgcn_s_memrealtime(); // diagnostic build: column k published
         }
@@ -1606,7 +1643,8 @@ __global__ __launch_bounds__(64) void k_dinv(const double *__restrict__ Lp, int 
 template <bool PUB, int SLOTS, bool BAND = false, bool TR = false>
 __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const double *__restrict__ ws, const chol_trsm_desc d, double (*sX)[TS * TS],
                                              int wave, int lane, const int *__restrict__ progress, int progress_base, int *__restrict__ info,
-                                             int *__restrict__ chan = nullptr, unsigned long long *xst = nullptr)
+                                             int *__restrict__ chan = nullptr, unsigned long long *xst = nullptr,
+                                             const int *__restrict__ progress_w = nullptr, int progress_w_base = 0)
 { // chan (program launch): the strip's rows are followed by a POTRF workgroup -- counter chan[J] is raised once column tile J
   // of the strip has been stored (follow_external)
   const double *Lm = base + d.l_off;
@@ -1639,10 +1677,9 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
     }
     tile[s] = v;
   }
-  // L tiles (J2, J) of the updates of step J (uniform branch per slot, one scalar base per step)
+  // L tiles (J2, J) of the updates of step J (uniform branch per slot, one scalar base per step); the caller has seen column J_ published
 #define LOAD_L(J_, buf_)                                                                                \
   if ((J_) < T) {                                                                                       \
-    if (PUB) seen = wait_progress(progress, progress_base + (J_) + 1, seen, info);                      \
     const double *lb_ = Lm + (int64_t)((J_) * TS) * ldl;                                                \
     _Pragma("unroll") for (int s = 0; s < SLOTS; ++s) {                                            \
       const int J2_ = wave + 4 * s;                                                                     \
@@ -1650,10 +1687,13 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
         _Pragma("unroll") for (int st = 0; st < 4; ++st) buf_[LS(s)][st] = gload<PUB>(&lb_[VOFF(J2_) + (int64_t)(4 * st) * ldl]); \
       }                                                                                                 \
     }                                                                                                   \
+    lmask |= 1 << ((J_) % 3);                                                                           \
   }
+  // the inverse of diagonal block J_: published by the POTRF workgroup right after the block's 16x16 Cholesky (progress_w), a step or
+  // two ahead of the column's panel tiles
 #define LOAD_W(J_, buf_)                                                                                \
   {                                                                                                     \
-    if (PUB) seen = wait_progress(progress, progress_base + (J_) + 1, seen, info);                      \
+    if (PUB) seen_w = wait_progress(progress_w, progress_w_base + (J_) + 1, seen_w, info);              \
     _Pragma("unroll") for (int st = 0; st < 4; ++st) buf_[st] = gload<PUB>(&W[(int64_t)(J_) * TS * TS + (4 * st + g) * TS + r15]); \
   }
 #define PUBLISH_X(J_, x_)                                                                               \
@@ -1676,9 +1716,15 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
       acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(lpre[(JX_) % 3][LS(s_)][st], -sX[(JX_) % 3][st * 64 + lp], acc_, 0, 0, 0); \
     tile[s_] = acc_;                                                                                    \
   }
-  // operands are fetched two steps ahead; vmcnt retires in order, so the inverse the next solve waits
-  // for is issued before the L tiles of the same step
-  int seen = 0; // last progress value read (fused launch)
+  // What step J (X_J -> X_{J+1}) needs: the L tiles of column J (the pivot's column J published: `progress`) and, in the next owner, the
+  // inverse of diagonal block J + 1 (`progress_w`: in the program launch the POTRF workgroup publishes it right after the block's
+  // Cholesky, ahead of the column).  A strip that keeps up with its pivot waits for exactly that and no more -- with both behind one
+  // word, or with the L tiles of column J + 2 waited for two steps ahead, it trailed the pivot by a whole column step (2.2 us on every
+  // pivot -> parent transition of the critical path).  Columns that are already published are still fetched two steps ahead (a strip
+  // that starts late, or runs behind, pays no load latency per step).  vmcnt retires in order: the inverse is issued before the L tiles.
+  int seen = 0, seen_w = 0; // last progress values read
+  int lmask = 0;            // bit (c mod 3): the L tiles of column c are in (or on their way into) lpre[c mod 3]
+  if (!progress_w) { progress_w = progress; progress_w_base = progress_base; }
   // the inverse of column tile c is loaded by its owner (wave c mod 4) in step c - 2 and used in step c - 1: ONE buffer per wave (a ring
   // of three, as for the L tiles, was 16 more registers that the band form's strips spilled -- with a vmcnt(0) behind every prefetch)
   double lpre[3][BAND ? 1 : SLOTS][4], wpre[4];
@@ -1693,9 +1739,10 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
     }
   }
   if (wave == 0) LOAD_W(0, wpre);
-  if (wave == 1 && 1 < T) LOAD_W(1, wpre);
+  if (PUB) seen = wait_progress(progress, progress_base + 1, seen, info);
   LOAD_L(0, lpre[0]);
-  LOAD_L(1, lpre[1]);
+  if (!PUB || seen >= progress_base + 2) LOAD_L(1, lpre[1]);
+  if (wave == 1 && 1 < T) LOAD_W(1, wpre);
   if (wave == 0) { // column tile 0 has no predecessors
     const d4 x = solve16(tile[0], wpre);
     PUBLISH_X(0, x);
@@ -1733,9 +1780,15 @@ __device__ __forceinline__ void trsm_rr_body(double *__restrict__ base, const do
         }
       }
       STAMP(2);
-      // prefetch for step J+2: buffer (J+2) % 3 == (J-1) % 3 is free (deferred work uses X_J / lpre[J % 3])
+      // for step J+1: the inverse of block J+2 (its owner), the L tiles of column J+1 unless they came in ahead; then, if the pivot is
+      // that far already, column J+2 (buffer (J+2) % 3 == (J-1) % 3 is free: deferred work uses X_J / lpre[J % 3])
+      lmask &= ~(1 << ((J + 2) % 3));
       if ((J + 2 < T) && (((J + 2) & 3) == wave)) LOAD_W(J + 2, wpre);
-      LOAD_L(J + 2, lpre[(J + 2) % 3]);
+      if (J + 1 < T && !(lmask & (1 << ((J + 1) % 3)))) {
+        if (PUB) seen = wait_progress(progress, progress_base + J + 2, seen, info);
+        LOAD_L(J + 1, lpre[(J + 1) % 3]);
+      }
+      if (J + 2 < T && (!PUB || seen >= progress_base + J + 3)) LOAD_L(J + 2, lpre[(J + 2) % 3]);
       STAMP(3);
     }
   }
@@ -1833,10 +1886,12 @@ __global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ bas
   // and when it ended, and the workgroup that ran it
   __shared__ double smem[RR_SMEM_DOUBLES];
   __shared__ int s_job;
+  const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // a scalar register for the whole launch; threadIdx.x itself (a vector register that
+                                                                        // would stay live across every role body) is rebuilt per job from it and the lane count
   for (;;) {
-    int tid = threadIdx.x;
+    int tid = wave_id * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(tid)); // opaque per job: lane-dependent addresses of the role bodies are not hoisted out of this loop (and spilled)
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_id;
     const int lane = tid & 63;
     const int grp = wave >> 2;
     __syncthreads(); // the previous job is through with the LDS image
@@ -1867,17 +1922,17 @@ __global__ __launch_bounds__(RR_THREADS) void k_program(double *__restrict__ bas
       const chol_potrf_desc pd = pdescs[jb.first];
       follow_args fa;
       fa.ext = exts + jb.ext_first; fa.n_ext = jb.n_ext; fa.ctr = ctr; fa.ctr_total = ctr_total; fa.epoch = epoch; fa.wl = waits + jb.wait_first; fa.n_wl = jb.n_wait; fa.stamp = TR && trace ? &trace[4 * j + 1] : nullptr; fa.xstamp = TR && trace ? &trace[4 * njobs + CHOL_TRACE_X * j] : nullptr;
-      potrf_rr_body<true, true, TR>(base, ws, pd, info, ctr + pd.ctr, epoch * ctr_total[pd.ctr], smem, pdescs[jb.first].sky, fa, tid);
+      potrf_rr_body<true, true, TR>(base, ws, pd, info, ctr + pd.ctr, epoch * ctr_total[pd.ctr], smem, pdescs[jb.first].sky, fa, tid, ctr + pd.ctr + 1); // counter pd.ctr + 1: the block's diagonal-block progress
     } else if (jb.kind == 1) {
       double (*sX)[3][TS * TS] = (double (*)[3][TS * TS])smem;
       chol_trsm_desc d = tdescs[jb.first + min(grp, jb.n - 1)];
       if (grp >= jb.n) d.m = 0; // every group runs the same number of barriers: the strips of a job share one pivot block
       if (d.band > 0) // a banded leaf pivot factored as one block (up to CHOL_RR_MAXN columns: (CHOL_RR_MAXN / 16 + 3) / 4 column tiles per wave)
         trsm_rr_body<true, (CHOL_RR_MAXN / TS + 3) / 4, true, TR>(base, ws, d, sX[grp], wave & 3, lane, ctr + d.flag, epoch * ctr_total[d.flag], info, d.chan >= 0 ? ctr + d.chan : nullptr,
-                                                                   TR && trace && grp == 0 ? &trace[4 * njobs + CHOL_TRACE_X * j] : nullptr);
+                                                                   TR && trace && grp == 0 ? &trace[4 * njobs + CHOL_TRACE_X * j] : nullptr, ctr + d.flag + 1, epoch * ctr_total[d.flag + 1]);
       else
         trsm_rr_body<true, FUSED_SLOTS, false, TR>(base, ws, d, sX[grp], wave & 3, lane, ctr + d.flag, epoch * ctr_total[d.flag], info, d.chan >= 0 ? ctr + d.chan : nullptr,
-                                                   TR && trace && grp == 0 ? &trace[4 * njobs + CHOL_TRACE_X * j] : nullptr);
+                                                   TR && trace && grp == 0 ? &trace[4 * njobs + CHOL_TRACE_X * j] : nullptr, ctr + d.flag + 1, epoch * ctr_total[d.flag + 1]);
     } else {
       stage_waits sw;
       sw.w = waits + jb.wait_first + jb.n_pre; sw.n = jb.n_wait - jb.n_pre; sw.ctr = ctr; sw.ctr_total = ctr_total; sw.epoch = epoch; sw.info = info;

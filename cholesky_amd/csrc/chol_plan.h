@@ -52,7 +52,8 @@ typedef struct {
   int n, lda;
   int sep;            /* label (for info reporting) */
   int col0;           /* first column of this diagonal block inside its pivot (blocked big pivots) */
-  int ctr, pad;       /* program launch: the block's progress counter (columns published) */
+  int ctr, pad;       /* program launch: the block's progress counter (columns published); counter ctr + 1: diagonal blocks published (L(k,k) and its inverse,
+                       * right after the block's 16x16 Cholesky -- what a strip needs to solve column tile k, ahead of the column's panel tiles) */
   unsigned char sky[24]; /* tile-level skyline of the block (leaf pivots; all zero otherwise): tile (i, j) of the block is structurally zero for
                           * j < sky[i] -- its trailing updates are skipped (chol_kernels.hip, potrf_rr_body) */
 } chol_potrf_desc;

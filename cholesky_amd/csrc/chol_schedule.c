@@ -525,7 +525,7 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
         push_phase(B, 0, p0, w->n_potrf - p0);
         int wide = 0;
         for (int i = t0; i < w->n_trsm; i++) if (w->trsm[i].n > CHOL_TRSM_W_MAXN) wide = 1;
-        push_phase(B, wide ? 1 : 4, t0, w->n_trsm - t0);
+        push_phase(B, opts->trsm_group > 0 ? 7 : wide ? 1 : 4, t0, w->n_trsm - t0); /* (trsm_group: the fp32 schedule's throughput TRSM) */
       }
       push_phase_f(B, 6, b0, w->n_bcast - b0, 1);
       push_phase(B, 2, k0, w->n_task - k0);
@@ -1001,6 +1001,7 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
       b->c0 = st * bw; b->nb = n - b->c0 < bw ? n - b->c0 : bw;
       b->potrf = -1; b->ch_below = b->ch_par = b->ch_rest = -1;
       b->c_prog = new_ctr(P, (b->nb + CHOL_NB - 1) / CHOL_NB);
+      (void)new_ctr(P, (b->nb + CHOL_NB - 1) / CHOL_NB); /* c_prog + 1: diagonal blocks whose L(k,k), L(k,k)^-1 are published (ahead of the column: the strips solve with it) */
       b->c_strips = new_ctr(P, 0);
     }
   }
@@ -1440,19 +1441,6 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
   #undef EMIT_POTRF
   if (!rc && w->n_task_mt > 0) { chol_set_error("program launch: macro-tile update phases"); rc = CHOLAMD_ERR_ARG; }
   if (!rc && w->n_task > PROG_MAX_TASKS) { chol_set_error("program launch: %d update tasks", w->n_task); rc = CHOLAMD_ERR_ARG; }
-  if (!rc && getenv("CHOLAMD_DUMP_JOB")) { /* development aid: the tasks and sources of one update job */
-    const int jd = atoi(getenv("CHOLAMD_DUMP_JOB"));
-    if (jd >= 0 && jd < pg->n_job && pg->job[jd].kind == 2) {
-      const chol_job *jb = &pg->job[jd];
-      fprintf(stderr, "job %d: %d tasks, mode %d, %d waits (%d up front)\n", jd, jb->n, jb->mode, jb->n_wait, jb->n_pre);
-      for (int t = jb->first; t < jb->first + jb->n; t++) {
-        const chol_upd_task *tk = &w->task[t];
-        fprintf(stderr, "  task %d: %d x %d, %d sources:", t, tk->mv, tk->nv, tk->src_end - tk->src_begin);
-        for (int q = tk->src_begin; q < tk->src_end; q++) fprintf(stderr, " [k %d stage %d rows %d-%d cols %d-%d]", w->src[q].k, w->src[q].stage, w->src[q].range & 255, (w->src[q].range >> 8) & 255, (w->src[q].range >> 16) & 255, (w->src[q].range >> 24) & 255);
-        fprintf(stderr, "\n");
-      }
-    }
-  }
   for (int s = 1; s <= ns; s++) { pg->ctr_total[c_upd[s]] = cnt_upd[s]; pg->ctr_total[c_updd[s]] = cnt_updd[s]; if (P->c_updp) pg->ctr_total[P->c_updp[s]] = P->cnt_updp[s]; }
   free(P->c_updp); free(P->cnt_updp); P->c_updp = P->cnt_updp = NULL;
   for (int s = 1; s <= ns; s++) free(pb[s]);
@@ -1500,7 +1488,7 @@ int chol_program_check(const plan_t *p, const chol_sched_opts *opts, int workers
       if (ok && jb->kind == 1 && val[w.trsm[jb->first].flag] < g.ctr_total[w.trsm[jb->first].flag]) ok = 0; /* its pivot block is factored */
       if (!ok) continue;
       /* complete */
-      if (jb->kind == 0) val[w.potrf[jb->first].ctr] = g.ctr_total[w.potrf[jb->first].ctr];
+      if (jb->kind == 0) { val[w.potrf[jb->first].ctr] = g.ctr_total[w.potrf[jb->first].ctr]; val[w.potrf[jb->first].ctr + 1] = g.ctr_total[w.potrf[jb->first].ctr + 1]; }
       if (jb->kind == 1)
         for (int i = jb->first; i < jb->first + jb->n; i++)
           if (w.trsm[i].chan >= 0 && w.trsm[i].m > 0)
@@ -1637,12 +1625,39 @@ int cholamd_plan_level_work_volume(const cholamd_plan *p, int level, int rank, i
     }
   }
   out[3] = w.n_bcast;
-  for (int i = 0; i < w.n_bcast; i++) { out[4] += w.bcast[i].count; out[5] = out[5] * 1000003 + w.bcast[i].off * 31 + w.bcast[i].owner + 7 * w.bcast[i].count; }
+  for (int i = 0; i < w.n_bcast; i++) { out[4] += w.bcast[i].count; out[5] = (int64_t)((uint64_t)out[5] * 1000003u + (uint64_t)w.bcast[i].off * 31u + (uint64_t)w.bcast[i].owner + 7u * (uint64_t)w.bcast[i].count); /* a hash of the sequence: wraps (unsigned) */ }
   int nb6 = 0;
   for (int i = 0; i < w.n_phase; i++) if (w.phase[i].kind == 6) nb6 += w.phase[i].n;
   if (nb6 != w.n_bcast) { chol_set_error("internal: %d broadcast entries, %d in phases", w.n_bcast, nb6); rc = CHOLAMD_ERR_ARG; }
   chol_level_work_free(&w);
   return rc;
+}
+
+/* Volume of the extend-add exchange for (rank, world) under dist_top = 0 / 1 / 2 (auto), in arena elements: out[0] received, out[1]
+ * sent, out[2] the tail, out[3] column-block pieces (0: replicated top levels, one all-reduce of the tail -- a ring moves
+ * 2 (world - 1) / world of it each way).  Distributed top levels: a rank receives world - 1 copies of every column block it owns and
+ * sends each block it does not own once, to the owner (chol_api.cpp, exchange_owned). */
+int cholamd_plan_exchange_volume(const cholamd_plan *p, int rank, int world, int dist_top, int64_t out[4])
+{
+  chol_sched_opts o;
+  chol_sched_opts_default(&o);
+  o.dist_top = dist_top;
+  const int d = chol_split_level(world);
+  if (world < 1 || (1 << d) != world || d > p->levels - 1 || rank < 0 || rank >= world) { chol_set_error("bad partition rank %d of %d", rank, world); return CHOLAMD_ERR_ARG; }
+  out[0] = out[1] = out[3] = 0;
+  out[2] = world > 1 ? p->arena - p->panel_off[p->nsep - (world - 1) + 1] : 0;
+  for (int lvl = d - 1; lvl >= 0; lvl--) {
+    chol_level_work w;
+    int rc = chol_build_level_work(p, &o, lvl, rank, world, &w);
+    if (rc) return rc;
+    for (int i = 0; i < w.n_bcast; i++) {
+      out[3]++;
+      if (w.bcast[i].owner == rank) out[0] += w.bcast[i].count * (world - 1); else out[1] += w.bcast[i].count;
+    }
+    chol_level_work_free(&w);
+  }
+  if (out[3] == 0 && world > 1) out[0] = out[1] = 2 * out[2] * (world - 1) / world;
+  return 0;
 }
 
 void chol_level_work_free(chol_level_work *w)

@@ -83,6 +83,10 @@ class Device:
     def set_partition(self, rank, world):
         check(self.L.cholamd_device_set_partition(self.h, rank, world), "cholamd_device_set_partition")
 
+    def dist_top_active(self):
+        """True when the partitioned schedule holds broadcast phases (top levels distributed by column blocks)."""
+        return self.L.cholamd_device_bcast_phases(self.h) > 0
+
     def set_option(self, name, value):
         """Schedule / kernel-selection switch of this device object (cholamd_device_set_option)."""
         check(self.L.cholamd_device_set_option(self.h, name.encode(), int(value)), "cholamd_device_set_option")
@@ -106,6 +110,20 @@ class Device:
     def factor_sharded(self, arena, comm, stream=None):
         """This rank's part of a sharded factorisation (cholamd_factor_sharded): local levels, RCCL exchange, top levels."""
         check(self.L.cholamd_factor_sharded(self.h, self.ptr(arena), comm.h if comm is not None else None, _stream_ptr(stream)), "cholamd_factor_sharded")
+
+    def factor_sharded_f32(self, arena32, comm, stream=None):
+        """The same with the fp32 factor (cholamd_factor_sharded_f32): mixed precision x multi-GPU."""
+        check(self.L.cholamd_factor_sharded_f32(self.h, self.ptr(arena32), comm.h if comm is not None else None, _stream_ptr(stream)), "cholamd_factor_sharded_f32")
+
+    def gather_to_root(self, arena, comm, stream=None):
+        """The subtree panels this rank owns -> rank 0's arena (cholamd_gather_to_root); fp64 or fp32 arena by the tensor's dtype."""
+        check(self.L.cholamd_gather_to_root(self.h, self.ptr(arena), int(arena.element_size()), comm.h, _stream_ptr(stream)), "cholamd_gather_to_root")
+
+    def exchange_volume(self):
+        """(received, sent, tail, pieces) in elements of the extend-add exchange of this rank's partition (cholamd_exchange_volume)."""
+        out = np.zeros(4, dtype=np.int64)
+        check(self.L.cholamd_exchange_volume(self.h, out.ctypes.data), "cholamd_exchange_volume")
+        return tuple(int(v) for v in out)
 
     def info(self):
         sep = C.c_int(0)
@@ -203,8 +221,11 @@ class Comm:
 
 def factor_multi(devs, arenas, local=True, streams=None):
     """One process driving the n rank objects `devs` (devs[g] partitioned as rank g of n): cholamd_factor_multi with a LOCAL
-    communicator (device-side sums and peer copies: the ranks may share a GPU) or an RCCL one (ncclCommInitAll, one GPU per rank)."""
+    communicator (device-side sums and peer copies: the ranks may share a GPU) or an RCCL one (ncclCommInitAll, one GPU per rank).
+    fp32 arenas (torch.float32) take the fp32 schedule (cholamd_factor_multi_f32)."""
+    import torch
     L = load()
+    f32 = arenas[0].dtype == torch.float32
     n = len(devs)
     hd = (C.c_void_p * n)(*[d.h for d in devs])
     ha = (C.c_void_p * n)(*[C.c_void_p(a.data_ptr()) for a in arenas])
@@ -212,7 +233,7 @@ def factor_multi(devs, arenas, local=True, streams=None):
     hs = (C.c_void_p * n)(*[_stream_ptr(s) for s in streams]) if streams is not None else None
     check((L.cholamd_comm_create_local if local else L.cholamd_comm_create_all)(hd, n, hc), "cholamd_comm_create")
     try:
-        check(L.cholamd_factor_multi(hd, ha, hc, n, hs), "cholamd_factor_multi")
+        check((L.cholamd_factor_multi_f32 if f32 else L.cholamd_factor_multi)(hd, ha, hc, n, hs), "cholamd_factor_multi")
         for d in devs:
             d.sync()
     finally:

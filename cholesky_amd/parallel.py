@@ -53,6 +53,10 @@ def factor_sharded(dev, arena, world, tail, stream=None, group=None, via_host=Fa
         dev.factor_sharded(arena, comm, stream)
         return
     d = split_level(world)
+    if dev.dist_top_active():
+        # the top levels distributed by column blocks hold ncclBroadcast phases: they need libcholamd's communicator
+        raise RuntimeError("factor_sharded without comm= (via_host / torch all_reduce) runs the REPLICATED top levels only: "
+                           "call dev.set_option('dist_top', 0) before dev.set_partition(rank, world), or pass comm=make_comm(...)")
     dev.factor_levels(arena, levels - 1, d, stream)
     t = arena[tail:]
     if via_host:

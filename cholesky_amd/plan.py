@@ -132,6 +132,12 @@ class Plan:
         check(self.L.cholamd_plan_level_work_counts(self.h, level, rank, world, out.ctypes.data), "cholamd_plan_level_work_counts")
         return tuple(int(v) for v in out)
 
+    def exchange_volume(self, rank, world, dist_top=2):
+        """(received, sent, tail, pieces) in arena elements of the extend-add exchange of (rank, world): cholamd_plan_exchange_volume."""
+        out = np.zeros(4, dtype=np.int64)
+        check(self.L.cholamd_plan_exchange_volume(self.h, rank, world, dist_top, out.ctypes.data), "cholamd_plan_exchange_volume")
+        return tuple(int(v) for v in out)
+
     def level_work_volume(self, level, rank=0, world=1, dist_top=2):
         """(POTRF columns, TRSM elements, update volume, broadcast entries, broadcast doubles, broadcast checksum) of one level's
         lists for (rank, world) with the top levels replicated (dist_top=0), distributed by column blocks (1) or automatic (2)."""

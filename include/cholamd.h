@@ -179,6 +179,9 @@ int cholamd_plan_level_work_counts(const cholamd_plan *p, int level, int rank, i
  * POTRF columns, TRSM elements, update volume (target elements x source depth), broadcast entries, broadcast doubles, checksum
  * of the broadcast list (the same on every rank) */
 int cholamd_plan_level_work_volume(const cholamd_plan *p, int level, int rank, int world, int dist_top, int64_t out[6]);
+/* volume of the extend-add exchange of (rank, world) under dist_top 0 / 1 / 2 (auto), in arena elements: received, sent, the tail,
+ * column-block pieces (0 pieces: the all-reduce of the replicated top levels) -- the host-side count behind cholamd_exchange_volume */
+int cholamd_plan_exchange_volume(const cholamd_plan *p, int rank, int world, int dist_top, int64_t out[4]);
 /* host-side self-check of the one-launch program cholamd_factor() runs for small problems on one GPU (chol_build_program):
  * simulated with `workers` resident workgroups and every counter raised only on job completion, no job may starve; counters
  * total up; pivot blocks and TRSM rows equal those of the per-level lists.  0 = consistent, otherwise cholamd_last_error()
@@ -254,7 +257,14 @@ int cholamd_device_fill(cholamd_device *d, double *d_arena, void *stream);
  * the multi-GPU driver to run subtree levels and top levels separately.
  * A device object carries one workspace (diagonal-block inverses, progress words of the fused launches, info):
  * it serves one factorisation or solve at a time; use one object per concurrent stream of work.  The arena is
- * the caller's: any number of arenas can be factored one after the other with the same object. */
+ * the caller's: any number of arenas can be factored one after the other with the same object.
+ * Co-residency of the one-launch form: its workgroups wait for each other inside the launch.  The job list is checked when the
+ * device object is built (simulated with four resident workgroups, counters raised on job completion: a list that cannot make
+ * progress that way is not used, the per-level launches are); on a GPU shared with other kernels a job may wait for a producer
+ * that is not resident yet -- every in-launch wait gives up after about two seconds of polling and the factorisation then FAILS
+ * through info = CHOLAMD_ERR_STALL (cholamd_factor_info), it never hangs.  A stalled factorisation has written part of the arena:
+ * refill (cholamd_device_fill) before factoring again; option "program" = 0 selects the per-level launches, which need no
+ * co-residency beyond one launch. */
 int cholamd_factor(cholamd_device *d, double *d_arena, void *stream);
 int cholamd_factor_levels(cholamd_device *d, double *d_arena, int level_hi, int level_lo, void *stream);
 /* Restrict the schedule to the subtrees owned by `rank` of `world` (a power of two <= 2^(levels-1)):
@@ -298,6 +308,9 @@ int cholamd_factor_info(cholamd_device *d, int *sep_out);
  * "super_blocks", "dist_top" (0 / 1 / 2 = automatic: top levels of a partitioned run distributed by column
  * blocks, see Multi-GPU below; CHOLAMD_DIST_TOP).  Rebuilds the work lists. */
 int cholamd_device_set_option(cholamd_device *d, const char *name, int value);
+/* number of broadcast phases in the partitioned schedule (> 0: the top levels are distributed by column blocks, option "dist_top",
+ * and cholamd_factor_levels over them needs a communicator: use cholamd_factor_sharded / cholamd_factor_multi) */
+int cholamd_device_bcast_phases(const cholamd_device *d);
 /* Solve phase, mmat.rg:1364-1495: b and x in ORIGINAL dof order (device pointers, n doubles).
  * The off-diagonal blocks accumulate into the vector with hardware fp64 atomics, so x agrees from run to run to
  * rounding (~1e-16 relative), NOT bit for bit; option "solve_reference_shape" selects the deterministic per-call
@@ -356,16 +369,32 @@ int cholamd_comm_count(const cholamd_comm *c, int *ranks_out); /* ncclCommCount:
 void cholamd_comm_destroy(cholamd_comm *c);
 int cholamd_comm_allreduce(cholamd_comm *c, double *d_buf, int64_t count, void *stream); /* in-place fp64 sum (ncclAllReduce), asynchronous on `stream` */
 int64_t cholamd_device_tail_offset(const cholamd_device *d);    /* first double of the shared top of the tree in the arena (arena size if world == 1) */
-/* the exchange alone: in-place ncclAllReduce(sum) of d_arena[tail .. arena), asynchronous on `stream` */
+/* the extend-add exchange alone, asynchronous on `stream`.  Replicated top levels: in-place ncclAllReduce(sum) of d_arena[tail .. arena).
+ * Top levels distributed by column blocks (option "dist_top"): OWNER-DIRECTED -- a rank works only on the column blocks it owns after the
+ * exchange, so every rank sends its partial copy of each block it does not own straight to the owner (grouped ncclSend / ncclRecv:
+ * point-to-point over all xGMI links at once) and the owner adds the world - 1 copies to its own in rank order (deterministic).  Each
+ * rank receives (world - 1) x its owned blocks and sends the others once: (world - 1) / world of the tail each way, half a ring
+ * all-reduce's volume; blocks a rank does not own hold partial sums afterwards and are overwritten by the owners' broadcasts. */
 int cholamd_exchange_tail(cholamd_device *d, double *d_arena, cholamd_comm *c, void *stream);
+/* elements this rank receives / sends in that exchange, elements of the tail, column-block pieces (0 pieces: the all-reduce) */
+int cholamd_exchange_volume(const cholamd_device *d, int64_t out[4]);
 /* one rank's part of a sharded factorisation: local levels, exchange, top levels; asynchronous on `stream`.
  * The arena must have been filled by cholamd_device_fill AFTER cholamd_device_set_partition (rank-aware fill). */
 int cholamd_factor_sharded(cholamd_device *d, double *d_arena, cholamd_comm *c, void *stream);
+/* the same with the fp32 factor (mixed precision x multi-GPU, BASELINE config 5): fp32 arena (cholamd_device_fill_f32 after
+ * set_partition), the fp32 schedule partitioned like the fp64 one, exchange and broadcasts on floats */
+int cholamd_factor_sharded_f32(cholamd_device *d, float *d_arena32, cholamd_comm *c, void *stream);
+/* the panels of the subtrees this rank owns travel to rank 0 (grouped ncclSend / ncclRecv), whose arena then holds the complete
+ * factor -- for cholamd_solve / cholamd_solve_refine on rank 0 and the writers.  elem_bytes: 8 (fp64 arena) or 4 (fp32 arena) */
+int cholamd_gather_to_root(cholamd_device *d, void *d_arena, int elem_bytes, cholamd_comm *c, void *stream);
 /* the same for one process driving n GPUs (devs[g] partitioned as rank g of n): the n all-reduces form one RCCL group */
 int cholamd_factor_multi(cholamd_device *const *devs, double *const *arenas, cholamd_comm *const *comms, int n, void *const *streams /* or NULL */);
 /* after cholamd_factor_multi: peer-copies the panels of the subtrees owned by ranks 1..n-1 into arenas[0], which then
  * holds the complete factor (for cholamd_solve and the writers) */
 int cholamd_gather_factor(cholamd_device *const *devs, double *const *arenas, int n, void *const *streams /* or NULL */);
+/* both for the fp32 factor */
+int cholamd_factor_multi_f32(cholamd_device *const *devs, float *const *arenas32, cholamd_comm *const *comms, int n, void *const *streams /* or NULL */);
+int cholamd_gather_factor_f32(cholamd_device *const *devs, float *const *arenas32, int n, void *const *streams /* or NULL */);
 
 /* ----------------------------------------------------------------------------------------- */
 /* L-B: task level -- the four fused leaf tasks of blas.rg.  A region is a block instance:     */

@@ -6,7 +6,7 @@ set -e
 name=$1; shift
 out=cholesky_amd/lib/alt_$name
 mkdir -p $out
-/opt/rocm/bin/hipcc -O3 -fPIC --offload-arch=gfx950 -Iinclude -Icholesky_amd/csrc -Wall "$@" -c cholesky_amd/csrc/chol_kernels.hip -o $out/chol_kernels.o
+/opt/rocm/bin/hipcc -O3 -fPIC --offload-arch=gfx950 -Iinclude -Icholesky_amd/csrc -Wall -mllvm -pragma-unroll-threshold=100000 "$@" -c cholesky_amd/csrc/chol_kernels.hip -o $out/chol_kernels.o
 /opt/rocm/bin/hipcc -O3 -fPIC --offload-arch=gfx950 -Iinclude -Icholesky_amd/csrc -Wall "$@" -c cholesky_amd/csrc/chol_kernels_f32.hip -o $out/chol_kernels_f32.o
 gcc -O2 -fPIC -Wall -Wextra -std=gnu11 -Iinclude -Icholesky_amd/csrc "$@" -c cholesky_amd/csrc/chol_schedule.c -o $out/chol_schedule.o
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $out/libcholamd.so cholesky_amd/lib/chol_ingest.o cholesky_amd/lib/chol_symbolic.o $out/chol_schedule.o \

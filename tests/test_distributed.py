@@ -127,6 +127,37 @@ def _gpu_worker(rank, world, port, case, q):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("case,world", [("lapl_3375x3375", 2), ("lapl_3375x3375", 4), ("lapl_3375x3375", 8), ((24, 24, 24, 5, 32), 8), ((30, 30, 10, 5, 32), 4)])
+def test_owner_directed_exchange_volume(case, world):
+    """The extend-add exchange under the distributed top levels is OWNER-DIRECTED (SURVEY 5 communication row, 8e
+    "Collective"): a rank receives world - 1 copies of exactly the column blocks it owns and sends each block it does not own once --
+    (world - 1) / world of the tail each way in total, half of what a ring all-reduce of the whole tail moves; with replicated top
+    levels (dist_top 0) it stays the all-reduce."""
+    import cholesky_amd as ca
+    plan = ca.Plan(*case_paths(case)[:3]) if isinstance(case, str) else ca.Problem(*case).plan()
+    d = world.bit_length() - 1
+    vols = [plan.exchange_volume(r, world, 1) for r in range(world)]
+    tail = vols[0][2]
+    assert all(v[2] == tail and v[3] == vols[0][3] and v[3] > 0 for v in vols)
+    # the pieces are the broadcast lists of the levels above the cut: owners and sizes from the same (checked) lists
+    owned = [0] * world
+    total = 0
+    for lvl in range(d):
+        n_b, doubles = plan.level_work_volume(lvl, 0, world, 1)[3:5]
+        total += doubles
+    for r in range(world):
+        recv, sent, _, _ = vols[r]
+        assert recv % (world - 1) == 0
+        owned[r] = recv // (world - 1)
+        assert sent == total - owned[r]                      # every block it does not own, once
+    assert sum(owned) == total                               # every column block has exactly one owner
+    assert 0.98 * tail <= total <= tail                      # the blocks cover the tail (bar the alignment gaps between panels)
+    assert sum(v[0] for v in vols) == sum(v[1] for v in vols) == (world - 1) * total
+    ring = 2 * tail * (world - 1) // world                   # what the all-reduce moves per rank, each way
+    assert all(plan.exchange_volume(r, world, 0) == (ring, ring, tail, 0) for r in range(world))
+    assert 2 * sum(v[0] for v in vols) <= world * ring * 1.0001  # over all ranks: half of what the ring all-reduce moves
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_factorisation_matches_single_gpu(world):

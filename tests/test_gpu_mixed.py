@@ -146,3 +146,61 @@ def test_config5_matrix_100_cubed_on_one_gpu(precision):
     assert rel <= 1e-10, rel
     del a, dev
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dims,world,dist_top", [((20, 20, 20, 4, 32), 2, 1), ((20, 20, 20, 4, 32), 4, 1), ((24, 24, 24, 5, 32), 8, 1), ((24, 24, 24, 5, 32), 4, 0)])
+def test_mixed_precision_sharded_over_the_local_communicator(dims, world, dist_top, tmp_path):
+    """BASELINE config 5 as written -- mixed precision x multi-GPU: the fp32 schedule partitioned by subtrees, the extend-add exchange
+    (owner-directed under dist_top) and the broadcasts on floats (cholamd_factor_multi_f32; the rank objects share the one GPU
+    through the local communicator), the complete fp32 factor gathered on rank 0 and refined there in fp64.  The sharded fp32 factor
+    agrees with the single-GPU fp32 factor to fp32 rounding (the exchange adds the ranks' contributions in another order), the
+    refined x with the oracle's fp64 x to 1e-10."""
+    import torch
+    import cholesky_amd as ca
+    from cholesky_amd import _lib
+    from cholesky_amd.device import factor_multi
+    import ctypes as C
+    orc.use_own_kernels()
+    prob = ca.Problem(*dims)
+    m, o, c, _ = prob.write(os.path.join(tmp_path, "gen"))
+    plan = prob.plan()
+    O = orc.Oracle(m, o, c)
+    O.factor()
+    one = ca.Device(plan, 0)
+    ref32 = one.new_arena_f32()
+    one.fill_f32(ref32)
+    one.factor_f32(ref32)
+    one.sync()
+    assert one.info() == (0, 0)
+    devs, arenas = [], []
+    for r in range(world):
+        dev = ca.Device(plan, 0)
+        dev.set_option("dist_top", dist_top)
+        dev.set_partition(r, world)
+        a = dev.new_arena_f32()
+        dev.fill_f32(a)
+        devs.append(dev)
+        arenas.append(a)
+    factor_multi(devs, arenas, local=True)
+    for dev in devs:
+        assert dev.info() == (0, 0)
+    L = _lib.load()
+    n = world
+    hd = (C.c_void_p * n)(*[d.h for d in devs])
+    ha = (C.c_void_p * n)(*[C.c_void_p(a.data_ptr()) for a in arenas])
+    _lib.check(L.cholamd_gather_factor_f32(hd, ha, n, None), "cholamd_gather_factor_f32")
+    devs[0].sync()
+    full32 = arenas[0].cpu().numpy().astype(np.float64)
+    r32 = ref32.cpu().numpy().astype(np.float64)
+    scale = max(1.0, np.abs(r32).max())
+    assert np.abs(full32 - r32).max() <= 2e-5 * scale
+    Lo = np.tril(O.dense())
+    assert np.abs(np.tril(plan.arena_to_dense(full32)) - Lo).max() <= 2e-5 * np.abs(Lo).max()
+    # refinement on rank 0 with the gathered fp32 factor
+    bvec = prob.rhs()
+    xo = O.solve(bvec)
+    d_b = torch.from_numpy(bvec).cuda()
+    d_x = torch.empty_like(d_b)
+    iters, rel = devs[0].solve_refine(arenas[0], d_b, d_x, max_iter=20, tol=1e-13)
+    assert rel <= 1e-12 and iters <= 8, (iters, rel)
+    assert np.abs(d_x.cpu().numpy() - xo).max() <= TOL_X * max(1.0, np.abs(xo).max())
