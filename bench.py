@@ -253,6 +253,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     info = dev.info()  # raises on a negative (internal) code: no line is printed for a failed factorisation
+    # every factorisation of the timed region factored the same matrix: the arenas must be bit-identical (a stalled or corrupted launch in the
+    # middle of the run would otherwise go unseen: info is the last launch's)
+    if world == 1 and K <= n_arenas and not all(bool(torch.equal(arenas[(done + i) % n_arenas], arenas[done % n_arenas])) for i in range(1, K)):
+        sys.exit("bench.py: the factors of the timed steps differ from each other (a launch failed or is not deterministic)")
     if world > 1:
         bad = torch.tensor([1.0 if info[0] != 0 else 0.0], device="cuda")
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)

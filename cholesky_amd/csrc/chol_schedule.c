@@ -1001,7 +1001,6 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
       b->c0 = st * bw; b->nb = n - b->c0 < bw ? n - b->c0 : bw;
       b->potrf = -1; b->ch_below = b->ch_par = b->ch_rest = -1;
       b->c_prog = new_ctr(P, (b->nb + CHOL_NB - 1) / CHOL_NB);
-      (void)new_ctr(P, (b->nb + CHOL_NB - 1) / CHOL_NB); /* c_prog + 1: diagonal blocks whose L(k,k), L(k,k)^-1 are published (ahead of the column: the strips solve with it) */
       b->c_strips = new_ctr(P, 0);
     }
   }
@@ -1488,7 +1487,7 @@ int chol_program_check(const plan_t *p, const chol_sched_opts *opts, int workers
       if (ok && jb->kind == 1 && val[w.trsm[jb->first].flag] < g.ctr_total[w.trsm[jb->first].flag]) ok = 0; /* its pivot block is factored */
       if (!ok) continue;
       /* complete */
-      if (jb->kind == 0) { val[w.potrf[jb->first].ctr] = g.ctr_total[w.potrf[jb->first].ctr]; val[w.potrf[jb->first].ctr + 1] = g.ctr_total[w.potrf[jb->first].ctr + 1]; }
+      if (jb->kind == 0) val[w.potrf[jb->first].ctr] = g.ctr_total[w.potrf[jb->first].ctr];
       if (jb->kind == 1)
         for (int i = jb->first; i < jb->first + jb->n; i++)
           if (w.trsm[i].chan >= 0 && w.trsm[i].m > 0)
