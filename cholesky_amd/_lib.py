@@ -120,6 +120,9 @@ def load():
     L.cholamd_gather_to_root.argtypes = [vp, vp, ci, vp, vp]
     L.cholamd_exchange_volume.argtypes = [vp, vp]
     L.cholamd_plan_exchange_volume.argtypes = [vp, ci, ci, ci, vp]
+    L.cholamd_follow_rounds.argtypes = [ci, ci, ci, vp, vp]
+    L.cholamd_plan_program_followers.argtypes = [vp, i64, vp]
+    L.cholamd_plan_program_followers.restype = i64
     L.cholamd_factor_multi_f32.argtypes = [vp, vp, vp, ci, vp]
     L.cholamd_gather_factor_f32.argtypes = [vp, vp, ci, vp]
     L.cholamd_device_alloc.argtypes = [vp, i64, C.POINTER(vp)]

@@ -944,27 +944,19 @@ __device__ __forceinline__ void follow_external(const double *__restrict__ base,
   // whenever all of it is known to be ready.
   int ready = 0, ng = 0; // ng: items of the round starting at i whose loads are in flight (0 = not issued)
   double va[FOLLOW_LOADS], vb[FOLLOW_LOADS];
-#ifndef FOLLOW_SINGLE_TAIL
-#define FOLLOW_SINGLE_TAIL 0 /* last items of a follower's list that go one by one (0 / 1 / 2: 189.5 / 190.4 / 190.2 us on lapl_3375, 44.5 / 45.0 / 45.1 on lapl_400) */
-#endif
 #ifndef FOLLOW_OWN_SLEEP
 #define FOLLOW_OWN_SLEEP 4
 #endif
 #ifndef FOLLOW_OWN_LAST_MAX
 #define FOLLOW_OWN_LAST_MAX 0 /* followers with at most this many items add their own tiles after the last one (3: lapl_3375 unchanged, lapl_400 45.8 -> 48.9 us) */
 #endif
-#ifndef FOLLOW_OWN_BEFORE
-#define FOLLOW_OWN_BEFORE 2  /* the follower's own tiles are added before its last FOLLOW_OWN_BEFORE items (<= FOLLOW_SINGLE_TAIL: never inside a pair) */
-#endif
-  const int pair_lim = 2 * T <= RR_MAXT ? f.n_ext - FOLLOW_SINGLE_TAIL : 0; // items [i, i + 1] form a round while i + 1 < pair_lim
+  static_assert(CHOL_FOLLOW_PAIR_MAXT == RR_MAXT, "a pair of followed column tiles shares one LDS buffer of RR_MAXT tiles");
   // where the follower's own tiles go in: before the last FOLLOW_OWN_BEFORE items (their round trip hides behind the wait for those) -- or,
   // for a follower with one source and a tail only (the next column block of a split pivot: its early jobs hang on the same strips as
   // its tail, they end after the tail has arrived), after the last item
-  int own_at = f.n_ext <= FOLLOW_OWN_LAST_MAX ? f.n_ext : 0;
-  if (own_at == 0) // the last round that starts at or before item n_ext - FOLLOW_OWN_BEFORE (never the second item of a pair)
-    for (int i = 0; i < f.n_ext; i += (i + 1 < pair_lim ? 2 : 1))
-      if (i <= f.n_ext - FOLLOW_OWN_BEFORE) own_at = i;
-#define EXT_ROUND(I_) ((I_) + 1 < pair_lim ? 2 : 1)
+  // (rounds and the own tiles' place: chol_follow_round / chol_follow_own_at in chol_plan.h -- functions of the list alone, checked on the host)
+  const int own_at = f.n_ext <= FOLLOW_OWN_LAST_MAX ? f.n_ext : chol_follow_own_at(f.n_ext, T);
+#define EXT_ROUND(I_) chol_follow_round(I_, f.n_ext, T)
 #define EXT_LOAD(I_, V_)                                                                                             \
   {                                                                                                                  \
     const chol_ext xl_ = f.ext[I_];                                                                                  \

@@ -120,6 +120,31 @@ typedef struct {       /* one followed column tile: (rows of the follower's bloc
   int ld, ncol;        /* leading dimension of the source panel, columns of the tile (<= 16) */
   int ctr, need;       /* counter raised by every one of the `need` strips covering the rows once it has stored this column tile */
 } chol_ext;
+/* How a follower consumes its list of followed column tiles (follow_external): in ROUNDS of one or two items.  The grouping is a pure
+ * function of (position in the list, length of the list, column tiles of the follower) -- every wave of the workgroup walks the list for
+ * itself and must count the same barriers (a grouping that depended on what had been published at the time dead-locked once: the waves
+ * disagreed).  Shared by the kernel and the host-side check (cholamd_follow_rounds, tests/test_host.py). */
+#define CHOL_FOLLOW_PAIR_MAXT 17   /* two column tiles share an LDS buffer of this many tiles */
+#define CHOL_FOLLOW_SINGLE_TAIL 0  /* last items of a list that go one by one (0 / 1 / 2 measured: 189.5 / 190.4 / 190.2 us on lapl_3375) */
+#define CHOL_FOLLOW_OWN_BEFORE 2   /* the follower's own tiles go in at the last round that starts at or before item n - CHOL_FOLLOW_OWN_BEFORE */
+#if defined(__HIPCC__)
+#define CHOL_HD __host__ __device__ __forceinline__
+#else
+#define CHOL_HD static inline
+#endif
+CHOL_HD int chol_follow_round(int i, int n_ext, int T)
+{ /* items of the round that starts at item i */
+  const int pair_lim = 2 * T <= CHOL_FOLLOW_PAIR_MAXT ? n_ext - CHOL_FOLLOW_SINGLE_TAIL : 0; /* items [i, i + 1] form a round while i + 1 < pair_lim */
+  return i + 1 < pair_lim ? 2 : 1;
+}
+CHOL_HD int chol_follow_own_at(int n_ext, int T)
+{ /* first item of the round in front of which the follower's own tiles are added */
+  int own_at = 0;
+  for (int i = 0; i < n_ext; i += chol_follow_round(i, n_ext, T))
+    if (i <= n_ext - CHOL_FOLLOW_OWN_BEFORE) own_at = i;
+  return own_at;
+}
+
 typedef struct {
   int n_job; chol_job *job;
   int n_wait; chol_wait *wait;

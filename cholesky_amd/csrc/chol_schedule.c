@@ -1580,6 +1580,31 @@ int64_t cholamd_plan_program_jobs(const cholamd_plan *p, int follow, int64_t cap
   chol_level_work_free(&w); chol_program_free(&g);
   return need;
 }
+int cholamd_follow_rounds(int n_ext, int tile_columns, int cap, int *rounds_out, int *own_at_out)
+{ /* the rounds in which a follower of `tile_columns` column tiles consumes a list of n_ext followed column tiles (the kernel's own functions,
+   * chol_plan.h): returns the number of rounds, their sizes in rounds_out[0 .. cap), the item in front of which its own tiles go in */
+  int n = 0;
+  for (int i = 0; i < n_ext; i += chol_follow_round(i, n_ext, tile_columns), n++)
+    if (n < cap && rounds_out) rounds_out[n] = chol_follow_round(i, n_ext, tile_columns);
+  if (own_at_out) *own_at_out = chol_follow_own_at(n_ext, tile_columns);
+  return n;
+}
+int64_t cholamd_plan_program_followers(const cholamd_plan *p, int64_t cap, int *out)
+{ /* per following POTRF job of the program launch: job index, followed column tiles, column tiles of its pivot block, wait-list entries (3 ints) */
+  chol_sched_opts o;
+  chol_sched_opts_default(&o);
+  chol_level_work w; chol_program g;
+  if (chol_build_program(p, &o, &w, &g)) return -1;
+  int64_t n = 0;
+  for (int j = 0; j < g.n_job; j++) {
+    const chol_job *jb = &g.job[j];
+    if (jb->kind != 0 || jb->n_ext <= 0) continue;
+    if (4 * n + 3 < cap) { out[4 * n] = j; out[4 * n + 1] = jb->n_ext; out[4 * n + 2] = (w.potrf[jb->first].n + CHOL_NB - 1) / CHOL_NB; out[4 * n + 3] = jb->n_wait; }
+    n++;
+  }
+  chol_level_work_free(&w); chol_program_free(&g);
+  return n;
+}
 int cholamd_plan_program_counts(const cholamd_plan *p, int follow, int out[6])
 { /* jobs, POTRF jobs that follow, update tasks, TRSM strips, counters, followed panels */
   chol_sched_opts o;

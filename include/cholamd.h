@@ -191,6 +191,10 @@ int cholamd_plan_program_check(const cholamd_plan *p, int follow, int workers);
  * switches as the environment sets them at the time of the call */
 int cholamd_plan_program_check_opts(const cholamd_plan *p, int follow_tail, int split_min, int split_nb, int workers);
 int cholamd_plan_program_counts(const cholamd_plan *p, int follow, int out[6]);
+/* the rounds (of one or two followed column tiles) in which a following POTRF job of `tile_columns` column tiles consumes a list of n_ext items --
+ * the kernel's own grouping, a function of the list alone; and the following jobs of a plan's program: (job, items, tile columns, waits) each */
+int cholamd_follow_rounds(int n_ext, int tile_columns, int cap, int *rounds_out, int *own_at_out);
+int64_t cholamd_plan_program_followers(const cholamd_plan *p, int64_t cap, int *out);
 int64_t cholamd_plan_program_jobs(const cholamd_plan *p, int follow, int64_t cap, int *out); /* diagnostic dump of the job queue (scripts/prog_trace.py) */ /* jobs, following POTRF jobs, update tasks, strips, counters, followed panels */
 /* dense N x N col-major image of an arena (zeros outside allocated blocks) and back */
 int cholamd_plan_arena_to_dense(const cholamd_plan *p, const double *arena, double *dense);

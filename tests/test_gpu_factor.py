@@ -164,7 +164,7 @@ def _snap_by_block(plan, lbl):
     return d
 
 
-@pytest.mark.parametrize("case", ["lapl_9x9", "lapl_25x25", "lapl_400x400"])
+@pytest.mark.parametrize("case", ["lapl_9x9", "lapl_25x25", "lapl_400x400", "lapl_3375x3375"])
 def test_fused_tasks_replay_reference_main_loop(case, ca, runs):
     import torch
     blas = ca.blas

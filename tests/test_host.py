@@ -283,3 +283,40 @@ def test_program_launch_on_generated_problems():
     big = ca.Problem(24, 24, 12, 2, 64).plan()
     with pytest.raises(ca.CholamdError):
         big.program_check(1, 256)
+
+
+def test_follower_round_grouping_is_a_function_of_the_list_alone():
+    """How a following POTRF job groups its followed column tiles into rounds (one or two per round) is computed by every wave of the
+    workgroup for itself; the waves count barriers by it, so it must depend on nothing but the list (its length) and the block's
+    tile columns -- a grouping by what happened to be published once dead-locked.  The kernel takes the grouping from
+    chol_follow_round / chol_follow_own_at (chol_plan.h); the same functions are checked here for every follower of every fixture's
+    program and exhaustively for small cases."""
+    import ctypes as C
+    from cholesky_amd import _lib
+    L = _lib.load()
+
+    def rounds(n_ext, T):
+        buf = (C.c_int * 64)()
+        own = C.c_int(-1)
+        n = L.cholamd_follow_rounds(n_ext, T, 64, buf, C.byref(own))
+        return [buf[i] for i in range(min(n, 64))], own.value
+
+    for T in range(1, 11):
+        for n_ext in range(1, 41):
+            r, own = rounds(n_ext, T)
+            assert (r, own) == rounds(n_ext, T)                                   # a pure function: the same answer every time
+            assert sum(r) == n_ext and all(x in (1, 2) for x in r)                 # the rounds tile the list, in order
+            assert all(x == 1 for x in r) or 2 * T <= 17                           # two column tiles share an LDS buffer of 17 tiles
+            starts = [sum(r[:i]) for i in range(len(r))]
+            assert own in starts and own <= max(n_ext - 2, 0)                      # the own tiles go in in front of a round, never inside a pair
+            assert own == max(s0 for s0 in starts if s0 <= max(n_ext - 2, 0))      # ... the last such round
+    import cholesky_amd as ca
+    for case in ("lapl_25x25", "lapl_400x400", "lapl_3375x3375"):
+        plan = ca.Plan(*case_paths(case)[:3])
+        buf = (C.c_int * 4096)()
+        nf = L.cholamd_plan_program_followers(plan.h, 4096, buf)
+        assert nf > 0
+        for i in range(nf):
+            job, n_ext, T, n_wait = buf[4 * i], buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]
+            r, own = rounds(n_ext, T)
+            assert 1 <= T <= 10 and n_ext >= 1 and sum(r) == n_ext, (case, job)
