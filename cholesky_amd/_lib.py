@@ -24,7 +24,8 @@ class Op(C.Structure):
 
 
 class Region(C.Structure):
-    _fields_ = [("ptr", C.c_void_p), ("ld", C.c_int), ("lo_x", C.c_int), ("lo_y", C.c_int), ("hi_x", C.c_int), ("hi_y", C.c_int)]
+    _fields_ = [("ptr", C.c_void_p), ("ld", C.c_int), ("lo_x", C.c_int), ("lo_y", C.c_int), ("hi_x", C.c_int), ("hi_y", C.c_int),
+                ("tile_row", C.POINTER(C.c_int))]
 
 
 class SepInfo(C.Structure):
@@ -149,6 +150,10 @@ def load():
     L.cholamd_comm_count.argtypes = [vp, C.POINTER(ci)]
     L.cholamd_device_event_overhead.argtypes = [vp, vp, C.POINTER(C.c_float)]
     RP, FP = C.POINTER(Region), C.POINTER(Filled)
+    L.cholamd_plan_region.argtypes = [vp, vp, ci, ci, RP]
+    L.cholamd_plan_arena_dense_doubles.argtypes = [vp]
+    L.cholamd_plan_arena_dense_doubles.restype = C.c_int64
+    L.cholamd_plan_block_tile_map.argtypes = [vp, ci, ci, vp]
     L.cholamd_fused_dpotrf.argtypes = [RP, FP, ci, ci, ci, ci, vp]
     L.cholamd_fused_dtrsm.argtypes = [RP, RP, FP, ci, FP, ci, ci, ci, ci, vp]
     L.cholamd_fused_dsyrk.argtypes = [RP, RP, RP, FP, ci, FP, ci, FP, ci, ci, ci, ci, ci, vp]

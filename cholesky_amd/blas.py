@@ -90,7 +90,15 @@ def openblas_set_num_threads(n):
 
 # ---- task level ---------------------------------------------------------------------------------
 def region(ptr, ld, lo_x, lo_y, hi_x, hi_y):
-    return Region(C.c_void_p(ptr), ld, lo_x, lo_y, hi_x, hi_y)
+    """A dense block instance: every row lo_x..hi_x stored from ptr."""
+    return Region(C.c_void_p(ptr), ld, lo_x, lo_y, hi_x, hi_y, None)
+
+
+def plan_region(plan, arena_ptr, r, c):
+    """Block instance (r, c) of an arena laid out by `plan` (row-compacted above the parent block: Region.tile_row)."""
+    rg = Region()
+    check(load().cholamd_plan_region(plan.h, C.c_void_p(arena_ptr), r, c, C.byref(rg)), "plan_region")
+    return rg
 
 
 def _arr(filled_list):

@@ -269,6 +269,7 @@ extern "C" int cholamd_device_set_option(cholamd_device *d, const char *name, in
   else if (n == "staged") d->opt.staged = value != 0;
   else if (n == "fine_upd") d->opt.fine_upd = value != 0;
   else if (n == "skyline") d->opt.skyline = value != 0;
+  else if (n == "merge_targets") d->opt.merge_targets = value != 0;
   else if (n == "trsm_wt_min") d->opt.trsm_wt_min = value < 0 ? 0 : value;
   else if (n == "stage_chunk") d->opt.stage_chunk = value < 0 ? 0 : value;
   else if (n == "dist_top") d->opt.dist_top = value;
@@ -888,8 +889,10 @@ static int run_potrf(const std::vector<chol_potrf_desc> &v, hipStream_t st, int 
 
 // ---- L-B: fused leaf tasks -------------------------------------------------------------------
 static double *tile_ptr(const cholamd_region *r, const cholamd_filled *f)
-{ // get_raw_ptr_2d, blas.rg:35-43
-  return r->ptr + (f->lo_x - r->lo_x) + (int64_t)(f->lo_y - r->lo_y) * r->ld;
+{ // get_raw_ptr_2d, blas.rg:35-43; a row-compacted block instance stores only the 16-row tiles its filled tiles touch (tile_row)
+  const int row = f->lo_x - r->lo_x;
+  const int64_t srow = r->tile_row ? (int64_t)r->tile_row[row / CHOL_NB] * CHOL_NB + row % CHOL_NB : row;
+  return r->ptr + srow + (int64_t)(f->lo_y - r->lo_y) * r->ld;
 }
 static int region_ok(const cholamd_region *r, const char *name)
 {
@@ -902,6 +905,21 @@ static int tile_inside(const cholamd_region *r, const cholamd_filled *f)
     chol_set_error("tile (%d,%d,%d) lies outside its region", f->sep_x, f->sep_y, f->cluster);
     return CHOLAMD_ERR_ARG;
   }
+  if (r->tile_row) // every row of the tile must have storage, consecutively
+    for (int t = (f->lo_x - r->lo_x) / CHOL_NB; t <= (f->hi_x - r->lo_x) / CHOL_NB; t++)
+      if (r->tile_row[t] < 0 || (t > (f->lo_x - r->lo_x) / CHOL_NB && r->tile_row[t] != r->tile_row[t - 1] + 1)) {
+        chol_set_error("tile (%d,%d,%d) touches rows its region does not store", f->sep_x, f->sep_y, f->cluster);
+        return CHOLAMD_ERR_ARG;
+      }
+  return 0;
+}
+
+extern "C" int cholamd_plan_region(const cholamd_plan *p, double *d_arena, int r, int c, cholamd_region *out)
+{
+  const chol_block *B = chol_plan_block(p, r, c);
+  if (!B || !out) { chol_set_error("no block (%d, %d)", r, c); return CHOLAMD_ERR_ARG; }
+  cholamd_region rg = { d_arena + B->off, B->ld, B->lo_x, B->lo_y, B->hi_x, B->hi_y, B->tmap };
+  *out = rg;
   return 0;
 }
 
@@ -1038,7 +1056,7 @@ extern "C" int cholamd_factor_debug(cholamd_device *d, double *d_arena, const ch
   std::vector<double> host((size_t)p->arena);
   auto region_of = [&](int r, int c) {
     const chol_block *B = chol_plan_block(p, r, c);
-    cholamd_region rg = { d_arena + B->off, B->ld, B->lo_x, B->lo_y, B->hi_x, B->hi_y };
+    cholamd_region rg = { d_arena + B->off, B->ld, B->lo_x, B->lo_y, B->hi_x, B->hi_y, B->tmap };
     return rg;
   };
   for (int lvl = L - 1; lvl >= 0; lvl--) {

@@ -2268,9 +2268,10 @@ __global__ __launch_bounds__(256) void k_gemv_fwd(const double *__restrict__ bas
   bool valid = false;
   for (int s = grp_start[g]; s < grp_start[g + 1]; ++s) {
     const chol_gemv_desc d = descs[s];
-    if (r < d.m) {
+    const int rr = r - d.y_off; // the source's rows start at row y_off of the target separator (a stored row run of its block)
+    if (rr >= 0 && rr < d.m) {
       valid = true;
-      const double *A = base + d.a_off + r;
+      const double *A = base + d.a_off + rr;
       const double *x = y + d.x_off;
       for (int k = 0; k < d.n; ++k) acc += A[(int64_t)k * d.lda] * x[k];
     }

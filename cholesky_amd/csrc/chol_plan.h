@@ -4,8 +4,13 @@
  * cholesky.cc:65-73): ONE contiguous fp64 arena holding one column-major PANEL per separator s.
  * Panel(s) has the separator's own columns (n_s of them) and the rows of s followed by the rows
  * of every ancestor of s in increasing permuted position (parent, grand-parent, ..., root), so
- * block (anc, s) of the reference is the row slice [row_off(anc) .. +n_anc) of panel(s) with the
- * panel's leading dimension.  Panels are laid out by ascending label, hence the panels of the top
+ * block (anc, s) of the reference is a row slice of panel(s) with the panel's leading dimension.
+ * ROW COMPACTION: the slice of the separator itself and of its parent hold every row; the slice of a
+ * higher ancestor holds only the 16-row tiles (rows 16 t .. 16 t + 15 of the ancestor) that a filled tile
+ * of the block touches at the time the separator is eliminated -- the others stay zero in the reference's
+ * dense block and are never read or written (blas.rg:385-395), here they have no storage
+ * (chol_block.tmap / chol_block_row; lapl_3375: 13.9 -> 8.9 MB, gen 60^3: 15.2 -> 5.1 GB).
+ * Panels are laid out by ascending label, hence the panels of the top
  * of the tree (root last) form a contiguous tail of the arena -- the extend-add exchange buffer of
  * the multi-GPU driver.
  */
@@ -41,8 +46,19 @@ typedef struct {
   int r, c;                       /* labels */
   int lo_x, lo_y, hi_x, hi_y;     /* permuted coords, inclusive */
   int rows, cols, ld;
-  int64_t off;                    /* arena offset (doubles) of element (lo_x, lo_y) */
+  int64_t off;                    /* arena offset (doubles) of the block's first stored row in column lo_y */
+  int *tmap;                      /* row compaction: tmap[t] = position of the block's 16-row tile t among the tiles the panel stores, -1 = not
+                                   * stored (structurally zero); NULL: every row is stored (diagonal and parent blocks, CHOLAMD_COMPACT=0) */
+  int crows;                      /* rows the panel stores for this block */
 } chol_block;
+/* arena offset of row `row` (relative to the block) in the block's first column; rows of one filled tile, or of adjacent filled tiles, are
+ * consecutive.  -1: the row has no storage */
+static inline int64_t chol_block_row(const chol_block *B, int row)
+{
+  if (!B->tmap) return B->off + row;
+  const int t = B->tmap[row / CHOL_NB];
+  return t < 0 ? -1 : B->off + (int64_t)t * CHOL_NB + row % CHOL_NB;
+}
 
 /* device-side work descriptors (shared with the kernels; plain ints / int64 offsets in doubles
  * relative to a base pointer passed at launch) */
@@ -187,6 +203,8 @@ typedef struct {
   int follow_tail_split;    /* the same tail for the next column block of a split pivot (one source: the strips of its own rows) */
   int follow_tail;          /* a follower wider than CHOL_FOLLOW_ALL_MAXT column tiles takes only the LAST follow_tail column tiles of each source
                              * itself; the columns before them reach its diagonal block through update jobs on other CUs (0: follows everything) */
+  int merge_targets;        /* level schedule: extend-add targets (and the row runs of a panel) that are neighbours in storage are merged, so that the
+                             * 64x64 macro tiles and the 16-row strips fill up (bit-identical sums) */
   int super_blocks;         /* column blocks per super-block of a wide pivot: the trailing matrix beyond a super-block gets one update of
                              * rank super_blocks * (block width) instead of one per block */
 } chol_sched_opts;
@@ -220,7 +238,8 @@ typedef struct {
   int64_t dinv_off; /* the separator's 16x16 diagonal-block inverses in the solve workspace */
 } chol_trsv_desc;
 typedef struct {
-  int64_t a_off; int m, n, lda; int x_off, y_off; /* y(m) -= A x(n)  or  y(n) -= A^T x(m) */
+  int64_t a_off; int m, n, lda; int x_off, y_off; /* y(m) -= A x(n)  or  y(n) -= A^T x(m); one descriptor per stored row run of a block.  Forward sources of the
+                                                   * target-centric level solve (chol_solve_level.fw): y_off = the run's first row inside the target separator */
 } chol_gemv_desc;
 
 struct cholamd_plan {
@@ -236,7 +255,9 @@ struct cholamd_plan {
   chol_clusters *cl;              /* index 1..nsep */
   int nblk; chol_block *blk;
   int *blk_index;                 /* (nsep+1)^2 -> index into blk or -1 */
-  int64_t *panel_off; int *panel_ld, *panel_rows; /* per label */
+  int64_t *panel_off; int *panel_ld, *panel_rows; /* per label (panel_rows: rows stored) */
+  int compact;                    /* row compaction of the ancestor blocks in force */
+  int64_t arena_dense;            /* what the arena would be with every ancestor row stored */
   int64_t arena;                  /* doubles */
   int64_t ws_doubles;             /* workspace (inverted diagonal blocks) */
   int64_t *dinv_off;              /* per label */

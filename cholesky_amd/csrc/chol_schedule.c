@@ -49,11 +49,39 @@ typedef struct {
   int src_sep;        /* the separator whose panel the contribution comes from */
 } upd_tuple;
 
+/* a target of the extend-add with its sources tu[i, e): one cluster-tile pair, or several merged ones */
+typedef struct { int i, e, bc, crow, ccol, m, n, syrk; int64_t c_off; int ldc, dead; } tgt_group;
+static int cmp_group_rows(const void *x, const void *y)
+{
+  const tgt_group *a = x, *b = y;
+  if (a->bc != b->bc) return a->bc < b->bc ? -1 : 1;
+  if (a->ccol != b->ccol) return a->ccol < b->ccol ? -1 : 1;
+  if (a->n != b->n) return a->n < b->n ? -1 : 1;
+  return a->crow < b->crow ? -1 : (a->crow > b->crow);
+}
+static int cmp_group_first(const void *x, const void *y)
+{
+  const tgt_group *a = x, *b = y;
+  return a->i < b->i ? -1 : (a->i > b->i);
+}
+/* the sources of b are those of a, shifted by dr rows in the A operand and dc rows in the B operand */
+static int same_sources(const upd_tuple *tu, const tgt_group *a, const tgt_group *b, int dr, int dc);
+
 static int cmp_tuple(const void *x, const void *y)
 {
   const upd_tuple *a = x, *b = y;
   if (a->key != b->key) return a->key < b->key ? -1 : 1;
   return a->seq < b->seq ? -1 : (a->seq > b->seq);
+}
+
+static int same_sources(const upd_tuple *tu, const tgt_group *a, const tgt_group *b, int dr, int dc)
+{
+  if (a->e - a->i != b->e - b->i) return 0;
+  for (int q = 0; q < a->e - a->i; q++) {
+    const upd_tuple *x = &tu[a->i + q], *y = &tu[b->i + q];
+    if (x->src_sep != y->src_sep || x->lda != y->lda || x->ldb != y->ldb || x->k != y->k || y->a_off != x->a_off + dr || y->b_off != x->b_off + dc) return 0;
+  }
+  return 1;
 }
 
 /* index of the filled tiles of snapshot lbl per block: first[b], count[b] */
@@ -88,7 +116,7 @@ static int env_int(const char *name, int dflt) { const char *e = getenv(name); r
 void chol_sched_opts_default(chol_sched_opts *o)
 {
   o->split_min = CHOL_SPLIT_MIN; o->split_nb = CHOL_SPLIT_NB; o->fuse = 1; o->fuse_update_max = CHOL_FUSE_UPDATE_MAX;
-  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->trsm_wt_min = CHOL_TRSM_WT_MIN; o->trsm_group = 0; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL; o->follow_tail_split = CHOL_FOLLOW_TAIL; o->staged = 1; o->fine_upd = 1; o->skyline = 1; o->stage_chunk = CHOL_STAGE_CHUNK;
+  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->trsm_wt_min = CHOL_TRSM_WT_MIN; o->trsm_group = 0; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL; o->follow_tail_split = CHOL_FOLLOW_TAIL; o->staged = 1; o->fine_upd = 1; o->skyline = 1; o->stage_chunk = CHOL_STAGE_CHUNK; o->merge_targets = 1;
 }
 void chol_sched_opts_from_env(chol_sched_opts *o)
 {
@@ -109,6 +137,7 @@ void chol_sched_opts_from_env(chol_sched_opts *o)
   o->staged = !env_int("CHOLAMD_NO_STAGED", 0);
   o->fine_upd = !env_int("CHOLAMD_NO_FINE_UPD", 0);
   o->skyline = !env_int("CHOLAMD_NO_SKYLINE", 0);
+  o->merge_targets = !env_int("CHOLAMD_NO_MERGE_TARGETS", 0);
   o->stage_chunk = env_int("CHOLAMD_STAGE_CHUNK", o->stage_chunk);
 }
 static int split_nb(const chol_sched_opts *o) { int v = o->split_nb; if (v > CHOL_RR_MAXN) v = CHOL_RR_MAXN; v = (v + 15) / 16 * 16; if (v < 16) v = 16; return v; }
@@ -278,7 +307,7 @@ static int emit_cell_tasks(builder *B, const plan_t *p, const upd_tuple *tu, int
         const int c0 = (u->ccol > 16 * J ? u->ccol : 16 * J) - 16 * J, c1 = (u->ccol + u->n < 16 * J + 16 ? u->ccol + u->n : 16 * J + 16) - 16 * J;
         q->key = ((int64_t)u->bc << 40) | ((int64_t)I << 20) | (int64_t)J;
         q->seq = u->seq;
-        q->c_off = Bc->off + 16 * I + (int64_t)(16 * J) * Bc->ld; q->ldc = Bc->ld;
+        q->c_off = chol_block_row(Bc, 16 * I) + (int64_t)(16 * J) * Bc->ld; q->ldc = Bc->ld;
         q->mv = Bc->rows - 16 * I < 16 ? Bc->rows - 16 * I : 16;
         q->nv = Bc->cols - 16 * J < 16 ? Bc->cols - 16 * J : 16;
         q->lower = diag && I == J;
@@ -353,32 +382,36 @@ static int tuples_are_small(const chol_sched_opts *o, const upd_tuple *tu, int n
 
 /* filled row runs of the ancestor blocks of panel(s): (arena offset of the run's first row in column 0
  * of the panel, rows); tiles come in increasing row order and adjacent ones are merged */
-typedef struct { int64_t off; int m; } row_run;
+typedef struct { int64_t off; int m; int64_t pos; } row_run; /* pos: the run's first row in the panel's uncompacted row numbering (adjacency is decided there) */
 /* which: 0 = every ancestor, 1 = the parent only, 2 = every ancestor but the parent */
-static int ancestor_runs_of(const plan_t *p, int h, int which, const cholamd_filled *snap, const int64_t *first, const int *count, row_run **out)
+static int ancestor_runs_of(const plan_t *p, int h, int which, int by_storage, const cholamd_filled *snap, const int64_t *first, const int *count, row_run **out)
 {
   const int s = p->tree[h];
   int cap = 16, n = 0;
   row_run *r = malloc(cap * sizeof(row_run));
-  for (int hp = h / 2; hp >= 1; hp /= 2) {
+  int64_t base = p->sep_size[s]; /* rows in front of the block in the uncompacted panel */
+  for (int hp = h / 2; hp >= 1; base += p->sep_size[p->tree[hp]], hp /= 2) {
     if ((which == 1 && hp != h / 2) || (which == 2 && hp == h / 2)) continue;
     const int b = BIDX(p, p->tree[hp], s);
     const chol_block *Bk = &p->blk[b];
     for (int q = 0; q < count[b]; q++) {
       const cholamd_filled *f = &snap[first[b] + q];
-      const int64_t off = Bk->off + (f->lo_x - Bk->lo_x);
+      const int64_t off = chol_block_row(Bk, f->lo_x - Bk->lo_x), pos = base + (f->lo_x - Bk->lo_x);
       const int m = f->hi_x - f->lo_x + 1;
-      if (n > 0 && r[n - 1].off + r[n - 1].m == off) { r[n - 1].m += m; continue; }
+      /* adjacent rows (of adjacent kept tiles) are adjacent in storage; with `by_storage` also runs that only storage makes neighbours
+       * (the unkept tiles between them have no rows): the rows of a panel are independent in the TRSM and in the panel's own trailing
+       * update, so longer runs mean fuller strips and macro tiles and the same numbers */
+      if (n > 0 && (by_storage || r[n - 1].pos + r[n - 1].m == pos) && r[n - 1].off + r[n - 1].m == off) { r[n - 1].m += m; continue; }
       if (n == cap) { cap *= 2; r = realloc(r, cap * sizeof(row_run)); }
-      r[n].off = off; r[n].m = m; n++;
+      r[n].off = off; r[n].m = m; r[n].pos = pos; n++;
     }
   }
   *out = r;
   return n;
 }
-static int ancestor_runs(const plan_t *p, int h, const cholamd_filled *snap, const int64_t *first, const int *count, row_run **out)
+static int ancestor_runs(const plan_t *p, int h, int by_storage, const cholamd_filled *snap, const int64_t *first, const int *count, row_run **out)
 {
-  return ancestor_runs_of(p, h, 0, snap, first, count, out);
+  return ancestor_runs_of(p, h, 0, by_storage, snap, first, count, out);
 }
 
 int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int level, int rank, int world, chol_level_work *w)
@@ -445,7 +478,7 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
       const int64_t dinv = p->dinv_off[s] + (int64_t)(c0 / CHOL_NB) * CHOL_NB * CHOL_NB;
       const int64_t colbase = (int64_t)c0 * ld;                              /* column c0 of the panel */
       const int below = n - c0 - nb;                                         /* pivot rows under the diagonal block */
-      row_run *runs; const int nr = ancestor_runs(p, h, snap, first, count, &runs);
+      row_run *runs; const int nr = ancestor_runs(p, h, opts->merge_targets, snap, first, count, &runs);
       const int mine = !dist || dist_owner(p, s, st, world) == rank;
       if (dist) { /* the column block travels from its owner to every rank once it is factored and solved */
         if (w->n_bcast == B->cap_b) { B->cap_b = B->cap_b ? 2 * B->cap_b : 16; w->bcast = realloc(w->bcast, B->cap_b * sizeof(chol_bcast)); }
@@ -581,9 +614,9 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
             int crow = fa->lo_x - Bc->lo_x, ccol = fb_->lo_x - Bc->lo_y;
             u->key = ((int64_t)bc << 40) | ((int64_t)crow << 20) | (int64_t)ccol;
             u->seq = seq++;
-            u->c_off = Bc->off + crow + (int64_t)ccol * Bc->ld; u->ldc = Bc->ld;
-            u->a_off = Ba->off + (fa->lo_x - Ba->lo_x); u->lda = Ba->ld;
-            u->b_off = Bb->off + (fb_->lo_x - Bb->lo_x); u->ldb = Bb->ld;
+            u->c_off = chol_block_row(Bc, crow) + (int64_t)ccol * Bc->ld; u->ldc = Bc->ld;
+            u->a_off = chol_block_row(Ba, fa->lo_x - Ba->lo_x); u->lda = Ba->ld;
+            u->b_off = chol_block_row(Bb, fb_->lo_x - Bb->lo_x); u->ldb = Bb->ld;
             u->m = fa->hi_x - fa->lo_x + 1; u->n = fb_->hi_x - fb_->lo_x + 1; u->k = n;
             u->syrk = (gp == par && fb_->cluster == fa->cluster);
             u->bc = bc; u->crow = crow; u->ccol = ccol; u->src_sep = s;
@@ -596,18 +629,55 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
   {
     const int k0 = w->n_task, km0 = w->n_task_mt;
     if (tuples_are_small(opts, tu, ntu)) emit_cell_tasks(B, p, tu, ntu);
-    else
-    for (int i = 0; i < ntu;) {
-      int e = i + 1;
-      while (e < ntu && tu[e].key == tu[i].key) e++;
-      const int sb = w->n_src;
-      for (int q = i; q < e; q++) {
-        chol_upd_src sd = { tu[q].a_off, tu[q].b_off, tu[q].lda, tu[q].ldb, tu[q].k, 0, 0, 0 };
-        push_src(B, sd);
+    else {
+      /* One target per cluster-tile pair of the reference would leave the 64x64 macro tiles a quarter full where the cluster tiles are
+       * 32 rows (the generated problems: 54 % of the macro-tile work of 60^3 was 32 x 32 targets).  Targets of one block that are
+       * neighbours IN STORAGE -- in the target and, with the same shift, in every source (row compaction makes the kept tiles of a
+       * block consecutive) -- and receive the same sources in the same order are merged, along the columns first, then along the rows:
+       * every element keeps its sources and their order (bit-identical sums), the tiles fill up.  SYRK targets stay alone. */
+      int ng = 0;
+      tgt_group *G = malloc((size_t)(ntu > 0 ? ntu : 1) * sizeof(tgt_group));
+      for (int i = 0; i < ntu;) {
+        int e = i + 1;
+        while (e < ntu && tu[e].key == tu[i].key) e++;
+        tgt_group g = { i, e, tu[i].bc, tu[i].crow, tu[i].ccol, tu[i].m, tu[i].n, tu[i].syrk, tu[i].c_off, tu[i].ldc, 0 };
+        G[ng++] = g;
+        i = e;
       }
-      if (dist) { B->tgt_sep = p->blk[tu[i].bc].c; B->tgt_col0 = tu[i].ccol; }
-      push_tasks(B, tu[i].c_off, tu[i].ldc, tu[i].m, tu[i].n, tu[i].syrk, sb, w->n_src);
-      i = e;
+      if (opts->merge_targets) {
+        /* columns: the groups are sorted by (block, first row, first column) */
+        for (int a = 0; a < ng;) {
+          int b = a + 1;
+          while (b < ng && !G[a].syrk && !G[b].syrk && G[b].bc == G[a].bc && G[b].crow == G[a].crow && G[b].m == G[a].m && G[b].ccol == G[a].ccol + G[a].n &&
+                 same_sources(tu, &G[a], &G[b], 0, G[a].n)) { G[a].n += G[b].n; G[b].dead = 1; b++; }
+          a = b;
+        }
+        int nl = 0;
+        for (int a = 0; a < ng; a++) if (!G[a].dead) G[nl++] = G[a];
+        ng = nl;
+        /* rows: by (block, first column, columns, first row) */
+        qsort(G, ng, sizeof(tgt_group), cmp_group_rows);
+        for (int a = 0; a < ng;) {
+          int b = a + 1;
+          while (b < ng && !G[a].syrk && !G[b].syrk && G[b].bc == G[a].bc && G[b].ccol == G[a].ccol && G[b].n == G[a].n && G[b].c_off == G[a].c_off + G[a].m &&
+                 same_sources(tu, &G[a], &G[b], G[a].m, 0)) { G[a].m += G[b].m; G[b].dead = 1; b++; }
+          a = b;
+        }
+        nl = 0;
+        for (int a = 0; a < ng; a++) if (!G[a].dead) G[nl++] = G[a];
+        ng = nl;
+        qsort(G, ng, sizeof(tgt_group), cmp_group_first);
+      }
+      for (int a = 0; a < ng; a++) {
+        const int sb = w->n_src;
+        for (int q = G[a].i; q < G[a].e; q++) {
+          chol_upd_src sd = { tu[q].a_off, tu[q].b_off, tu[q].lda, tu[q].ldb, tu[q].k, 0, 0, 0 };
+          push_src(B, sd);
+        }
+        if (dist) { B->tgt_sep = p->blk[G[a].bc].c; B->tgt_col0 = G[a].ccol; }
+        push_tasks(B, G[a].c_off, G[a].ldc, G[a].m, G[a].n, G[a].syrk, sb, w->n_src);
+      }
+      free(G);
     }
     flush_targets(B);
     if (dist) push_phase(B, 2, k0, w->n_task - k0); else
@@ -732,7 +802,7 @@ static int push_block_rows(builder *B, const plan_t *p, int anc, int s, int lo, 
       if (run_hi == a0) { run_hi = a1; continue; }
     }
     if (run_lo >= 0) {
-      push_trsm_run(B, diag, dinv, Bk->off + run_lo + colbase, nb, ld, run_hi - run_lo, flag);
+      push_trsm_run(B, diag, dinv, chol_block_row(Bk, run_lo) + colbase, nb, ld, run_hi - run_lo, flag);
     }
     run_lo = a0; run_hi = a1;
   }
@@ -1175,10 +1245,10 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
                 const int sb_ = w->n_src;
                 for (int c = 0; c * EARLY_CHUNK < ntl_; c++) {
                   const int col0 = c * EARLY_CHUNK * CHOL_NB, kc = nb - col0 < EARLY_CHUNK * CHOL_NB ? nb - col0 : EARLY_CHUNK * CHOL_NB;
-                  chol_upd_src sa = { Bk->off + run_lo + colbase + (int64_t)col0 * ld, x_piv + (int64_t)col0 * ld, ld, ld, kc, 0, opts->staged ? 2 * c + 2 : 0, 0 };
+                  chol_upd_src sa = { chol_block_row(Bk, run_lo) + colbase + (int64_t)col0 * ld, x_piv + (int64_t)col0 * ld, ld, ld, kc, 0, opts->staged ? 2 * c + 2 : 0, 0 };
                   push_src(B, sa);
                 }
-                push_tasks(B, Bk->off + run_lo + (int64_t)(c0 + nb) * ld, ld, run_hi - run_lo, fast_cols, 0, sb_, w->n_src);
+                push_tasks(B, chol_block_row(Bk, run_lo) + (int64_t)(c0 + nb) * ld, ld, run_hi - run_lo, fast_cols, 0, sb_, w->n_src);
               }
               run_lo = a0; run_hi = a1;
             }
@@ -1231,9 +1301,9 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
                 if (run_hi == a0) { run_hi = a1; continue; }
               }
               if (run_lo >= 0 && below > fast_cols) { /* the columns beyond the fast part */
-                chol_upd_src sa = { Bk->off + run_lo + colbase, x_piv + fast_cols, ld, ld, nb, 0, 0, 0 };
+                chol_upd_src sa = { chol_block_row(Bk, run_lo) + colbase, x_piv + fast_cols, ld, ld, nb, 0, 0, 0 };
                 const int si = push_src(B, sa);
-                push_tasks(B, Bk->off + run_lo + (int64_t)(c0 + nb + fast_cols) * ld, ld, run_hi - run_lo, below - fast_cols, 0, si, si + 1);
+                push_tasks(B, chol_block_row(Bk, run_lo) + (int64_t)(c0 + nb + fast_cols) * ld, ld, run_hi - run_lo, below - fast_cols, 0, si, si + 1);
               }
               run_lo = a0; run_hi = a1;
             }
@@ -1255,9 +1325,9 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
                 if (run_hi == a0) { run_hi = a1; continue; }
               }
               if (run_lo >= 0) {
-                chol_upd_src sa = { Bk->off + run_lo + colbase, x_piv, ld, ld, nb, 0, 0, 0 };
+                chol_upd_src sa = { chol_block_row(Bk, run_lo) + colbase, x_piv, ld, ld, nb, 0, 0, 0 };
                 const int si = push_src(B, sa);
-                push_tasks(B, Bk->off + run_lo + (int64_t)(c0 + nb) * ld, ld, run_hi - run_lo, below, 0, si, si + 1);
+                push_tasks(B, chol_block_row(Bk, run_lo) + (int64_t)(c0 + nb) * ld, ld, run_hi - run_lo, below, 0, si, si + 1);
               }
               run_lo = a0; run_hi = a1;
             }
@@ -1337,9 +1407,9 @@ int chol_build_program(const plan_t *p, const chol_sched_opts *opts, chol_level_
                 const int crow = fa->lo_x - Bc->lo_x, ccol = fb_->lo_x - Bc->lo_y;
                 u->key = ((int64_t)bc << 40) | ((int64_t)crow << 20) | (int64_t)ccol;
                 u->seq = seq++;
-                u->c_off = Bc->off + crow + (int64_t)ccol * Bc->ld; u->ldc = Bc->ld;
-                u->a_off = Ba->off + (fa->lo_x - Ba->lo_x); u->lda = Ba->ld;
-                u->b_off = Bb->off + (fb_->lo_x - Bb->lo_x); u->ldb = Bb->ld;
+                u->c_off = chol_block_row(Bc, crow) + (int64_t)ccol * Bc->ld; u->ldc = Bc->ld;
+                u->a_off = chol_block_row(Ba, fa->lo_x - Ba->lo_x); u->lda = Ba->ld;
+                u->b_off = chol_block_row(Bb, fb_->lo_x - Bb->lo_x); u->ldb = Bb->ld;
                 u->m = fa->hi_x - fa->lo_x + 1; u->n = fb_->hi_x - fb_->lo_x + 1; u->k = n;
                 u->syrk = (gp == par && fb_->cluster == fa->cluster);
                 u->bc = bc; u->crow = crow; u->ccol = ccol; u->src_sep = s;
@@ -1695,13 +1765,36 @@ void chol_level_work_free(chol_level_work *w)
 /*   forward  (bottom-up): TRSV per separator, then target-centric GEMV into every ancestor   */
 /*   backward (top-down) : per separator gather from all ancestors (GEMV Trans), then TRSV^T  */
 /* ---------------------------------------------------------------------------------------- */
+/* the stored row runs of a block: maximal runs of consecutive kept 16-row tiles (one run = the whole block without compaction).
+ * Calls f(ctx, first row, rows, arena offset of the first row) per run; rows in [lo, hi) only */
+typedef struct { int row0, m; int64_t off; } blk_run;
+static int block_runs(const chol_block *B, int lo, int hi, blk_run **out)
+{
+  int cap = 8, n = 0;
+  blk_run *r = malloc(cap * sizeof(blk_run));
+  if (hi > B->rows) hi = B->rows;
+  if (!B->tmap) {
+    if (lo < hi) { r[0].row0 = lo; r[0].m = hi - lo; r[0].off = B->off + lo; n = 1; }
+  } else
+    for (int t = lo / CHOL_NB; t * CHOL_NB < hi; t++) {
+      if (B->tmap[t] < 0) continue;
+      const int a = t * CHOL_NB > lo ? t * CHOL_NB : lo, b = (t + 1) * CHOL_NB < hi ? (t + 1) * CHOL_NB : hi;
+      if (n > 0 && r[n - 1].row0 + r[n - 1].m == a) { r[n - 1].m += b - a; continue; }
+      if (n == cap) { cap *= 2; r = realloc(r, cap * sizeof(blk_run)); }
+      r[n].row0 = a; r[n].m = b - a; r[n].off = chol_block_row(B, a); n++;
+    }
+  *out = r;
+  return n;
+}
+
 int chol_build_solve_level(const plan_t *p, int level, chol_solve_level *w)
 {
   memset(w, 0, sizeof *w);
   const int h0 = 1 << level, h1 = (1 << (level + 1)) - 1, cnt = h1 - h0 + 1;
+  int capb = cnt * (level > 0 ? level : 1);
   w->trsv = malloc(cnt * sizeof(chol_trsv_desc));
   w->bw_start = malloc((cnt + 1) * sizeof(int));
-  w->bw = malloc((size_t)(cnt * (level > 0 ? level : 1)) * sizeof(chol_gemv_desc));
+  w->bw = malloc((size_t)capb * sizeof(chol_gemv_desc));
   for (int h = h0; h <= h1; h++) {
     int s = p->tree[h];
     chol_trsv_desc t = { p->panel_off[s], p->sep_size[s], p->panel_ld[s], p->sep_off[s], s, p->dinv_off[s] };
@@ -1712,12 +1805,18 @@ int chol_build_solve_level(const plan_t *p, int level, chol_solve_level *w)
       int par = p->tree[hp];
       const chol_block *B = &p->blk[BIDX(p, par, s)];
       if (B->rows == 0 || B->cols == 0) continue;
-      chol_gemv_desc g = { B->off, B->rows, B->cols, B->ld, p->sep_off[par], p->sep_off[s] };
-      w->bw[w->n_bw++] = g;
+      blk_run *rr; const int nr = block_runs(B, 0, B->rows, &rr); /* one descriptor per stored row run */
+      for (int q = 0; q < nr; q++) {
+        if (w->n_bw == capb) { capb *= 2; w->bw = realloc(w->bw, (size_t)capb * sizeof(chol_gemv_desc)); }
+        chol_gemv_desc g = { rr[q].off, rr[q].m, B->cols, B->ld, p->sep_off[par] + rr[q].row0, p->sep_off[s] };
+        w->bw[w->n_bw++] = g;
+      }
+      free(rr);
     }
   }
   w->bw_start[w->n_trsv] = w->n_bw;
-  /* forward: for every ancestor separator `par` (levels above), chunks of 256 rows */
+  /* forward: for every ancestor separator `par` (levels above), chunks of 256 rows; a source = the stored rows of a block inside the
+   * chunk (y_off = first row of the run, relative to the target separator) */
   int cap = 16, capg = 16;
   w->fw = malloc(cap * sizeof(chol_gemv_desc));
   w->grp_start = malloc((capg + 1) * sizeof(int));
@@ -1735,9 +1834,13 @@ int chol_build_solve_level(const plan_t *p, int level, chol_solve_level *w)
           int s = p->tree[h];
           const chol_block *B = &p->blk[BIDX(p, par, s)];
           if (B->rows == 0 || B->cols == 0) continue;
-          if (w->n_fw == cap) { cap *= 2; w->fw = realloc(w->fw, cap * sizeof(chol_gemv_desc)); }
-          chol_gemv_desc g = { B->off, B->rows, B->cols, B->ld, p->sep_off[s], p->sep_off[par] };
-          w->fw[w->n_fw++] = g;
+          blk_run *rr; const int nr = block_runs(B, row0, row0 + 256, &rr);
+          for (int q = 0; q < nr; q++) {
+            if (w->n_fw == cap) { cap *= 2; w->fw = realloc(w->fw, cap * sizeof(chol_gemv_desc)); }
+            chol_gemv_desc g = { rr[q].off, rr[q].m, B->cols, B->ld, p->sep_off[s], rr[q].row0 };
+            w->fw[w->n_fw++] = g;
+          }
+          free(rr);
         }
       }
     }
@@ -1773,6 +1876,42 @@ int cholamd_plan_fill_host_part(const cholamd_plan *p, double *arena, int rank, 
   memset(arena, 0, (size_t)p->arena * sizeof(double));
   for (int64_t e = 0; e < p->nnz_a; e++)
     if (rank == 0 || p->a_dst[e] < tail) arena[p->a_dst[e]] = p->a_val[e];
+  return 0;
+}
+
+/* how full the 64x64 macro-tile tasks of one level are: out = { tasks, tasks with 64 x 64 valid elements, sum over tasks of valid elements x K,
+ * sum over tasks of 4096 x K } (K = total depth of the task's sources): out[2] / out[3] is the share of the kernel's MFMA work that lands on
+ * valid elements */
+int cholamd_plan_level_mt_hist(const cholamd_plan *p, int level, int64_t out[16])
+{ /* K-weighted count of the macro-tile tasks by (ceil(mv / 16) - 1, ceil(nv / 16) - 1) */
+  chol_level_work w;
+  int rc = chol_build_level_work(p, NULL, level, 0, 1, &w);
+  if (rc) return rc;
+  for (int i = 0; i < 16; i++) out[i] = 0;
+  for (int i = 0; i < w.n_task_mt; i++) {
+    const chol_upd_task *t = &w.task_mt[i];
+    int64_t K = 0;
+    for (int q = t->src_begin; q < t->src_end; q++) K += w.src[q].k;
+    out[((t->mv + 15) / 16 - 1) * 4 + (t->nv + 15) / 16 - 1] += K;
+  }
+  chol_level_work_free(&w);
+  return 0;
+}
+int cholamd_plan_level_mt_fill(const cholamd_plan *p, int level, int64_t out[4])
+{
+  chol_level_work w;
+  int rc = chol_build_level_work(p, NULL, level, 0, 1, &w);
+  if (rc) return rc;
+  out[0] = w.n_task_mt; out[1] = out[2] = out[3] = 0;
+  for (int i = 0; i < w.n_task_mt; i++) {
+    const chol_upd_task *t = &w.task_mt[i];
+    int64_t K = 0;
+    for (int q = t->src_begin; q < t->src_end; q++) K += w.src[q].k;
+    const int64_t valid = t->lower ? (int64_t)t->mv * (t->mv + 1) / 2 : (int64_t)t->mv * t->nv;
+    out[1] += t->mv == 64 && t->nv == 64;
+    out[2] += valid * K; out[3] += (t->lower ? 64 * 65 / 2 : 4096) * K;
+  }
+  chol_level_work_free(&w);
   return 0;
 }
 

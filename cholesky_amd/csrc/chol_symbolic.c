@@ -139,6 +139,51 @@ static int cmp_dv(const void *x, const void *y)
 }
 
 /* ---------------------------------------------------------------------------------------- */
+/* Arena layout: one column-major panel per separator, by ascending label: the separator's own rows, then bottom-up the rows of every
+ * ancestor block -- all of them for the parent (a follower reads its children's strips of its whole diagonal-block height), the
+ * kept 16-row tiles for the ancestors above it (keep[b], from the fill analysis; NULL entries / CHOLAMD_COMPACT=0: all rows). */
+static void layout_panels(plan_t *p, unsigned char **keep)
+{
+  const int ns = p->nsep;
+  const char *e = getenv("CHOLAMD_COMPACT");
+  p->compact = !(e && e[0] == '0');
+  int64_t off = 0, ws = 0, dense = 0;
+  for (int c = 1; c <= ns; c++) {
+    int rows = 0, rows_dense = 0;
+    for (int h = p->heap_of[c]; h >= 1; h /= 2) {
+      chol_block *b = &p->blk[BIDX(p, p->tree[h], c)];
+      const int T = (b->rows + CHOL_NB - 1) / CHOL_NB;
+      rows_dense += b->rows;
+      if (p->compact && keep[BIDX(p, p->tree[h], c)]) {
+        const unsigned char *k = keep[BIDX(p, p->tree[h], c)];
+        b->tmap = malloc((size_t)(T > 0 ? T : 1) * sizeof(int));
+        b->crows = 0;
+        int nk = 0;
+        for (int t = 0; t < T; t++) {
+          b->tmap[t] = k[t] ? nk++ : -1;
+          if (k[t]) b->crows += b->rows - t * CHOL_NB < CHOL_NB ? b->rows - t * CHOL_NB : CHOL_NB;
+        }
+      }
+      b->off = rows; /* relative to the panel for now */
+      rows += b->crows;
+    }
+    p->panel_rows[c] = rows;
+    p->panel_ld[c] = (rows + 3) & ~3; /* 32-byte aligned columns */
+    p->panel_off[c] = off;
+    for (int h = p->heap_of[c]; h >= 1; h /= 2) {
+      chol_block *b = &p->blk[BIDX(p, p->tree[h], c)];
+      b->off += off; b->ld = p->panel_ld[c];
+    }
+    off += (int64_t)p->panel_ld[c] * p->sep_size[c];
+    off = (off + 15) & ~(int64_t)15; /* 128-byte aligned panels */
+    dense += (int64_t)((rows_dense + 3) & ~3) * p->sep_size[c];
+    dense = (dense + 15) & ~(int64_t)15;
+    p->dinv_off[c] = ws;
+    ws += (int64_t)((p->sep_size[c] + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB;
+  }
+  p->arena = off; p->ws_doubles = ws; p->arena_dense = dense;
+}
+
 int chol_plan_finish(plan_t *p, int nz, const int *a_row, const int *a_col, const double *a_val)
 {
   const int ns = p->nsep, L = p->levels, n = p->n;
@@ -184,21 +229,7 @@ int chol_plan_finish(plan_t *p, int nz, const int *a_row, const int *a_col, cons
   p->nblk = 0;
   for (int c = 1; c <= ns; c++) p->nblk += p->level_of[c] + 1;
   p->blk = calloc(p->nblk, sizeof(chol_block));
-  {
-    /* blocks are stored sorted by (r, c); first count per row label, then place */
-    int64_t off = 0, ws = 0;
-    for (int c = 1; c <= ns; c++) {
-      int rows = 0;
-      for (int h = p->heap_of[c]; h >= 1; h /= 2) rows += p->sep_size[p->tree[h]];
-      p->panel_rows[c] = rows;
-      p->panel_ld[c] = (rows + 3) & ~3; /* 32-byte aligned columns */
-      p->panel_off[c] = off;
-      off += (int64_t)p->panel_ld[c] * p->sep_size[c];
-      off = (off + 15) & ~(int64_t)15; /* 128-byte aligned panels */
-      p->dinv_off[c] = ws;
-      ws += (int64_t)((p->sep_size[c] + CHOL_NB - 1) / CHOL_NB) * CHOL_NB * CHOL_NB;
-    }
-    p->arena = off; p->ws_doubles = ws;
+  { /* block geometry; the arena layout follows the fill analysis (layout_panels) */
     int k = 0;
     for (int r = 1; r <= ns; r++)
       for (int c = 1; c <= r; c++) {
@@ -209,10 +240,8 @@ int chol_plan_finish(plan_t *p, int nz, const int *a_row, const int *a_col, cons
         b->r = r; b->c = c;
         b->lo_x = p->sep_off[r]; b->hi_x = p->sep_off[r] + p->sep_size[r] - 1;
         b->lo_y = p->sep_off[c]; b->hi_y = p->sep_off[c] + p->sep_size[c] - 1;
-        b->rows = p->sep_size[r]; b->cols = p->sep_size[c]; b->ld = p->panel_ld[c];
-        int row_off = 0; /* rows of c, then its ancestors bottom-up, precede r inside panel(c) */
-        for (int h = hc; h > hr; h /= 2) row_off += p->sep_size[p->tree[h]];
-        b->off = p->panel_off[c] + row_off;
+        b->rows = p->sep_size[r]; b->cols = p->sep_size[c];
+        b->tmap = NULL; b->crows = b->rows;
         BIDX(p, r, c) = k++;
       }
     if (k != p->nblk) { chol_set_error("internal: block count mismatch"); return CHOLAMD_ERR_INVARIANT; }
@@ -224,12 +253,13 @@ int chol_plan_finish(plan_t *p, int nz, const int *a_row, const int *a_col, cons
   p->a_val = malloc((size_t)(nz > 0 ? nz : 1) * sizeof(double));
   p->nnz_a = 0; p->dropped = 0;
   int *px = malloc((size_t)(nz > 0 ? nz : 1) * sizeof(int)), *py = malloc((size_t)(nz > 0 ? nz : 1) * sizeof(int));
+  unsigned char **keep = calloc(p->nblk, sizeof(unsigned char *)); /* per block: the 16-row tiles the panel must store */
   for (int e = 0; e < nz; e++) {
     int i = a_row[e], j = a_col[e];
     if (i < 0 || j < 0 || i >= n || j >= n) {
       chol_set_error("matrix entry %d out of range", e);
       for (int b = 0; b < p->nblk; b++) free(F[b].f);
-      free(F); free(px); free(py); /* a_dst / a_val belong to the plan: cholamd_plan_destroy frees them */
+      free(F); free(px); free(py); free(keep); /* a_dst / a_val belong to the plan: cholamd_plan_destroy frees them */
       return CHOLAMD_ERR_FORMAT;
     }
     if (a_val[e] == 0.0) continue; /* explicit zeros are invisible to the reference (mnd.c:168-195) */
@@ -238,7 +268,7 @@ int chol_plan_finish(plan_t *p, int nz, const int *a_row, const int *a_col, cons
     int bi = BIDX(p, p->sep_of_pos[x], p->sep_of_pos[y]);
     if (bi < 0) { p->dropped++; continue; } /* not in an ancestor/descendant block: the ordering is not a valid ND */
     const chol_block *b = &p->blk[bi];
-    p->a_dst[p->nnz_a] = b->off + (x - b->lo_x) + (int64_t)(y - b->lo_y) * b->ld;
+    p->a_dst[p->nnz_a] = bi; /* the block for now: the arena offset once the panels are laid out */
     p->a_val[p->nnz_a] = a_val[e];
     px[p->nnz_a] = x; py[p->nnz_a] = y;
     p->nnz_a++;
@@ -246,7 +276,6 @@ int chol_plan_finish(plan_t *p, int nz, const int *a_row, const int *a_col, cons
     F[bi].f[(size_t)tr * F[bi].nc + tc] = 1;
   }
   scalar_symbolic(p, px, py);
-  free(px); free(py);
   { /* A as a full symmetric CSR in ORIGINAL dof order (both triangles, explicit zeros skipped, entries the schedule
      * dropped included): the operator of the fp64 residual r = b - A x of the iterative refinement */
     int64_t *ptr = calloc((size_t)n + 1, sizeof(int64_t));
@@ -269,15 +298,6 @@ int chol_plan_finish(plan_t *p, int nz, const int *a_row, const int *a_col, cons
     free(fillp);
     p->csr_ptr = ptr;
   }
-  { /* ascending arena offsets: coalesced device scatter, and the entries of the shared top of the
-     * tree (the tail of the arena) form a suffix that non-root ranks skip (multi-GPU fill) */
-    typedef struct { int64_t d; double v; } dv_t;
-    dv_t *t = malloc((size_t)(p->nnz_a > 0 ? p->nnz_a : 1) * sizeof(dv_t));
-    for (int64_t e = 0; e < p->nnz_a; e++) { t[e].d = p->a_dst[e]; t[e].v = p->a_val[e]; }
-    qsort(t, (size_t)p->nnz_a, sizeof(dv_t), cmp_dv);
-    for (int64_t e = 0; e < p->nnz_a; e++) { p->a_dst[e] = t[e].d; p->a_val[e] = t[e].v; }
-    free(t);
-  }
   /* per-level fill prediction, snapshots and the reference-order call list
    * (compute_filled_clusters mmat.rg:896-1028 interleaved with the schedule mmat.rg:1227-1355) */
   p->snap_n = calloc(L, sizeof(int64_t));
@@ -286,6 +306,22 @@ int chol_plan_finish(plan_t *p, int nz, const int *a_row, const int *a_col, cons
   int t = 0, lbl = 0;
   for (int lvl = L - 1; lvl >= 0; lvl--, lbl++) {
     const int h0 = 1 << lvl, h1 = (1 << (lvl + 1)) - 1;
+    /* the panels of this level are final in structure now: the rows a panel stores for an ancestor above its parent are the 16-row
+     * tiles its filled tiles touch (every later access -- strips, update sources, solves -- stays inside them) */
+    for (int h = h0; h <= h1; h++)
+      for (int hp = h / 4; hp >= 1; hp /= 2) {
+        const int b = BIDX(p, p->tree[hp], p->tree[h]);
+        const fillmat *Fb = &F[b];
+        const chol_clusters *cr = &p->cl[p->tree[hp]];
+        keep[b] = calloc((size_t)(p->blk[b].rows + CHOL_NB - 1) / CHOL_NB + 1, 1);
+        if (Fb->t != t) continue;
+        for (int i = 0; i < Fb->nr; i++) {
+          int any = 0;
+          for (int j = 0; j < Fb->nc; j++) any |= Fb->f[(size_t)i * Fb->nc + j];
+          if (!any || cr->start[t][i + 1] <= cr->start[t][i]) continue;
+          for (int q = cr->start[t][i] / CHOL_NB; q <= (cr->start[t][i + 1] - 1) / CHOL_NB; q++) keep[b][q] = 1;
+        }
+      }
     /* symbolic update of the ancestors' blocks */
     for (int h = h0; h <= h1; h++) {
       int s = p->tree[h];
@@ -405,6 +441,26 @@ int chol_plan_finish(plan_t *p, int nz, const int *a_row, const int *a_col, cons
   }
   for (int b = 0; b < p->nblk; b++) free(F[b].f);
   free(F);
+  layout_panels(p, keep);
+  for (int b = 0; b < p->nblk; b++) free(keep[b]);
+  free(keep);
+  /* scatter map of tril(A) */
+  for (int64_t e = 0; e < p->nnz_a; e++) {
+    const chol_block *b = &p->blk[p->a_dst[e]];
+    const int64_t row = chol_block_row(b, px[e] - b->lo_x);
+    if (row < 0) { chol_set_error("internal: matrix entry (%d, %d) outside the stored rows of block (%d, %d)", px[e], py[e], b->r, b->c); free(px); free(py); return CHOLAMD_ERR_INVARIANT; }
+    p->a_dst[e] = row + (int64_t)(py[e] - b->lo_y) * b->ld;
+  }
+  free(px); free(py);
+  { /* ascending arena offsets: coalesced device scatter, and the entries of the shared top of the
+     * tree (the tail of the arena) form a suffix that non-root ranks skip (multi-GPU fill) */
+    typedef struct { int64_t d; double v; } dv_t;
+    dv_t *t = malloc((size_t)(p->nnz_a > 0 ? p->nnz_a : 1) * sizeof(dv_t));
+    for (int64_t e = 0; e < p->nnz_a; e++) { t[e].d = p->a_dst[e]; t[e].v = p->a_val[e]; }
+    qsort(t, (size_t)p->nnz_a, sizeof(dv_t), cmp_dv);
+    for (int64_t e = 0; e < p->nnz_a; e++) { p->a_dst[e] = t[e].d; p->a_val[e] = t[e].v; }
+    free(t);
+  }
   return 0;
 }
 
@@ -550,6 +606,7 @@ void cholamd_plan_destroy(cholamd_plan *p)
     }
   if (p->snap) for (int l = 0; l < p->levels; l++) free(p->snap[l]);
   free(p->cl); free(p->snap); free(p->snap_n); free(p->perm); free(p->iperm); free(p->sep_of_pos); free(p->sep_size);
+  if (p->blk) for (int b = 0; b < p->nblk; b++) free(p->blk[b].tmap);
   free(p->sep_off); free(p->tree); free(p->heap_of); free(p->level_of); free(p->blk); free(p->blk_index);
   free(p->panel_off); free(p->panel_ld); free(p->panel_rows); free(p->dinv_off); free(p->a_dst); free(p->a_val); free(p->ops);
   free(p->csr_ptr); free(p->csr_col); free(p->csr_val);
@@ -566,6 +623,15 @@ int cholamd_plan_num_separators(const cholamd_plan *p) { return p->nsep; }
 int cholamd_plan_max_int_size(const cholamd_plan *p) { return p->max_int_size; }
 int cholamd_plan_num_blocks(const cholamd_plan *p) { return p->nblk; }
 int64_t cholamd_plan_arena_doubles(const cholamd_plan *p) { return p->arena; }
+int64_t cholamd_plan_arena_dense_doubles(const cholamd_plan *p) { return p->arena_dense; }
+int cholamd_plan_block_tile_map(const cholamd_plan *p, int r, int c, int *out)
+{
+  const chol_block *B = chol_plan_block(p, r, c);
+  if (!B) return CHOLAMD_ERR_ARG;
+  const int T = (B->rows + CHOL_NB - 1) / CHOL_NB;
+  for (int t = 0; t < T; t++) out[t] = B->tmap ? B->tmap[t] : t;
+  return T;
+}
 int64_t cholamd_plan_dropped_entries(const cholamd_plan *p) { return p->dropped; }
 const char *cholamd_plan_banner(const cholamd_plan *p) { return p->banner; }
 void cholamd_plan_perm(const cholamd_plan *p, int *out) { memcpy(out, p->perm, p->n * sizeof(int)); }
@@ -614,14 +680,26 @@ int cholamd_plan_fill_host(const cholamd_plan *p, double *arena)
   return 0;
 }
 
+/* element (i, j) of a block; rows without storage are the zeros of the reference's dense block */
+static double block_value(const chol_block *B, const double *arena, int i, int j)
+{
+  const int64_t row = chol_block_row(B, i);
+  return row < 0 ? 0.0 : arena[row + (int64_t)j * B->ld];
+}
+
 int cholamd_plan_arena_to_dense(const cholamd_plan *p, const double *arena, double *dense)
 {
   const size_t n = p->n;
   memset(dense, 0, n * n * sizeof(double));
   for (int b = 0; b < p->nblk; b++) {
     const chol_block *B = &p->blk[b];
-    for (int j = 0; j < B->cols; j++)
-      memcpy(dense + (size_t)B->lo_x + (size_t)(B->lo_y + j) * n, arena + B->off + (int64_t)j * B->ld, (size_t)B->rows * sizeof(double));
+    for (int i0 = 0; i0 < B->rows; i0 += CHOL_NB) { /* tile by tile: a tile without storage is zero */
+      const int64_t row = chol_block_row(B, i0);
+      const int m = B->rows - i0 < CHOL_NB ? B->rows - i0 : CHOL_NB;
+      if (row < 0) continue;
+      for (int j = 0; j < B->cols; j++)
+        memcpy(dense + (size_t)B->lo_x + i0 + (size_t)(B->lo_y + j) * n, arena + row + (int64_t)j * B->ld, (size_t)m * sizeof(double));
+    }
   }
   return 0;
 }
@@ -635,7 +713,7 @@ int cholamd_plan_write_matrix(const cholamd_plan *p, const double *arena, const 
   for (int b = 0; b < p->nblk; b++) {
     const chol_block *B = &p->blk[b];
     for (int j = 0; j < B->cols; j++)
-      for (int i = 0; i < B->rows; i++) nnz += arena[B->off + i + (int64_t)j * B->ld] != 0.0;
+      for (int i = 0; i < B->rows; i++) nnz += block_value(B, arena, i, j) != 0.0;
   }
   MM_typecode tc; memcpy(tc, p->typecode, 4);
   mm_write_banner(fp, tc);
@@ -644,7 +722,7 @@ int cholamd_plan_write_matrix(const cholamd_plan *p, const double *arena, const 
     const chol_block *B = &p->blk[b];
     for (int i = 0; i < B->rows; i++)
       for (int j = 0; j < B->cols; j++) {
-        double v = arena[B->off + i + (int64_t)j * B->ld];
+        double v = block_value(B, arena, i, j);
         if (v != 0.0) fprintf(fp, full_precision ? "%d %d %.17g\n" : "%d %d %0.8g\n", B->lo_x + i + 1, B->lo_y + j + 1, v);
       }
   }
@@ -714,7 +792,7 @@ int cholamd_plan_write_blocks_txt(const cholamd_plan *p, const double *arena, co
     fprintf(fp, "Color: %d %d size: %dx%d bounds.lo: %d %d bounds.hi: %d %d vol: %d\n", B->r, B->c, B->rows, B->cols, B->lo_x, B->lo_y, B->hi_x, B->hi_y, B->rows * B->cols);
     for (int i = 0; i < B->rows; i++) {
       for (int j = 0; j < B->cols; j++) {
-        const double v = arena[B->off + i + (int64_t)j * B->ld];
+        const double v = block_value(B, arena, i, j);
         fprintf(fp, v < 0 ? "%0.2f, " : " %0.2f, ", v);
       }
       fprintf(fp, "\n");

@@ -90,6 +90,24 @@ class Plan:
         off = (raw[:, 7] & 0xFFFFFFFF) | (raw[:, 8] << 32)
         return np.concatenate([raw[:, :7], off[:, None]], axis=1)
 
+    def heap_of(self, label):
+        """Heap index (root = 1, children of h = 2 h, 2 h + 1) of a separator label."""
+        return int(np.nonzero(self.tree == label)[0][0]) + 1
+
+    @property
+    def arena_dense_doubles(self):
+        """What the arena would hold with every ancestor row stored (no row compaction)."""
+        return int(self.L.cholamd_plan_arena_dense_doubles(self.h))
+
+    def block_tile_map(self, r, c):
+        """Stored position of every 16-row tile of block (r, c) in its panel (-1: the tile has no storage)."""
+        rows = int(self.sep_sizes[r - 1])
+        out = np.zeros((rows + 15) // 16 + 1, dtype=np.int32)
+        n = self.L.cholamd_plan_block_tile_map(self.h, r, c, out.ctypes.data)
+        if n < 0:
+            raise ValueError(f"no block ({r}, {c})")
+        return out[:n]
+
     def snapshot(self, interval_lbl):
         n = self.L.cholamd_plan_snapshot_count(self.h, interval_lbl)
         buf = (Filled * max(n, 1))()

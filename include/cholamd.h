@@ -142,6 +142,13 @@ int cholamd_plan_num_separators(const cholamd_plan *p);
 int cholamd_plan_max_int_size(const cholamd_plan *p);
 int cholamd_plan_num_blocks(const cholamd_plan *p);
 int64_t cholamd_plan_arena_doubles(const cholamd_plan *p);   /* size of the panel arena */
+/* Row compaction.  panel(s) stores the rows of s and of its parent in full; of every higher ancestor only the 16-row tiles (rows 16 t ..
+ * 16 t + 15 of the ancestor) that a filled tile of block (ancestor, s) touches when s is eliminated -- the rest of the reference's dense
+ * block instance stays zero and is never touched (blas.rg:385-395).  CHOLAMD_COMPACT=0 in the environment at plan creation stores every
+ * row (the round-1/2 layout).  arena_dense_doubles: the size without compaction; block_tile_map: out[t] = stored position of tile t of
+ * block (r, c) in units of 16 rows from the block's first stored row, -1 = not stored; returns the number of tiles. */
+int64_t cholamd_plan_arena_dense_doubles(const cholamd_plan *p);
+int cholamd_plan_block_tile_map(const cholamd_plan *p, int r, int c, int *out);
 int64_t cholamd_plan_dropped_entries(const cholamd_plan *p); /* entries of A outside every allocated block */
 const char *cholamd_plan_banner(const cholamd_plan *p);
 void cholamd_plan_perm(const cholamd_plan *p, int *out);          /* n ints */
@@ -175,6 +182,9 @@ int cholamd_plan_fill_host_part(const cholamd_plan *p, double *arena, int rank, 
 /* sizes of the device work lists of one tree level for (rank, world): potrf descriptors, trsm
  * strips, update tasks, update sources */
 int cholamd_plan_level_work_counts(const cholamd_plan *p, int level, int rank, int world, int out[4]);
+/* how full the 64 x 64 macro-tile update tasks of a level are (single GPU): out = { tasks, tasks with all 64 x 64 elements valid,
+ * sum of valid elements x depth, sum of tile elements x depth } */
+int cholamd_plan_level_mt_fill(const cholamd_plan *p, int level, int64_t out[4]);
 /* volumes of the same lists with the top levels replicated (dist_top = 0) or distributed by column blocks (1; 2 = automatic):
  * POTRF columns, TRSM elements, update volume (target elements x source depth), broadcast entries, broadcast doubles, checksum
  * of the broadcast list (the same on every rank) */
@@ -410,7 +420,12 @@ typedef struct cholamd_region {
   double *ptr;
   int ld;
   int lo_x, lo_y, hi_x, hi_y;
+  const int *tile_row; /* NULL: every row lo_x..hi_x is stored, row x at ptr + (x - lo_x).  Else (row-compacted block instance of the arena):
+                        * 16-row tile t of the block (rows lo_x + 16 t ..) is stored at rows 16 * tile_row[t] .. from ptr, or not at all (-1: no
+                        * filled tile touches it -- the reference never reads or writes those rows, blas.rg:385-395) */
 } cholamd_region;
+/* the block instance (r, c) of an arena laid out by `plan` (tile_row points into the plan) */
+int cholamd_plan_region(const cholamd_plan *plan, double *d_arena, int r, int c, cholamd_region *out);
 
 /* fused_dpotrf, blas.rg:292-315.  Returns LAPACK info of the first failing tile (the reference discards it). */
 int cholamd_fused_dpotrf(const cholamd_region *rA, const cholamd_filled *filled_rA, int nA, int level, int interval, int debug, void *stream);

@@ -23,7 +23,7 @@ bench)  run bench 300 python bench.py --steps 200 --warmup 10 > $out/bench.json 
 stats)  (cd /tmp && run stats 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/stats.err); find $out/stats -name "*kernel_stats.csv" -exec head -8 {} \; ;;
 pmc)    for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
           n=$(echo $grp | cut -d' ' -f1)
-          (cd /tmp && run pmc_$n 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc_$n -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $out/pmc_$n.json 2> $out/pmc_$n.err) || tail -5 $out/pmc_$n.err
+          (cd /tmp && run pmc_$n 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc_$n -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 2 --no-cpu-baseline --sustained 0 > $out/pmc_$n.json 2> $out/pmc_$n.err) || tail -5 $out/pmc_$n.err
         done ;;
 gen)    for c in gen:40:6 gen:60:8; do n=$(echo $c | tr ':' '_')
           (cd /tmp && run stats_$n 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$n -o s -- python3 $GRAFT_REPO_ROOT/bench.py --case $c --steps 5 --warmup 1 > $out/bench_$n.json 2> $out/stats_$n.err); cat $out/bench_$n.json
@@ -43,10 +43,10 @@ profiles) # every rocprofv3 pass behind profiles/r2/summary.json: key | bench ar
           [ -z "$key" ] && continue
           [ -n "$PROFILE_KEYS" ] && ! echo " $PROFILE_KEYS " | grep -q " $key " && continue
           d=$out/$key; mkdir -p $d
-          (cd /tmp && run stats_$key 500 rocprofv3 --kernel-trace --stats --output-format csv -d $d/stats -o s -- python3 $GRAFT_REPO_ROOT/bench.py $bargs --steps $nsteps --warmup 2 --no-cpu-baseline > $d/bench_under_rocprof.json 2> $d/stats.err) || tail -3 $d/stats.err
-          (cd /tmp && run pmc_$key 500 rocprofv3 --kernel-trace --pmc $SQ $mops GRBM_GUI_ACTIVE --output-format csv -d $d/pmc_SQ -o p -- python3 $GRAFT_REPO_ROOT/bench.py $bargs --steps $nsteps --warmup 2 --no-cpu-baseline > $d/pmc_SQ.json 2> $d/pmc_SQ.err) || tail -3 $d/pmc_SQ.err
+          (cd /tmp && run stats_$key 500 rocprofv3 --kernel-trace --stats --output-format csv -d $d/stats -o s -- python3 $GRAFT_REPO_ROOT/bench.py $bargs --steps $nsteps --warmup 2 --no-cpu-baseline --sustained 0 > $d/bench_under_rocprof.json 2> $d/stats.err) || tail -3 $d/stats.err
+          (cd /tmp && run pmc_$key 500 rocprofv3 --kernel-trace --pmc $SQ $mops GRBM_GUI_ACTIVE --output-format csv -d $d/pmc_SQ -o p -- python3 $GRAFT_REPO_ROOT/bench.py $bargs --steps $nsteps --warmup 2 --no-cpu-baseline --sustained 0 > $d/pmc_SQ.json 2> $d/pmc_SQ.err) || tail -3 $d/pmc_SQ.err
           if [ "$traffic" = "1" ]; then for c in FETCH_SIZE WRITE_SIZE; do
-            (cd /tmp && run ${c}_$key 500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d/pmc_$c -o p -- python3 $GRAFT_REPO_ROOT/bench.py $bargs --steps $nsteps --warmup 2 --no-cpu-baseline > $d/pmc_$c.json 2> $d/pmc_$c.err) || tail -3 $d/pmc_$c.err
+            (cd /tmp && run ${c}_$key 500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d/pmc_$c -o p -- python3 $GRAFT_REPO_ROOT/bench.py $bargs --steps $nsteps --warmup 2 --no-cpu-baseline --sustained 0 > $d/pmc_$c.json 2> $d/pmc_$c.err) || tail -3 $d/pmc_$c.err
           done; fi
           rm -f $d/*/*_kernel_trace.csv $d/*/*agent_info.csv   # per-dispatch traces are large; the stats / counter CSVs are what is kept
         done <<'LIST'

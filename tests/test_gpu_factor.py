@@ -172,11 +172,8 @@ def test_fused_tasks_replay_reference_main_loop(case, ca, runs):
     plan = r["plan"]
     arena = torch.from_numpy(plan.fill_host()).cuda()
     base = arena.data_ptr()
-    blk = {(int(b[0]), int(b[1])): b for b in plan.blocks}
-
-    def reg(rs, cs):
-        b = blk[(rs, cs)]
-        return blas.region(base + 8 * int(b[7]), int(b[6]), int(b[2]), int(b[3]), int(b[4]), int(b[5]))
+    def reg(rs, cs):  # the block instance inside the arena (row-compacted above the parent block: Region.tile_row)
+        return blas.plan_region(plan, base, rs, cs)
 
     tree = plan.tree  # heap index-1 -> label
     levels = plan.levels

@@ -118,10 +118,33 @@ def test_panel_layout(plans):
         r, c = int(row[0]), int(row[1])
         d = diag[diag[:, 1] == c][0]
         assert row[6] == d[6] and row[7] >= d[7]
-        if c < ns:
+        tm = P.block_tile_map(r, c)
+        rows = int(row[4] - row[2] + 1)
+        stored = sum(min(16, rows - 16 * t) for t in range(len(tm)) if tm[t] >= 0)
+        kept = tm[tm >= 0]
+        assert np.array_equal(kept, np.arange(len(kept)))  # kept tiles keep their order, no holes in storage
+        if r == c or P.heap_of(r) == P.heap_of(c) // 2:
+            assert stored == rows  # the separator's own rows and its parent's are stored in full
+        if c < ns and stored > 0:
             nxt = diag[diag[:, 1] == c + 1][0]
-            assert row[7] + (row[5] - row[3]) * row[6] + (row[4] - row[2]) < nxt[7]
-    assert P.arena_doubles * 8 < 16e6  # 13.9 MB of allocated blocks + alignment
+            assert row[7] + (row[5] - row[3]) * row[6] + (stored - 1) < nxt[7]
+    assert P.arena_dense_doubles * 8 < 16e6  # 13.9 MB of allocated blocks + alignment
+    assert P.arena_doubles * 8 < 9.0e6       # row compaction: 8.9 MB
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_row_compaction_keeps_every_filled_tile(case, plans):
+    """Every filled tile of every snapshot (the only rows the reference's tasks touch, blas.rg:385-395) lies in stored rows that are
+    consecutive in storage; the arena never exceeds the uncompacted one."""
+    P = plans[case]
+    assert P.arena_doubles <= P.arena_dense_doubles
+    off = P.sep_offsets
+    maps = {}
+    for lbl in range(P.levels):
+        for sx, sy, _, lo_x, _, hi_x, _ in P.snapshot_array(lbl):
+            tm = maps.setdefault((sx, sy), P.block_tile_map(int(sx), int(sy)))
+            t0, t1 = (lo_x - off[sx - 1]) // 16, (hi_x - off[sx - 1]) // 16
+            assert tm[t0] >= 0 and np.array_equal(tm[t0:t1 + 1], tm[t0] + np.arange(t1 - t0 + 1))
 
 
 def test_writers_roundtrip(tmp_path, ca, plans, golden):
