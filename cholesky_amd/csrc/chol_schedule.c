@@ -198,13 +198,21 @@ static int push_src(builder *B, chol_upd_src sd)
 }
 /* tasks of one m x n target whose sources are [src_begin, src_end): 16x16 sub-tiles for small targets
  * (k_update: the four waves split K), 64x64 macro tiles otherwise (k_update_mt: LDS-staged panels) */
+#ifndef MT_ORDER
+#define MT_ORDER 8
+#endif
 static void emit_tasks(builder *B, int macro, int64_t c_off, int ldc, int m, int n, int syrk, int src_begin, int src_end, int blk, int ar0, int br0)
 {
   chol_level_work *w = B->w;
   const int ts = macro ? 64 : 16;
   const int tr = (m + ts - 1) / ts, tc = (n + ts - 1) / ts;
-  for (int a = 0; a < tr; a++)
-    for (int b = 0; b < tc; b++) {
+  /* macro tiles in MT_ORDER x MT_ORDER blocks of the tile grid: the tasks an XCD works on at one time (a contiguous stretch of the list, k_update_mt)
+   * then share MT_ORDER row panels and MT_ORDER column panels through its L2 instead of one row panel and sixty-four column panels */
+  const int blk_o = macro ? MT_ORDER : (tr > tc ? tr : tc) + 1;
+  for (int a0 = 0; a0 < tr; a0 += blk_o)
+  for (int b0 = 0; b0 < tc; b0 += blk_o)
+  for (int a = a0; a < tr && a < a0 + blk_o; a++)
+    for (int b = b0; b < tc && b < b0 + blk_o; b++) {
       if (syrk && b > a) continue;
       chol_upd_task *t;
       if (macro) {
@@ -1900,9 +1908,21 @@ int cholamd_plan_level_mt_hist(const cholamd_plan *p, int level, int64_t out[16]
 int cholamd_plan_level_mt_fill(const cholamd_plan *p, int level, int64_t out[4])
 {
   chol_level_work w;
-  int rc = chol_build_level_work(p, NULL, level, 0, 1, &w);
+  chol_sched_opts o; chol_sched_opts_from_env(&o);
+  int rc = chol_build_level_work(p, &o, level, 0, 1, &w);
   if (rc) return rc;
   out[0] = w.n_task_mt; out[1] = out[2] = out[3] = 0;
+  if (getenv("CHOLAMD_PRINT_PHASES"))
+    for (int i = 0; i < w.n_phase; i++)
+      if (w.phase[i].kind == 3) {
+        double work = 0; int64_t nsrc = 0, kmax = 0;
+        for (int q = w.phase[i].first; q < w.phase[i].first + w.phase[i].n; q++) {
+          const chol_upd_task *t = &w.task_mt[q];
+          for (int z = t->src_begin; z < t->src_end; z++) { work += 2.0 * 4096 * w.src[z].k; if (w.src[z].k > kmax) kmax = w.src[z].k; }
+          nsrc += t->src_end - t->src_begin;
+        }
+        fprintf(stderr, "level %d phase %d: %d macro-tile tasks, %.3g padded flop, %.2f sources per task, K max %ld\n", level, i, w.phase[i].n, work, (double)nsrc / w.phase[i].n, (long)kmax);
+      }
   for (int i = 0; i < w.n_task_mt; i++) {
     const chol_upd_task *t = &w.task_mt[i];
     int64_t K = 0;
