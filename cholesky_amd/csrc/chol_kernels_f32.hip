@@ -268,6 +268,13 @@ __global__ __launch_bounds__(256) void k32_update(float *__restrict__ base, cons
 #define M32_STAGES 2
 #endif
 #define M32_SRC_BATCH 32
+/* LDS image of one 16-deep chunk of an operand: four PIECES (one per wave's DMA instruction: k-rows 4 w .. 4 w + 3, 256 floats) M32_PS
+ * floats apart.  k-step kk of the MFMA loop gives lane group g the k-row kk of piece g (k = 4 g + kk): the four groups then read at
+ * g * 272 + ..., i.e. from four different quarters of the banks.  With k = 4 kk + g out of an unpadded [k][64] image -- rounds 1 and 2 --
+ * the four groups' addresses were 64 floats apart: the same bank, a four-way conflict on every ds_read_b32, and the LDS pipe as busy as
+ * the matrix pipe (the loop without transfers and barriers stopped at 93 of 157 TF/s). */
+#define M32_PS (4 * M32 + 16)
+#define M32_IMG (4 * M32_PS)
 /* timing diagnostics of scripts/mt_bench32.hip (wrong results): -DM32_NODMA leaves the operand transfers out, -DM32_NOBAR the ring's barriers */
 #ifdef M32_NODMA
 #define M32_DIAG_DMA(x_) ((void)0)
@@ -288,19 +295,45 @@ __device__ __forceinline__ void lds_dma16_f32(const float *g, float *lds)
   const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds);
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
-// one 16-deep chunk out of the LDS images into the wave's 2 x 2 accumulators; the operands of k-step kk + 1 are requested before the
+// one 16-deep chunk out of the LDS images into the wave's quadrant.
+#ifndef M32_MFMA16
+// v_mfma_f32_32x32x2_f32: the quadrant is ONE 32 x 32 accumulator (16 registers, as many as the 2 x 2 of 16 x 16), eight MFMAs of 64 cycles
+// per chunk.  In k-step s lanes 0-31 take k = s (pieces 0, 1), lanes 32-63 k = 8 + s (pieces 2, 3); a lane reads row xo32 + (lane & 31) of
+// both operands.  (The 16x16x4 form issues at ~59 % of the matrix pipe's rate however it is fed -- the loop without transfers and barriers
+// stops at 93 TF/s, with or without bank conflicts -- as the fp64 16x16x4 does at 64 %; the 32x32x2 form reaches 155.7 of 157 TF/s in
+// scripts/mfma_peak.hip.)  nq: the quadrant has rows and columns inside the tile (wave uniform), else nothing is computed.
+__device__ __forceinline__ void m32_chunk(f16 &acc, const float *sa, const float *sb, int lane, int xo32, int yo32, bool nq)
+{
+  if (!nq) return;
+  const int h = lane >> 5;
+  const float *pa = sa + 2 * h * M32_PS + xo32, *pb = sb + 2 * h * M32_PS + yo32;
+  float x = pa[0], y = pb[0];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    float nx = 0.f, ny = 0.f;
+#ifndef M32_NOLDS /* (timing diagnostic of scripts/mt_bench32.hip: the operands of the first k-step for all of them) */
+    if (s + 1 < 8) { const int o = ((s + 1) >> 2) * M32_PS + ((s + 1) & 3) * M32; nx = pa[o]; ny = pb[o]; }
+#else
+    nx = x; ny = y;
+#endif
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, acc, 0, 0, 0);
+    x = nx; y = ny;
+  }
+}
+#else
+// (-DM32_MFMA16: the round-2 form) 2 x 2 accumulators of v_mfma_f32_16x16x4_f32; the operands of k-step kk + 1 are requested before the
 // MFMAs of k-step kk are issued.  ni / nj: 16-row / 16-column blocks of the quadrant inside the tile (wave uniform)
 __device__ __forceinline__ void m32_chunk(f4 (&acc)[2][2], const float *sa, const float *sb, int g, int xo, int yo, int ni, int nj)
 {
   float x[2], y[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) { x[i] = sa[g * M32 + xo + 16 * i]; y[i] = sb[g * M32 + yo + 16 * i]; }
+  for (int i = 0; i < 2; ++i) { x[i] = sa[g * M32_PS + xo + 16 * i]; y[i] = sb[g * M32_PS + yo + 16 * i]; }
 #pragma unroll
   for (int kk = 0; kk < M32_KB / 4; ++kk) {
     float nx[2] = { 0.f, 0.f }, ny[2] = { 0.f, 0.f };
     if (kk + 1 < M32_KB / 4) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { nx[i] = sa[(4 * (kk + 1) + g) * M32 + xo + 16 * i]; ny[i] = sb[(4 * (kk + 1) + g) * M32 + yo + 16 * i]; }
+      for (int i = 0; i < 2; ++i) { nx[i] = sa[g * M32_PS + (kk + 1) * M32 + xo + 16 * i]; ny[i] = sb[g * M32_PS + (kk + 1) * M32 + yo + 16 * i]; }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -311,10 +344,11 @@ __device__ __forceinline__ void m32_chunk(f4 (&acc)[2][2], const float *sa, cons
     for (int i = 0; i < 2; ++i) { x[i] = nx[i]; y[i] = ny[i]; }
   }
 }
+#endif
 __global__ __launch_bounds__(256, M32_WPE) void k32_update_mt(float *__restrict__ base, const chol_upd_task *__restrict__ tasks, const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd, int64_t arena_elems)
 {
-  __shared__ float sA[M32_STAGES][M32_KB][M32];
-  __shared__ float sB[M32_STAGES][M32_KB][M32];
+  __shared__ float sA[M32_STAGES][M32_IMG];
+  __shared__ float sB[M32_STAGES][M32_IMG];
   __shared__ chol_upd_src sS[M32_SRC_BATCH];
   __shared__ int sOk;
   const int tt = threadIdx.x, lane = tt & 63;
@@ -322,8 +356,16 @@ __global__ __launch_bounds__(256, M32_WPE) void k32_update_mt(float *__restrict_
   const int tid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= per_xcd || tid >= ntask) return;
   const chol_upd_task t = tasks[tid];
-  const int r15 = lane & 15, g = lane >> 4;
   const int wr = wave & 1, wc = wave >> 1;
+#ifndef M32_MFMA16
+  const int xo32 = 32 * wr + (lane & 31), yo32 = 32 * wc + (lane & 31);
+  f16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  const bool nq = 32 * wr < t.mv && 32 * wc < t.nv && (!t.lower || t.ar + 32 * wr + 31 >= t.br + 32 * wc); // (a quadrant above the diagonal of a SYRK tile stores nothing)
+#define M32_CHUNK(sa_, sb_) m32_chunk(acc, sa_, sb_, lane, xo32, yo32, nq)
+#else
+  const int r15 = lane & 15, g = lane >> 4;
   const int xo = 32 * wr + r15, yo = 32 * wc + r15;
   f4 acc[2][2];
 #pragma unroll
@@ -331,6 +373,8 @@ __global__ __launch_bounds__(256, M32_WPE) void k32_update_mt(float *__restrict_
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f4){ 0.f, 0.f, 0.f, 0.f };
   const int ni = max(0, min(2, (t.mv - 32 * wr + 15) >> 4)), nj = max(0, min(2, (t.nv - 32 * wc + 15) >> 4));
+#define M32_CHUNK(sa_, sb_) m32_chunk(acc, sa_, sb_, g, xo, yo, ni, nj)
+#endif
   bool full = t.mv == M32 && t.nv == M32;
   if (!full && arena_elems > 0) { // an edge tile: may the DMA read 64 rows of every source?
     if (tt == 0) sOk = 1;
@@ -359,8 +403,8 @@ __global__ __launch_bounds__(256, M32_WPE) void k32_update_mt(float *__restrict_
         while (is < ns && ik + M32_KB > sS[is].k) { ++is; ik = 0; }                                                   \
         const int e_ = 256 * wave + 4 * lane;                                                                         \
         const int st_ = issued % M32_STAGES;                                                                          \
-        M32_DIAG_DMA(lds_dma16_f32(base + sS[is].a_off + t.ar + e_ % M32 + (int64_t)(ik + e_ / M32) * sS[is].lda, &sA[st_][0][0] + 256 * wave)); \
-        M32_DIAG_DMA(lds_dma16_f32(base + sS[is].b_off + t.br + e_ % M32 + (int64_t)(ik + e_ / M32) * sS[is].ldb, &sB[st_][0][0] + 256 * wave)); \
+        M32_DIAG_DMA(lds_dma16_f32(base + sS[is].a_off + t.ar + e_ % M32 + (int64_t)(ik + e_ / M32) * sS[is].lda, &sA[st_][0] + M32_PS * wave)); \
+        M32_DIAG_DMA(lds_dma16_f32(base + sS[is].b_off + t.br + e_ % M32 + (int64_t)(ik + e_ / M32) * sS[is].ldb, &sB[st_][0] + M32_PS * wave)); \
         ++issued; ik += M32_KB;                                                                                       \
       }
       for (int i = 0; i < M32_STAGES - 1 && issued < total; ++i) M32_ISSUE();
@@ -369,7 +413,7 @@ __global__ __launch_bounds__(256, M32_WPE) void k32_update_mt(float *__restrict_
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         M32_DIAG_BAR(__builtin_amdgcn_s_barrier()); // every wave's part of chunk c is in LDS; every wave has left chunk c - 1
         if (issued < total) M32_ISSUE(); // into the stage chunk c - 1 occupied
-        m32_chunk(acc, &sA[c % M32_STAGES][0][0], &sB[c % M32_STAGES][0][0], g, xo, yo, ni, nj);
+        M32_CHUNK(&sA[c % M32_STAGES][0], &sB[c % M32_STAGES][0]);
       }
 #undef M32_ISSUE
     }
@@ -396,7 +440,7 @@ __global__ __launch_bounds__(256, M32_WPE) void k32_update_mt(float *__restrict_
       }
       for (int k0 = kbeg; k0 < K; k0 += M32_KB) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sA[buf][skq + 4 * i][srow] = ra[i]; sB[buf][skq + 4 * i][srow] = rb[i]; }
+        for (int i = 0; i < 4; ++i) { sA[buf][i * M32_PS + skq * M32 + srow] = ra[i]; sB[buf][i * M32_PS + skq * M32 + srow] = rb[i]; } // k = skq + 4 i: row skq of piece i
         if (k0 + M32_KB < K) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -406,11 +450,31 @@ __global__ __launch_bounds__(256, M32_WPE) void k32_update_mt(float *__restrict_
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // LDS-only barrier: the prefetch stays in flight
-        m32_chunk(acc, &sA[buf][0][0], &sB[buf][0][0], g, xo, yo, ni, nj);
+        M32_CHUNK(&sA[buf][0], &sB[buf][0]);
         buf ^= 1;
       }
     }
   }
+#ifndef M32_MFMA16
+  // epilogue: register q of lane l is C(row l & 31, column 8 (q >> 2) + 4 (l >> 5) + (q & 3)) of the wave's quadrant (first MFMA operand = the
+  // column side); every C value of the lane requested before the first is used (clamped addresses, masked stores)
+  if (nq) {
+    const int r = 32 * wr + (lane & 31);
+    const float *Cr = base + t.c_off + min(r, t.mv - 1);
+    float cv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = min(32 * wc + 8 * (q >> 2) + 4 * (lane >> 5) + (q & 3), t.nv - 1);
+      cv[q] = *(const volatile float *)(Cr + (int64_t)c * t.ldc);
+    }
+    float *C = base + t.c_off + r;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = 32 * wc + 8 * (q >> 2) + 4 * (lane >> 5) + (q & 3);
+      if (r < t.mv && c < t.nv && (!t.lower || t.ar + r >= t.br + c)) C[(int64_t)c * t.ldc] = cv[q] - acc[q];
+    }
+  }
+#else
   // epilogue: every C value of the lane requested before the first is used (clamped addresses, masked stores); register q of lane
   // (r15, g) is C(row 16 i + r15, column 16 j + 4 g + q) of the wave's quadrant
   float cv[2][2][4];
@@ -435,6 +499,8 @@ __global__ __launch_bounds__(256, M32_WPE) void k32_update_mt(float *__restrict_
         if (r < t.mv && c < t.nv && (!t.lower || t.ar + r >= t.br + c)) C[(int64_t)c * t.ldc] = cv[i][j][q] - acc[i][j][q];
       }
     }
+#endif
+#undef M32_CHUNK
 }
 
 // ------------------------------------------------------------------------------------------------
