@@ -151,6 +151,8 @@ def load():
     L.cholamd_device_event_overhead.argtypes = [vp, vp, C.POINTER(C.c_float)]
     RP, FP = C.POINTER(Region), C.POINTER(Filled)
     L.cholamd_plan_region.argtypes = [vp, vp, ci, ci, RP]
+    L.cholamd_plan_level_work_volume_opts.argtypes = [vp, ci, ci, ci, vp]
+    L.cholamd_plan_level_mt_fill.argtypes = [vp, ci, vp]
     L.cholamd_plan_arena_dense_doubles.argtypes = [vp]
     L.cholamd_plan_arena_dense_doubles.restype = C.c_int64
     L.cholamd_plan_block_tile_map.argtypes = [vp, ci, ci, vp]

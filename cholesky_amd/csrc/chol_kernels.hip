@@ -417,22 +417,32 @@ __device__ __forceinline__ void update_mt_body(double *__restrict__ base, const 
       __builtin_amdgcn_s_barrier();
       int total = 0;
       for (int s = 0; s < ns; ++s) total += sS[s].k / MKB;
-      int is = 0, ik = 0, issued = 0; // issue cursor
+      // issue cursor: source `is`, `left` full chunks of it to go, the lane's addresses of the next chunk in registers (the descriptor in LDS is read
+      // once per source, not once per chunk: its round trips sat in front of every chunk's MFMAs)
+      int is = -1, left = 0, issued = 0;
+      const double *pa[QA], *pb[QB];
+      int64_t sta = 0, stb = 0;
 #define MT_ISSUE()                                                                                                    \
       {                                                                                                               \
-        while (is < ns && ik + MKB > sS[is].k) { ++is; ik = 0; }                                                      \
-        const int64_t ao_ = sS[is].a_off, bo_ = sS[is].b_off;                                                         \
-        const int lda_ = sS[is].lda, ldb_ = sS[is].ldb;                                                               \
+        while (left == 0) {                                                                                           \
+          ++is;                                                                                                       \
+          left = sS[is].k / MKB;                                                                                      \
+          const int64_t ao_ = sS[is].a_off, bo_ = sS[is].b_off;                                                       \
+          const int lda_ = sS[is].lda, ldb_ = sS[is].ldb;                                                             \
+          _Pragma("unroll") for (int pp = 0; pp < QA; ++pp) {                                                         \
+            const int e_ = 128 * (QA * wave + pp) + 2 * lane;                                                         \
+            pa[pp] = base + ao_ + t.ar + e_ % TM + (int64_t)(e_ / TM) * lda_;                                         \
+          }                                                                                                           \
+          _Pragma("unroll") for (int pp = 0; pp < QB; ++pp) {                                                         \
+            const int e_ = 128 * (QB * wave + pp) + 2 * lane;                                                         \
+            pb[pp] = base + bo_ + t.br + e_ % TN + (int64_t)(e_ / TN) * ldb_;                                         \
+          }                                                                                                           \
+          sta = (int64_t)MKB * lda_; stb = (int64_t)MKB * ldb_;                                                       \
+        }                                                                                                             \
         const int st_ = issued % MT_STAGES;                                                                           \
-        _Pragma("unroll") for (int pp = 0; pp < QA; ++pp) {                                                           \
-          const int e_ = 128 * (QA * wave + pp) + 2 * lane;                                                           \
-          MT_DIAG_DMA(lds_dma16(base + ao_ + t.ar + e_ % TM + (int64_t)(ik + e_ / TM) * lda_, &sA[st_][0][0] + 128 * (QA * wave + pp))); \
-        }                                                                                                             \
-        _Pragma("unroll") for (int pp = 0; pp < QB; ++pp) {                                                           \
-          const int e_ = 128 * (QB * wave + pp) + 2 * lane;                                                           \
-          MT_DIAG_DMA(lds_dma16(base + bo_ + t.br + e_ % TN + (int64_t)(ik + e_ / TN) * ldb_, &sB[st_][0][0] + 128 * (QB * wave + pp))); \
-        }                                                                                                             \
-        ++issued; ik += MKB;                                                                                          \
+        _Pragma("unroll") for (int pp = 0; pp < QA; ++pp) { MT_DIAG_DMA(lds_dma16(pa[pp], &sA[st_][0][0] + 128 * (QA * wave + pp))); pa[pp] += sta; } \
+        _Pragma("unroll") for (int pp = 0; pp < QB; ++pp) { MT_DIAG_DMA(lds_dma16(pb[pp], &sB[st_][0][0] + 128 * (QB * wave + pp))); pb[pp] += stb; } \
+        --left; ++issued;                                                                                             \
       }
       for (int i = 0; i < MT_STAGES - 1 && issued < total; ++i) MT_ISSUE();
       for (int c = 0; c < total; ++c) {

@@ -396,16 +396,26 @@ __global__ __launch_bounds__(256, M32_WPE) void k32_update_mt(float *__restrict_
       __builtin_amdgcn_s_barrier();
       int total = 0;
       for (int s = 0; s < ns; ++s) total += sS[s].k / M32_KB;
-      int is = 0, ik = 0, issued = 0; // issue cursor
-      // one DMA instruction per wave, chunk and operand: wave w moves k-rows 4 w .. 4 w + 3 (256 floats), lane l the four floats at 4 l
+      // issue cursor: source `is`, `left` full chunks of it to go, the lane's addresses of the next chunk in registers -- the descriptor in LDS is
+      // read once per source, not once per chunk (five LDS round trips in front of every chunk's MFMAs otherwise).
+      // One DMA instruction per wave, chunk and operand: wave w moves k-rows 4 w .. 4 w + 3 (256 floats), lane l the four floats at 4 l
+      int is = -1, left = 0, issued = 0;
+      const float *pa = nullptr, *pb = nullptr;
+      int64_t sta = 0, stb = 0;
+      const int e_ = 256 * wave + 4 * lane;
 #define M32_ISSUE()                                                                                                   \
       {                                                                                                               \
-        while (is < ns && ik + M32_KB > sS[is].k) { ++is; ik = 0; }                                                   \
-        const int e_ = 256 * wave + 4 * lane;                                                                         \
+        while (left == 0) {                                                                                           \
+          ++is;                                                                                                       \
+          left = sS[is].k / M32_KB;                                                                                   \
+          pa = base + sS[is].a_off + t.ar + e_ % M32 + (int64_t)(e_ / M32) * sS[is].lda;                              \
+          pb = base + sS[is].b_off + t.br + e_ % M32 + (int64_t)(e_ / M32) * sS[is].ldb;                              \
+          sta = (int64_t)M32_KB * sS[is].lda; stb = (int64_t)M32_KB * sS[is].ldb;                                     \
+        }                                                                                                             \
         const int st_ = issued % M32_STAGES;                                                                          \
-        M32_DIAG_DMA(lds_dma16_f32(base + sS[is].a_off + t.ar + e_ % M32 + (int64_t)(ik + e_ / M32) * sS[is].lda, &sA[st_][0] + M32_PS * wave)); \
-        M32_DIAG_DMA(lds_dma16_f32(base + sS[is].b_off + t.br + e_ % M32 + (int64_t)(ik + e_ / M32) * sS[is].ldb, &sB[st_][0] + M32_PS * wave)); \
-        ++issued; ik += M32_KB;                                                                                       \
+        M32_DIAG_DMA(lds_dma16_f32(pa, &sA[st_][0] + M32_PS * wave));                                                 \
+        M32_DIAG_DMA(lds_dma16_f32(pb, &sB[st_][0] + M32_PS * wave));                                                 \
+        pa += sta; pb += stb; --left; ++issued;                                                                       \
       }
       for (int i = 0; i < M32_STAGES - 1 && issued < total; ++i) M32_ISSUE();
       for (int c = 0; c < total; ++c) {

@@ -1701,15 +1701,13 @@ int cholamd_plan_program_counts(const cholamd_plan *p, int follow, int out[6])
 /* volumes of one level's lists for (rank, world) under dist_top = 0 / 1 / 2 (auto): what the CPU tests sum over the ranks.
  * out: POTRF columns, TRSM elements (rows x columns), update volume (target elements x source depth), broadcast entries,
  * broadcast doubles, a checksum of the broadcast list (identical on every rank: the sequence is collective) */
-int cholamd_plan_level_work_volume(const cholamd_plan *p, int level, int rank, int world, int dist_top, int64_t out[6])
+static int level_work_volume(const cholamd_plan *p, const chol_sched_opts *o, int level, int rank, int world, int64_t out[6], int64_t counts[3])
 {
-  chol_sched_opts o;
-  chol_sched_opts_default(&o);
-  o.dist_top = dist_top;
   chol_level_work w;
-  int rc = chol_build_level_work(p, &o, level, rank, world, &w);
+  int rc = chol_build_level_work(p, o, level, rank, world, &w);
   if (rc) return rc;
   memset(out, 0, 6 * sizeof(int64_t));
+  if (counts) { counts[0] = w.n_task; counts[1] = w.n_task_mt; counts[2] = 0; for (int i = 0; i < w.n_trsm; i++) counts[2] += w.trsm[i].m > 0; }
   for (int i = 0; i < w.n_potrf; i++) out[0] += w.potrf[i].n;
   for (int i = 0; i < w.n_trsm; i++) out[1] += (int64_t)w.trsm[i].m * w.trsm[i].n;
   for (int pass = 0; pass < 2; pass++) {
@@ -1733,6 +1731,23 @@ int cholamd_plan_level_work_volume(const cholamd_plan *p, int level, int rank, i
   if (nb6 != w.n_bcast) { chol_set_error("internal: %d broadcast entries, %d in phases", w.n_bcast, nb6); rc = CHOLAMD_ERR_ARG; }
   chol_level_work_free(&w);
   return rc;
+}
+int cholamd_plan_level_work_volume(const cholamd_plan *p, int level, int rank, int world, int dist_top, int64_t out[6])
+{
+  chol_sched_opts o;
+  chol_sched_opts_default(&o);
+  o.dist_top = dist_top;
+  return level_work_volume(p, &o, level, rank, world, out, NULL);
+}
+/* the same volumes under the level schedule's merging switch and macro-tile threshold (single GPU), plus the list lengths:
+ * out[6..8] = 16x16 tasks, 64x64 macro-tile tasks, TRSM strips */
+int cholamd_plan_level_work_volume_opts(const cholamd_plan *p, int level, int merge_targets, int mt_min_tiles, int64_t out[9])
+{
+  chol_sched_opts o;
+  chol_sched_opts_default(&o);
+  o.merge_targets = merge_targets != 0;
+  if (mt_min_tiles >= 0) o.mt_min_tiles = mt_min_tiles;
+  return level_work_volume(p, &o, level, 0, 1, out, out + 6);
 }
 
 /* Volume of the extend-add exchange for (rank, world) under dist_top = 0 / 1 / 2 (auto), in arena elements: out[0] received, out[1]

@@ -163,6 +163,12 @@ class Plan:
         check(self.L.cholamd_plan_level_work_volume(self.h, level, rank, world, dist_top, out.ctypes.data), "cholamd_plan_level_work_volume")
         return tuple(int(v) for v in out)
 
+    def level_work_volume_opts(self, level, merge_targets=1, mt_min_tiles=-1):
+        """level_work_volume (single GPU) under option merge_targets / mt_min_tiles + (16x16 tasks, macro-tile tasks, TRSM strips)."""
+        out = np.zeros(9, dtype=np.int64)
+        check(self.L.cholamd_plan_level_work_volume_opts(self.h, level, int(merge_targets), int(mt_min_tiles), out.ctypes.data), "cholamd_plan_level_work_volume_opts")
+        return tuple(int(v) for v in out)
+
     def program_check(self, follow=True, workers=64):
         """Host-side self-check of the one-launch program (raises CholamdError on a dead-lock or a mismatch)."""
         check(self.L.cholamd_plan_program_check(self.h, int(follow), int(workers)), "cholamd_plan_program_check")

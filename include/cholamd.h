@@ -182,6 +182,9 @@ int cholamd_plan_fill_host_part(const cholamd_plan *p, double *arena, int rank, 
 /* sizes of the device work lists of one tree level for (rank, world): potrf descriptors, trsm
  * strips, update tasks, update sources */
 int cholamd_plan_level_work_counts(const cholamd_plan *p, int level, int rank, int world, int out[4]);
+/* the volumes of cholamd_plan_level_work_volume (single GPU) under the level schedule's merging switch (option merge_targets) and macro-tile
+ * threshold (mt_min_tiles, < 0: default), plus the list lengths: out[6..8] = 16x16 tasks, 64x64 macro-tile tasks, TRSM strips */
+int cholamd_plan_level_work_volume_opts(const cholamd_plan *p, int level, int merge_targets, int mt_min_tiles, int64_t out[9]);
 /* how full the 64 x 64 macro-tile update tasks of a level are (single GPU): out = { tasks, tasks with all 64 x 64 elements valid,
  * sum of valid elements x depth, sum of tile elements x depth } */
 int cholamd_plan_level_mt_fill(const cholamd_plan *p, int level, int64_t out[4]);

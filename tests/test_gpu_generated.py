@@ -133,3 +133,33 @@ def test_super_block_trailing_updates_match_oracle(opts, tmp_path):
     dev.sync()
     L32 = np.tril(plan.arena_to_dense(a32.cpu().numpy().astype(np.float64)))
     assert np.abs(L32 - Lo).max() <= 2e-5 * np.abs(Lo).max()
+
+
+@pytest.mark.parametrize("dims", [(20, 20, 20, 4, 16), (24, 24, 12, 3, 32), (18, 18, 18, 3, 48)])
+def test_merged_targets_and_row_compaction_keep_the_factor(dims):
+    """Level schedule on 64x64 macro tiles (mt_min_tiles = 1 forces them on a small problem): extend-add targets and panel row runs merged
+    where they are neighbours in storage (option merge_targets) against the unmerged lists.  Every element keeps its sources and
+    their order; a merged target may move from the 16x16 kernel (four waves split K) to the macro-tile kernel (K in 16-deep chunks), so the
+    factors agree to rounding (1e-13 of the largest entry), bit for bit where the targets were macro tiles before."""
+    import cholesky_amd as ca
+    orc.use_own_kernels()
+    prob = ca.Problem(*dims)
+    plan = prob.plan()
+    assert plan.arena_doubles <= plan.arena_dense_doubles
+    res = []
+    for merge in (0, 1):
+        dev = ca.Device(plan, 0)
+        dev.set_option("program", 0)
+        dev.set_option("mt_min_tiles", 1)
+        dev.set_option("merge_targets", merge)
+        arena = dev.new_arena()
+        dev.fill(arena)
+        dev.factor(arena)
+        dev.sync()
+        assert dev.info() == (0, 0)
+        res.append(arena.cpu().numpy())
+    assert np.abs(res[0] - res[1]).max() <= 1e-13 * np.abs(res[0]).max()
+    L = np.tril(plan.arena_to_dense(res[1]))
+    A = plan.arena_to_dense(plan.fill_host())
+    A = A + np.tril(A, -1).T
+    assert np.linalg.norm(L @ L.T - A) / np.linalg.norm(A) <= 1e-10

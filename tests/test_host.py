@@ -343,3 +343,18 @@ def test_follower_round_grouping_is_a_function_of_the_list_alone():
             job, n_ext, T, n_wait = buf[4 * i], buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]
             r, own = rounds(n_ext, T)
             assert 1 <= T <= 10 and n_ext >= 1 and sum(r) == n_ext, (case, job)
+
+
+@pytest.mark.parametrize("dims", [(20, 20, 20, 4, 16), (24, 24, 12, 3, 32), (30, 30, 10, 5, 32)])
+def test_merged_targets_cover_the_same_work_with_fewer_tasks(dims, ca):
+    """Level schedule, option merge_targets: extend-add targets / panel row runs that are neighbours in storage become one target / run.
+    The pivots, the solved elements and the update volume (target elements x source depth) do not change, the lists get shorter."""
+    plan = ca.Problem(*dims).plan()
+    shorter = 0
+    for lvl in range(plan.levels):
+        a = plan.level_work_volume_opts(lvl, merge_targets=0, mt_min_tiles=1)
+        b = plan.level_work_volume_opts(lvl, merge_targets=1, mt_min_tiles=1)
+        assert a[:3] == b[:3]                      # POTRF columns, TRSM elements, update volume
+        assert b[6] + b[7] <= a[6] + a[7] and b[8] <= a[8]   # update tasks (16x16 + macro tiles: a merged target may move from one list to the other), strips
+        shorter += (a[6] + a[7] - b[6] - b[7]) + (a[8] - b[8])
+    assert shorter > 0
