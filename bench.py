@@ -36,10 +36,17 @@ CASES = {
     "lapl_400x400": ("lapl_20_2.mtx", "lapl_20_2_ord_5.txt", "lapl_20_2_clust_5.txt"),
     "lapl_3375x3375": ("lapl_15_3.mtx", "lapl_15_3_ord_5.txt", "lapl_15_3_clust_5.txt"),
 }
-SUSTAINED_FP64_MFMA_TFLOPS = 50.0  # measured on this pool (scripts/mfma_peak.hip): v_mfma_f64_16x16x4_f64 out of registers on all 256 CUs: 48-50 TF/s
-SUSTAINED_NOTE = ("what a register-operand v_mfma_f64_16x16x4_f64 loop on all 256 CUs sustains here (scripts/mfma_peak.hip; profiles/r3/mfma_peak/): "
-                  "64 % of `peak`; `frac` stays against `peak`")
-PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r2", "summary.json")  # scripts/profile_summary.py over the rocprofv3 passes of this command
+SUSTAINED_FP64_MFMA_TFLOPS = 53.5  # highest executed fp64 MFMA rate measured on this pool: k_update_mt on one 8192^2 SYRK at K = 432 (scripts/mt_bench.hip)
+SUSTAINED_NOTE = ("highest executed v_mfma_f64_16x16x4_f64 rate measured on this pool: the macro-tile update kernel on one 8192^2 SYRK target at K = 432 "
+                  "(scripts/mt_bench.hip); register-operand loops on all 256 CUs reach 47.7-50.5 (scripts/mfma_peak.hip, scripts/mfma32_probe.hip; "
+                  "profiles/r3/mfma_peak/): 68 % of `peak`; `frac` stays against `peak`")
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r3", "summary.json")  # scripts/profile_summary.py over the rocprofv3 passes of this command
+
+
+def stored_rows(plan, r, c, rows):
+    """Rows of block (r, c) that its panel stores (row compaction: the kept 16-row tiles)."""
+    tm = plan.block_tile_map(r, c)
+    return int(sum(min(16, rows - 16 * t) for t in range(len(tm)) if tm[t] >= 0))
 
 
 def profile_numbers(kernel, case, mixed, options=()):
@@ -51,7 +58,7 @@ def profile_numbers(kernel, case, mixed, options=()):
         key = case + (":mixed" if mixed else "") + ("".join(":" + o for o in sorted(options)) if options else "")
         k = runs[key]["kernels"][kernel]
         return {"hbm_bytes_per_launch": k.get("hbm_bytes_per_launch_corrected"), "avg_launch_us": k.get("avg_launch_us"),
-                "mfma_busy_frac": k.get("mfma_busy_frac"), "source": "profiles/r2/summary.json: " + runs[key].get("source", "")}
+                "mfma_busy_frac": k.get("mfma_busy_frac"), "source": "profiles/r3/summary.json: " + runs[key].get("source", "")}
     except Exception:
         return {}
 
@@ -365,7 +372,7 @@ def main():
             "plan": {"n": plan.n, "levels": plan.levels, "nsep": plan.nsep, "flops": plan.flops, "alg_bytes": plan.alg_bytes,
                      "flops_by_kind": {"potrf": float(flops[0]), "trsm": float(flops[1]), "update": float(flops[2] + flops[3])},
                      "piv_entries": sum(n * (n + 1) // 2 for n in sizes.values()),
-                     "anc_entries": sum(int(b[4] - b[2] + 1) * sizes[int(b[1])] for b in blocks if b[0] != b[1])},
+                     "anc_entries": sum(stored_rows(plan, int(b[0]), int(b[1]), int(b[4] - b[2] + 1)) * sizes[int(b[1])] for b in blocks if b[0] != b[1])},
             "workload": (f"generated {gn}^3 7-point Laplacian, geometric nested dissection ({glv} levels, tile {gtile}), cholamd_generate_laplacian" if generated else
                          f"tests/{args.case} (reference fixture: 7-point Laplacian, nested-dissection ordering from the fixture files)"),
             "data": "synthetic (generated Laplacian, ordering and clusters)" if generated else "reference fixture (matrix, ordering and cluster files from the reference's tests/, copied as data); no random data anywhere",

@@ -100,7 +100,7 @@ def assemble(rec):
                      "peak_note": f"{world} x {peak1} TFLOP/s" if world > 1 else None,
                      "traffic": traffic, "traffic_note": traffic_note,
                      "alg_bytes_per_launch": plan["alg_bytes"] / max(launches_per_step, 1e-9),
-                     "alg_bytes_note": "SURVEY 8(d): B_alg = 8 (nnz(tril A) + nnz(L)) per factorisation / launches of the kernel per factorisation; dense_panel_bytes_per_launch = what the dense panels (structural zeros included) make those launches move",
+                     "alg_bytes_note": "SURVEY 8(d): B_alg = 8 (nnz(tril A) + nnz(L)) per factorisation / launches of the kernel per factorisation; dense_panel_bytes_per_launch = what the stored panels (row-compacted; the structural zeros inside the kept tiles included) make those launches move",
                      "dense_panel_bytes_per_launch": (panel_bytes[dom] / max(launches_per_step, 1e-9)) if panel_bytes[dom] else None,
                      "avg_launch_us": round(avg_s * 1e6, 2), "avg_launch_us_events_raw": round(avg_s_raw * 1e6, 2), "event_pair_overhead_us": round(ev_ms * 1e3, 2),
                      "slowest_rank": dom_rank,

@@ -37,7 +37,7 @@ prog)   run prog 180 python scripts/prog_check.py > $out/prog_check.txt 2>&1; ca
 proggen) run proggen 240 python scripts/prog_check.py gen:12,12,12,4,16 gen:20,20,20,5,64 gen:10,9,8,5,8 > $out/prog_gen.txt 2>&1; cat $out/prog_gen.txt ;;
 trace)  run trace 120 python scripts/prog_trace.py lapl_3375x3375 > $out/prog_trace.txt 2>&1; cat $out/prog_trace.txt
         run trace0 120 python scripts/prog_trace.py lapl_3375x3375 follow=0 > $out/prog_trace_nofollow.txt 2>&1; cat $out/prog_trace_nofollow.txt ;;
-profiles) # every rocprofv3 pass behind profiles/r2/summary.json: key | bench arguments | steps
+profiles) # every rocprofv3 pass behind profiles/rN/summary.json: key | bench arguments | steps
         SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU"
         while IFS='|' read -r key bargs nsteps mops traffic; do
           [ -z "$key" ] && continue
@@ -56,6 +56,7 @@ gen_40_6|--case gen:40:6|5|SQ_INSTS_VALU_MFMA_MOPS_F64|0
 gen_60_8|--case gen:60:8|3|SQ_INSTS_VALU_MFMA_MOPS_F64|1
 gen_60_8_mixed|--case gen:60:8 --precision mixed|3|SQ_INSTS_VALU_MFMA_MOPS_F32|0
 gen_100_10_mixed|--case gen:100:10 --precision mixed|2|SQ_INSTS_VALU_MFMA_MOPS_F32|0
+gen_100_10|--case gen:100:10|2|SQ_INSTS_VALU_MFMA_MOPS_F64|0
 LIST
         ;;
 super)  for sb in 1 2 3 4; do for c in gen:40:6 gen:60:8; do

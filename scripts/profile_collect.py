@@ -11,7 +11,7 @@ import shutil
 import sys
 
 KEYS = {"lapl_3375": "lapl_3375x3375", "lapl_3375_levels": "lapl_3375x3375:program=0", "gen_40_6": "gen:40:6", "gen_60_8": "gen:60:8",
-        "gen_60_8_mixed": "gen:60:8:mixed", "gen_100_10_mixed": "gen:100:10:mixed"}
+        "gen_60_8_mixed": "gen:60:8:mixed", "gen_100_10_mixed": "gen:100:10:mixed", "gen_100_10": "gen:100:10"}
 
 
 def short(name):
