@@ -1964,10 +1964,13 @@ template <int T, int NT> __device__ __forceinline__ void trsm_w_solve(d4 (&tile)
     for (int st = 0; st < 4; ++st) wv[st] = sd[st * 64];
     const d4 x = solve16(tile[J], wv);
     if (vrow) {
+      int ro = r15;
+      asm volatile("" : "+v"(ro)); // the lane's store address is rebuilt per column tile (two instructions): hoisted, it was the one 64-bit value
+                                   // the nine-tile instance spilled, with a scratch reload in front of every tile's stores
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int col = J * TS + g + 4 * q;
-        if (J + 1 < T || col < n) B[r15 + (int64_t)col * ldb] = x[q];
+        if (J + 1 < T || col < n) B[ro + (int64_t)col * ldb] = x[q];
       }
     }
     double nx[4];
@@ -2113,6 +2116,10 @@ __global__ __launch_bounds__(64 * TT_WAVES) void k_trsm_wt(double *__restrict__ 
     const chol_trsm_desc d = descs[id0 + wave];
     b_off = d.b_off; m = d.m; ldb = d.ldb;
   }
+  // the strip's base is wave uniform: kept in scalar registers (as a vector pair it was the one value the T = 9 instance spilled -- a scratch
+  // reload in front of every column tile's store)
+  b_off = ((int64_t)__builtin_amdgcn_readfirstlane((int)(b_off >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)b_off);
+  m = __builtin_amdgcn_readfirstlane(m); ldb = __builtin_amdgcn_readfirstlane(ldb);
   double *B = base + b_off;
   const bool vrow = r15 < m;
   // the LDS-DMA pairs rows (r, r + 1): with n odd the pair (n - 1, n) is fetched from (n - 2, n - 1) and row n - 1 of the last row
@@ -2414,10 +2421,9 @@ template <bool BWD, class TL>
 __global__ __launch_bounds__(256) void k_solve_trsv(const TL *__restrict__ base, const chol_trsv_desc *__restrict__ descs, const double *__restrict__ Wall,
                                                     double *__restrict__ y, int col0)
 {
-  __shared__ double sL[SNB][SNB + 1]; // [r][c] of the diagonal block
+  __shared__ double sL[SNB][SNB + 1]; // [r][c] of the current diagonal block
   __shared__ double sW[SNB / TS][TS * TS];
-  __shared__ double sx[SNB];
-  __shared__ double sred[4][SNB];
+  __shared__ double sxs[SSPAN]; // the span's part of the vector: lives in LDS from the first block to the last
   const chol_trsv_desc d = descs[blockIdx.x];
   const TL *Lm = base + d.a_off;
   const double *W = Wall + d.dinv_off;
@@ -2426,91 +2432,102 @@ __global__ __launch_bounds__(256) void k_solve_trsv(const TL *__restrict__ base,
   if (d.n <= col0) return;
   const int n = min(d.n, col0 + SSPAN); // rows and columns of this launch's span
   const int nblk = (n - col0 + SNB - 1) / SNB;
-  for (int bi = 0; bi < nblk; ++bi) {
+  // The span is a chain of (at most) four 64-column blocks: in-block solve on wave 0, then the fold of the block into the span's other rows (forward:
+  // the rows below, x[r] -= L(r, J) x_J; backward: the columns in front, x[c] -= L(J, c)^T x_J).  Nothing the chain reads from memory depends on x,
+  // and a 256-thread workgroup alone on its CU owns 512 registers per lane: EVERY load of the span -- the four triangles, their 16x16 inverses and
+  // the six fold passes -- is requested before the first block is solved, so the span costs one memory round trip instead of three per block
+  // (100 spans per direction at 100^3 are the critical path of a solve: 62 / 71 us per span in profiles/r3, forward / backward, before this).
+  constexpr int NB4 = SSPAN / SNB, NL = SNB * SNB / 256, NW = (SNB / TS) * TS * TS / 256, NF = NB4 * (NB4 - 1) / 2;
+  static_assert(SSPAN == 256 && NB4 == 4, "one thread per span row, four blocks");
+  TL lv[NB4][NL], fa[NF][16];
+  double wv[NB4][NW];
+  const int fi = tid >> 2, part = tid & 3; // fold: four threads per row (forward) / column (backward), sixteen elements each
+#pragma unroll
+  for (int bi = 0; bi < NB4; ++bi) {
+    if (bi >= nblk) break;
     const int J0 = col0 + (BWD ? nblk - 1 - bi : bi) * SNB, jb = min(SNB, n - J0);
-    // stage the block: triangle, inverses, right-hand side
-    for (int e = tid; e < SNB * SNB; e += 256) {
-      const int r = e & (SNB - 1), c = e >> 6;
-      sL[r][c] = (r < jb && c <= r) ? (double)Lm[(J0 + r) + (int64_t)(J0 + c) * lda] : 0.0;
+#pragma unroll
+    for (int u = 0; u < NL; ++u) { // (clamped addresses: a partial block reads its last row / column again)
+      const int e = tid + 256 * u, r = e & (SNB - 1), c = e >> 6;
+      lv[bi][u] = Lm[(J0 + min(r, jb - 1)) + (int64_t)(J0 + min(c, jb - 1)) * lda];
     }
-    for (int e = tid; e < (SNB / TS) * TS * TS; e += 256) {
-      const int t = e >> 8;
-      if (t * TS < jb) sW[t][e & 255] = W[(int64_t)(J0 / TS + t) * TS * TS + (e & 255)];
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+      const int e = tid + 256 * u, t = min(e >> 8, (jb - 1) / TS);
+      wv[bi][u] = W[(int64_t)(J0 / TS + t) * TS * TS + (e & 255)];
     }
-    if (BWD) {
-      // x_J <- x_J - L(rows below, J)^T x(rows below): wave w takes the columns w, w+4, ..., lanes stride the rows
-      // sixteen columns per wave, all sixteen loads of a row chunk in flight (one column after the other is one memory round trip
-      // after the other: the launch was latency bound at ~115 us per 256-column span)
-      double acc[SNB / 4];
 #pragma unroll
-      for (int cc = 0; cc < SNB / 4; ++cc) acc[cc] = 0.0;
-      for (int i = J0 + jb + lane; i < n; i += 64) {
-        const double xi = x[i];
-        TL lv[SNB / 4];
+    for (int p = 0; p < NB4 - 1 - bi; ++p) { // the bi-th block of the chain has at most 3 - bi blocks of 64 rows / columns to fold into
+      const int f = bi * (NB4 - 1) - bi * (bi - 1) / 2 + p;
+      if (BWD) {
+        const int c = col0 + 64 * p + fi; // a column in front of the block (every block in front of another one is full)
+        if (col0 + 64 * p < J0) {
 #pragma unroll
-        for (int cc = 0; cc < SNB / 4; ++cc) { const int c = wave + 4 * cc; lv[cc] = Lm[i + (int64_t)(J0 + min(c, jb - 1)) * lda]; }
+          for (int u = 0; u < 16; ++u) fa[f][u] = Lm[J0 + min(16 * part + u, jb - 1) + (int64_t)c * lda];
+        }
+      } else {
+        const int r0 = J0 + jb + 64 * p;
+        if (r0 < n) {
 #pragma unroll
-        for (int cc = 0; cc < SNB / 4; ++cc) acc[cc] += (double)lv[cc] * xi;
+          for (int u = 0; u < 16; ++u) fa[f][u] = Lm[min(r0 + fi, n - 1) + (int64_t)(J0 + min(16 * part + u, jb - 1)) * lda];
+        }
       }
-#pragma unroll
-      for (int cc = 0; cc < SNB / 4; ++cc) {
-        const int c = wave + 4 * cc;
-        double a = acc[cc];
-        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
-        if (lane == 0) sx[c] = (c < jb) ? x[J0 + c] - a : 0.0;
-      }
-    } else {
-      if (tid < SNB) sx[tid] = (tid < jb) ? x[J0 + tid] : 0.0;
     }
+  }
+  sxs[tid] = col0 + tid < n ? x[col0 + tid] : 0.0;
+#pragma unroll
+  for (int bi = 0; bi < NB4; ++bi) {
+    if (bi >= nblk) break;
+    const int J0 = col0 + (BWD ? nblk - 1 - bi : bi) * SNB, jb = min(SNB, n - J0);
+    double *const sx = sxs + (J0 - col0); // the block's right-hand side, then its solution (the blocks solved before it have folded themselves in)
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int e = tid + 256 * u, r = e & (SNB - 1), c = e >> 6;
+      sL[r][c] = (r < jb && c <= r) ? (double)lv[bi][u] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < NW; ++u) { const int e = tid + 256 * u; sW[e >> 8][e & 255] = wv[bi][u]; }
     __syncthreads();
-    if (wave == 0) { // in-block solve with the 16x16 inverses, lane = row of the block
+    if (wave == 0) { // in-block solve with the 16x16 inverses, lane = row of the block.  The sub-block's right-hand side and solution go
+                     // through sx (LDS executes a wave's accesses in order; every lane reads them back as broadcasts): sixteen shuffles of a value
+                     // that the same loop updates were sixteen dependent LDS-crossbar round trips per sub-block and loop -- most of the span's time
       double v = sx[lane];
-      const int nsub = (jb + TS - 1) / TS;
+      const int nsub = (jb + TS - 1) / TS, g4 = lane >> 4, r16 = lane & 15;
       for (int su = 0; su < nsub; ++su) {
-        const int j = BWD ? nsub - 1 - su : su, r16 = lane & 15;
+        const int j = BWD ? nsub - 1 - su : su;
+        if (g4 == j) sx[lane] = v; // the sub-block's right-hand side, the earlier sub-blocks folded in
         // x_j = Linv_j v_j (forward) / Linv_j^T v_j (backward); sW[j][k * 16 + c] = Linv(c, k)
         double xj = 0.0;
 #pragma unroll
-        for (int k = 0; k < TS; ++k) {
-          const double vk = __shfl(v, j * TS + k, 64);
-          xj += (BWD ? sW[j][r16 * TS + k] : sW[j][k * TS + r16]) * vk;
-        }
-        if ((lane >> 4) == j) v = xj;
-        // fold x_j into the rest of the block
+        for (int k = 0; k < TS; ++k) xj += (BWD ? sW[j][r16 * TS + k] : sW[j][k * TS + r16]) * sx[j * TS + k];
+        if (g4 == j) sx[lane] = xj;
+        // fold x_j into the rest of the block: every lane forms its dot product (unconditional LDS reads: they batch behind one wait; inside a
+        // per-lane-group branch each of the sixteen was a branch, two reads and a wait of its own), the lanes it concerns subtract it
+        double fd = 0.0;
 #pragma unroll
-        for (int k = 0; k < TS; ++k) {
-          const double xk = __shfl(v, j * TS + k, 64);
-          if (BWD) { if ((lane >> 4) < j) v -= sL[j * TS + k][lane] * xk; }
-          else { if ((lane >> 4) > j) v -= sL[lane][j * TS + k] * xk; }
-        }
+        for (int k = 0; k < TS; ++k) fd += (BWD ? sL[j * TS + k][lane] : sL[lane][j * TS + k]) * sx[j * TS + k];
+        if (BWD ? g4 < j : g4 > j) v -= fd;
       }
-      sx[lane] = v;
-      if (lane < jb) x[J0 + lane] = v;
     }
     __syncthreads();
-    if (!BWD) { // rows below the block: x[r] -= L(r, J) x_J
-      for (int r = J0 + jb + tid; r < n; r += 256) {
+#pragma unroll
+    for (int p = 0; p < NB4 - 1 - bi; ++p) {
+      const int f = bi * (NB4 - 1) - bi * (bi - 1) / 2 + p;
+      const int tgt = BWD ? 64 * p + fi : (J0 - col0) + jb + 64 * p + fi; // the target row / column inside the span
+      const bool live = BWD ? col0 + 64 * p < J0 : J0 + jb + 64 * p < n;
+      if (live) {
         double acc = 0.0;
-        const TL *A = Lm + r + (int64_t)J0 * lda;
-        int k = 0;
-        for (; k + 16 <= jb; k += 16) { // sixteen loads in flight
-          TL a[16];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) a[u] = A[(int64_t)(k + u) * lda];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) acc += (double)a[u] * sx[k + u];
-        }
-        for (; k < jb; ++k) acc += (double)A[(int64_t)k * lda] * sx[k];
-        x[r] -= acc;
+        for (int u = 0; u < 16; ++u) acc += (16 * part + u < jb) ? (double)fa[f][u] * sx[16 * part + u] : 0.0;
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (part == 0 && col0 + tgt < n) sxs[tgt] -= acc;
       }
     }
-    __syncthreads();
+    __syncthreads(); // the block's folds are in LDS (the next block's right-hand side), sL / sW may be rewritten
   }
-  (void)sred;
+  if (col0 + tid < n) x[col0 + tid] = sxs[tid];
 }
-
-// rows below the span of a wide separator: forward x[r] -= L(r, span) x_span (one thread per row, deterministic);
-// backward x_span[c] -= L(rows, c)^T x[rows] for a chunk of CHOL_SOLVE_BW_ROWS rows (atomics).  grid (separators, chunks)
 template <bool BWD, class TL>
 __global__ __launch_bounds__(256) void k_solve_panel(const TL *__restrict__ base, const chol_trsv_desc *__restrict__ descs, double *__restrict__ y, int col0)
 {
@@ -2528,12 +2545,12 @@ __global__ __launch_bounds__(256) void k_solve_panel(const TL *__restrict__ base
     const int r = r0 + blockIdx.y * 256 + tid;
     const TL *A = Lm + min(r, n - 1) + (int64_t)col0 * lda;
     double acc = 0.0;
-    for (int k = 0; k < SSPAN; k += 8) {
-      double a[8];
+    for (int k = 0; k < SSPAN; k += 16) { // sixteen loads in flight per thread
+      TL a[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] = (double)A[(int64_t)(k + u) * lda];
+      for (int u = 0; u < 16; ++u) a[u] = A[(int64_t)(k + u) * lda];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc += a[u] * sx[k + u];
+      for (int u = 0; u < 16; ++u) acc += (double)a[u] * sx[k + u];
     }
     if (r < n) x[r] -= acc;
   } else {
@@ -2546,16 +2563,23 @@ __global__ __launch_bounds__(256) void k_solve_panel(const TL *__restrict__ base
       const int i = row0 + lane + 64 * u;
       xa[u] = i < n ? x[i] : 0.0;
     }
-    for (int c = wave; c < SSPAN; c += 4) {
-      const TL *Ac = Lm + (int64_t)(col0 + c) * lda;
-      double a[PER];
+    for (int c = wave; c < SSPAN; c += 16) { // four columns per round: 4 PER loads in flight per lane (one column at a time was one memory round trip per column,
+                                            // sixty-four in a row per wave)
+      TL a[4][PER];
 #pragma unroll
-      for (int u = 0; u < PER; ++u) a[u] = (double)Ac[min(row0 + lane + 64 * u, n - 1)];
-      double acc = 0.0;
+      for (int q = 0; q < 4; ++q) {
+        const TL *Ac = Lm + (int64_t)(col0 + c + 4 * q) * lda;
 #pragma unroll
-      for (int u = 0; u < PER; ++u) acc += a[u] * xa[u];
-      for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-      if (lane == 0) unsafeAtomicAdd(&x[col0 + c], -acc);
+        for (int u = 0; u < PER; ++u) a[q][u] = Ac[min(row0 + lane + 64 * u, n - 1)];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) acc += (double)a[q][u] * xa[u];
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if (lane == 0) unsafeAtomicAdd(&x[col0 + c + 4 * q], -acc);
+      }
     }
   }
 }
