@@ -516,12 +516,21 @@ __device__ __forceinline__ void update_mt_body(double *__restrict__ base, const 
       }
     }
 }
+#ifdef MT_CLOCK /* timing diagnostic of scripts/mt_bench.hip: shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) one workgroup in the middle of the grid spends on its tile */
+__device__ unsigned long long g_mt_clock[2];
+#endif
 __global__ __launch_bounds__(256) void k_update_mt(double *__restrict__ base, const chol_upd_task *__restrict__ tasks,
                                                    const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd, int64_t arena_elems)
 {
   const int tid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if ((blockIdx.x >> 3) >= per_xcd || tid >= ntask) return;
+#ifdef MT_CLOCK
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   update_mt_body<MT, MT, 2, 2>(base, tasks[tid], srcs, arena_elems);
+#ifdef MT_CLOCK
+  if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) { g_mt_clock[0] = __builtin_amdgcn_s_memtime() - clk_t0; g_mt_clock[1] = __builtin_amdgcn_s_memrealtime() - clk_r0; }
+#endif
 }
 
 // ================================================================================================

@@ -345,8 +345,14 @@ __device__ __forceinline__ void m32_chunk(f4 (&acc)[2][2], const float *sa, cons
   }
 }
 #endif
+#ifdef M32_CLOCK /* timing diagnostic of scripts/mt_bench32.hip: shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) one workgroup in the middle of the grid spends on its tile */
+__device__ unsigned long long g_m32_clock[2];
+#endif
 __global__ __launch_bounds__(256, M32_WPE) void k32_update_mt(float *__restrict__ base, const chol_upd_task *__restrict__ tasks, const chol_upd_src *__restrict__ srcs, int ntask, int per_xcd, int64_t arena_elems)
 {
+#ifdef M32_CLOCK
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   __shared__ float sA[M32_STAGES][M32_IMG];
   __shared__ float sB[M32_STAGES][M32_IMG];
   __shared__ chol_upd_src sS[M32_SRC_BATCH];
@@ -511,6 +517,9 @@ __global__ __launch_bounds__(256, M32_WPE) void k32_update_mt(float *__restrict_
     }
 #endif
 #undef M32_CHUNK
+#ifdef M32_CLOCK
+  if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) { g_m32_clock[0] = __builtin_amdgcn_s_memtime() - clk_t0; g_m32_clock[1] = __builtin_amdgcn_s_memrealtime() - clk_r0; }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -83,5 +83,9 @@ int main(int argc, char **argv)
   // a few entries against the host (row sums of X X^T)
   { std::vector<double> C((size_t)n * 4); hipMemcpy(C.data(), dC, C.size() * 8, hipMemcpyDeviceToHost); double err = 0; for (int c = 0; c < 4; c++) for (int r = c; r < n; r += 997) { double sum = 0; for (int q = 0; q < k; q++) sum += X[r + (size_t)q * n] * X[c + (size_t)q * n]; err = std::max(err, fabs(C[r + (size_t)c * n] + 5.0 * sum) / (1.0 + fabs(sum))); } printf("check (5 launches accumulate): rel err %.2e\n", err); }
   printf("TS=%d BL=%d n=%d k=%d: %zu macro tiles, %.3f ms, %.1f TF/s executed\n", TSZ, BL, n, k, tasks.size(), best, flops / best * 1e-9);
+#ifdef MT_CLOCK
+  { unsigned long long c[2]; hipMemcpyFromSymbol(c, HIP_SYMBOL(g_mt_clock), sizeof c);
+    printf("   one workgroup mid-grid: %llu shader cycles in %.2f us on its tile -> in-kernel clock %.3f GHz; %.0f cycles per 16-deep chunk\n", c[0], c[1] * 0.01, (double)c[0] / (double)c[1] * 0.1, (double)c[0] / (k / 16)); }
+#endif
   return 0;
 }

@@ -56,5 +56,9 @@ int main(int argc, char **argv)
     printf("check (5 launches accumulate): rel err %.2e, %d entries above the diagonal touched\n", err, upper);
   }
   printf("fp32 tile %d n=%d k=%d off=%d: %zu macro tiles, %.3f ms, %.1f TF/s\n", T, n, k, off, tasks.size(), best, flops / best * 1e-9);
+#ifdef M32_CLOCK
+  { unsigned long long c[2]; hipMemcpyFromSymbol(c, HIP_SYMBOL(g_m32_clock), sizeof c);
+    printf("   one workgroup mid-grid: %llu shader cycles in %.2f us on its tile -> in-kernel clock %.3f GHz; %.0f cycles per 16-deep chunk\n", c[0], c[1] * 0.01, (double)c[0] / (double)c[1] * 0.1, (double)c[0] / (k / 16)); }
+#endif
   return 0;
 }
