@@ -143,6 +143,8 @@ def load():
     L.cholamd_solve_f32.argtypes = [vp, vp, vp, vp, vp]
     L.cholamd_solve_refine.argtypes = [vp, vp, vp, vp, ci, cd, C.POINTER(ci), C.POINTER(cd), vp]
     L.cholamd_residual.argtypes = [vp, vp, vp, vp, C.POINTER(cd), vp]
+    L.cholamd_device_alloc_arena.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(C.c_int64)]
+    L.cholamd_device_free_arena.argtypes = [vp, vp]
     L.cholamd_device_set_timing.argtypes = [vp, ci]
     L.cholamd_device_get_timing.argtypes = [vp, vp, vp]
     L.cholamd_device_get_timing_ex.argtypes = [vp, vp, vp]

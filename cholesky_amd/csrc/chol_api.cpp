@@ -44,6 +44,9 @@ struct solve_dev {
 struct timed_launch { hipEvent_t a, b; int kind; };
 
 struct cholamd_device {
+  struct vmm_arena { void *va; size_t total; std::vector<hipMemGenericAllocationHandle_t> handles; };
+  std::vector<vmm_arena> vmm; // sharded arenas of this rank (cholamd_device_alloc_arena)
+
   const cholamd_plan *plan = nullptr;
   int dev = 0, rank = 0, world = 1;
   std::vector<level_dev> lv;
@@ -223,6 +226,12 @@ extern "C" void cholamd_device_destroy(cholamd_device *d)
   if (!d) return;
   (void)hipSetDevice(d->dev);
   free_levels(d);
+  for (auto &a : d->vmm) { // sharded arenas the caller did not free
+    (void)hipDeviceSynchronize();
+    (void)hipMemUnmap(a.va, a.total);
+    for (auto h : a.handles) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(a.va, a.total);
+  }
   for (auto &s : d->sv) { (void)hipFree(s.trsv); (void)hipFree(s.fw); (void)hipFree(s.bw); (void)hipFree(s.grp_start); (void)hipFree(s.grp_rows); (void)hipFree(s.bw_start); (void)hipFree(s.ifw); (void)hipFree(s.ibw); }
   (void)hipFree(d->ws32); (void)hipFree(d->csr_ptr); (void)hipFree(d->csr_col); (void)hipFree(d->csr_val); (void)hipFree(d->rvec); (void)hipFree(d->dxvec); (void)hipFree(d->partial);
   (void)hipFree(d->xstage); (void)hipFree(d->xdesc);
@@ -311,11 +320,120 @@ extern "C" int cholamd_device_sync(cholamd_device *d, void *stream)
   return 0;
 }
 
+// ---- per-rank arenas (multi-GPU) -----------------------------------------------------------------
+// The ranges of the arena a rank works on: the panels of its subtrees (one contiguous label range per tree level below the cut) and the shared
+// top (the tail).  Rank 0 -- which gathers the factor and solves -- and a single-GPU device own everything.
+static void owned_ranges(const cholamd_device *d, std::vector<std::pair<int64_t, int64_t>> &out)
+{
+  const cholamd_plan *p = d->plan;
+  out.clear();
+  if (d->world <= 1 || d->rank == 0) { out.push_back({ 0, p->arena }); return; }
+  for (int s = 1; s <= p->nsep; s++) {
+    const int o = chol_owner_of(p, s, d->world);
+    if (o >= 0 && o != d->rank) continue;
+    const int64_t lo = p->panel_off[s], hi = s < p->nsep ? p->panel_off[s + 1] : p->arena;
+    if (!out.empty() && out.back().second == lo) out.back().second = hi; else out.push_back({ lo, hi });
+  }
+}
+// zero what the rank owns (the other ranks' panels are never read on this rank; in a sharded arena they alias one scratch chunk)
+static int clear_owned(cholamd_device *d, void *arena, size_t elem, hipStream_t st)
+{
+  std::vector<std::pair<int64_t, int64_t>> r;
+  owned_ranges(d, r);
+  for (auto &x : r) HIPCHK(hipMemsetAsync((char *)arena + (size_t)x.first * elem, 0, (size_t)(x.second - x.first) * elem, st));
+  return 0;
+}
+#define CHOL_VMM_CHUNK ((size_t)2 << 20)   /* owned ranges are backed in 2 MB steps */
+#define CHOL_VMM_SCRATCH ((size_t)64 << 20) /* the chunk every range of another rank's panels aliases */
+// An arena for this rank of cholamd_plan_arena_doubles() elements of elem_bytes (8: fp64, 4: the fp32 factor) whose address range is complete --
+// every work descriptor keeps its offset -- but of which only the rank's own panels and the shared top are backed by memory of their own
+// (hipMemAddressReserve / hipMemCreate / hipMemMap): the ranges of the other ranks' panels all alias ONE 64 MB scratch chunk (this rank never
+// reads them; the fill's scatter of A and the macro-tile kernels' edge reads may touch them).  Rank 0 and single-GPU devices get a plain
+// allocation.  *backed_bytes: the device memory the arena really takes.
+extern "C" int cholamd_device_alloc_arena(cholamd_device *d, int elem_bytes, void **dptr, int64_t *backed_bytes)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  if (elem_bytes != 4 && elem_bytes != 8) { chol_set_error("alloc_arena: element size %d", elem_bytes); return CHOLAMD_ERR_ARG; }
+  const size_t full = (size_t)d->plan->arena * (size_t)elem_bytes;
+  if (d->world <= 1 || d->rank == 0) {
+    HIPCHK(hipMalloc(dptr, full > 0 ? full : 1));
+    if (backed_bytes) *backed_bytes = (int64_t)full;
+    return 0;
+  }
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = d->dev;
+  size_t gran = 0;
+  HIPCHK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+  const size_t G = gran > CHOL_VMM_CHUNK ? gran : CHOL_VMM_CHUNK, total = (full + G - 1) / G * G, scratch = (CHOL_VMM_SCRATCH + G - 1) / G * G;
+  std::vector<std::pair<int64_t, int64_t>> own;
+  owned_ranges(d, own);
+  std::vector<std::pair<size_t, size_t>> back; // owned byte ranges, widened to the chunk size, merged
+  for (auto &x : own) {
+    const size_t lo = (size_t)x.first * elem_bytes / G * G, hi = std::min(total, ((size_t)x.second * elem_bytes + G - 1) / G * G);
+    if (!back.empty() && lo <= back.back().second) back.back().second = std::max(back.back().second, hi); else back.push_back({ lo, hi });
+  }
+  cholamd_device::vmm_arena A; A.va = nullptr; A.total = total;
+  HIPCHK(hipMemAddressReserve(&A.va, total, G, nullptr, 0));
+  auto fail = [&](hipError_t e, const char *what) {
+    (void)hipMemUnmap(A.va, total);
+    for (auto h : A.handles) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(A.va, total);
+    chol_set_error("alloc_arena: %s: %s", what, hipGetErrorString(e));
+    return CHOLAMD_ERR_HIP;
+  };
+  hipMemGenericAllocationHandle_t hs;
+  hipError_t e = hipMemCreate(&hs, scratch, &prop, 0);
+  if (e != hipSuccess) { (void)hipMemAddressFree(A.va, total); chol_set_error("alloc_arena: hipMemCreate: %s", hipGetErrorString(e)); return CHOLAMD_ERR_HIP; }
+  A.handles.push_back(hs);
+  size_t backed = scratch, pos = 0;
+  auto alias = [&](size_t lo, size_t hi) { // [lo, hi) onto the scratch chunk, piece by piece
+    for (size_t o = lo; o < hi;) {
+      const size_t n = std::min(scratch, hi - o);
+      hipError_t e2 = hipMemMap((char *)A.va + o, n, 0, hs, 0);
+      if (e2 != hipSuccess) return e2;
+      o += n;
+    }
+    return hipSuccess;
+  };
+  for (auto &b : back) {
+    if ((e = alias(pos, b.first)) != hipSuccess) return fail(e, "hipMemMap (scratch)");
+    hipMemGenericAllocationHandle_t h;
+    if ((e = hipMemCreate(&h, b.second - b.first, &prop, 0)) != hipSuccess) return fail(e, "hipMemCreate");
+    A.handles.push_back(h);
+    if ((e = hipMemMap((char *)A.va + b.first, b.second - b.first, 0, h, 0)) != hipSuccess) return fail(e, "hipMemMap");
+    backed += b.second - b.first;
+    pos = b.second;
+  }
+  if ((e = alias(pos, total)) != hipSuccess) return fail(e, "hipMemMap (scratch)");
+  hipMemAccessDesc acc = {};
+  acc.location.type = hipMemLocationTypeDevice; acc.location.id = d->dev; acc.flags = hipMemAccessFlagsProtReadWrite;
+  if ((e = hipMemSetAccess(A.va, total, &acc, 1)) != hipSuccess) return fail(e, "hipMemSetAccess");
+  d->vmm.push_back(A);
+  *dptr = A.va;
+  if (backed_bytes) *backed_bytes = (int64_t)backed;
+  return 0;
+}
+extern "C" int cholamd_device_free_arena(cholamd_device *d, void *dptr)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  for (size_t i = 0; i < d->vmm.size(); i++)
+    if (d->vmm[i].va == dptr) {
+      HIPCHK(hipDeviceSynchronize());
+      (void)hipMemUnmap(dptr, d->vmm[i].total);
+      for (auto h : d->vmm[i].handles) (void)hipMemRelease(h);
+      (void)hipMemAddressFree(dptr, d->vmm[i].total);
+      d->vmm.erase(d->vmm.begin() + i);
+      return 0;
+    }
+  HIPCHK(hipFree(dptr));
+  return 0;
+}
+
 extern "C" int cholamd_device_fill(cholamd_device *d, double *d_arena, void *stream)
 {
   HIPCHK(hipSetDevice(d->dev));
   hipStream_t st = (hipStream_t)stream;
-  HIPCHK(hipMemsetAsync(d_arena, 0, (size_t)d->plan->arena * sizeof(double), st));
+  { int rc = clear_owned(d, d_arena, sizeof(double), st); if (rc) return rc; }
   // multi-GPU: the shared top of the tree (tail of the arena) starts from A on rank 0 only and from
   // zero elsewhere, so that the sum over ranks after the local levels is A_top - all contributions
   int64_t nnz = d->plan->nnz_a;
@@ -642,7 +760,7 @@ extern "C" int cholamd_device_fill_f32(cholamd_device *d, float *d_arena32, void
 {
   HIPCHK(hipSetDevice(d->dev));
   hipStream_t st = (hipStream_t)stream;
-  HIPCHK(hipMemsetAsync(d_arena32, 0, (size_t)d->plan->arena * sizeof(float), st));
+  { int rc = clear_owned(d, d_arena32, sizeof(float), st); if (rc) return rc; }
   int64_t nnz = d->plan->nnz_a;
   if (d->world > 1 && d->rank != 0) { // the shared top starts from A on rank 0 only (see cholamd_device_fill)
     const int64_t tail = d->plan->panel_off[d->plan->nsep - (d->world - 1) + 1];

@@ -17,6 +17,29 @@ def _stream_ptr(stream):
     return C.c_void_p(int(stream))
 
 
+class RankArena:
+    """A device arena owned by the library (Device.alloc_arena): data_ptr() like a tensor, numpy() = a host copy of the whole address range."""
+
+    def __init__(self, dev, ptr, elem_bytes, backed_bytes):
+        self.dev, self._ptr, self.elem_bytes, self.backed_bytes = dev, ptr, elem_bytes, backed_bytes
+        self.nbytes = dev.plan.arena_doubles * elem_bytes
+
+    def data_ptr(self):
+        return self._ptr
+
+    def numpy(self):
+        n = self.dev.plan.arena_doubles
+        out = np.empty(n, dtype=np.float64 if self.elem_bytes == 8 else np.float32)
+        words = out.nbytes // 8  # cholamd_device_download counts doubles (the fp32 arena of an even number of floats, or its last float stays behind)
+        check(self.dev.L.cholamd_device_download(self.dev.h, out.ctypes.data, C.c_void_p(self._ptr), words, None), "download")
+        return out
+
+    def free(self):
+        if self._ptr:
+            check(self.dev.L.cholamd_device_free_arena(self.dev.h, C.c_void_p(self._ptr)), "cholamd_device_free_arena")
+            self._ptr = 0
+
+
 class Device:
     KINDS = ("potrf", "trsm", "update", "other")
 
@@ -51,6 +74,13 @@ class Device:
         """A torch fp64 CUDA tensor of the arena size (caller-owned buffer, like Legion's regions)."""
         import torch
         return torch.empty(self.plan.arena_doubles, dtype=torch.float64, device=f"cuda:{self.device_id}")
+
+    def alloc_arena(self, elem_bytes=8):
+        """This rank's arena by cholamd_device_alloc_arena: complete address range, memory of its own only under the rank's panels and the shared
+        top (the other ranks' panels alias one scratch chunk); rank 0 / single GPU: a plain allocation.  Returns a RankArena."""
+        p, backed = C.c_void_p(), C.c_int64(0)
+        check(self.L.cholamd_device_alloc_arena(self.h, int(elem_bytes), C.byref(p), C.byref(backed)), "cholamd_device_alloc_arena")
+        return RankArena(self, p.value, int(elem_bytes), backed.value)
 
     @staticmethod
     def ptr(t):
@@ -225,7 +255,7 @@ def factor_multi(devs, arenas, local=True, streams=None):
     fp32 arenas (torch.float32) take the fp32 schedule (cholamd_factor_multi_f32)."""
     import torch
     L = load()
-    f32 = arenas[0].dtype == torch.float32
+    f32 = arenas[0].elem_bytes == 4 if isinstance(arenas[0], RankArena) else arenas[0].dtype == torch.float32
     n = len(devs)
     hd = (C.c_void_p * n)(*[d.h for d in devs])
     ha = (C.c_void_p * n)(*[C.c_void_p(a.data_ptr()) for a in arenas])

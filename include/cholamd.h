@@ -385,6 +385,14 @@ int cholamd_comm_adopt(void *nccl_comm /* ncclComm_t */, int world, int rank, ch
 int cholamd_comm_count(const cholamd_comm *c, int *ranks_out); /* ncclCommCount: the ranks the communicator really joins */
 void cholamd_comm_destroy(cholamd_comm *c);
 int cholamd_comm_allreduce(cholamd_comm *c, double *d_buf, int64_t count, void *stream); /* in-place fp64 sum (ncclAllReduce), asynchronous on `stream` */
+/* Per-rank arenas (multi-GPU).  An arena of cholamd_plan_arena_doubles() elements of elem_bytes (8: fp64, 4: the fp32 factor) for this rank: its
+ * address range is complete, so every entry point takes it like a plain allocation, but only the rank's own panels (the subtrees cholamd_device_set_partition
+ * gave it) and the shared top of the tree are backed by memory of their own (hipMemAddressReserve / hipMemCreate / hipMemMap); the ranges of the other
+ * ranks' panels -- never read on this rank -- all alias one 64 MB scratch chunk.  Rank 0 (it gathers the factor and solves) and single-GPU devices get a
+ * plain hipMalloc.  Call after cholamd_device_set_partition; *backed_bytes = device memory the arena takes; free with cholamd_device_free_arena (any
+ * arena of cholamd_device_alloc / _alloc_arena). */
+int cholamd_device_alloc_arena(cholamd_device *d, int elem_bytes, void **dptr, int64_t *backed_bytes);
+int cholamd_device_free_arena(cholamd_device *d, void *dptr);
 int64_t cholamd_device_tail_offset(const cholamd_device *d);    /* first double of the shared top of the tree in the arena (arena size if world == 1) */
 /* the extend-add exchange alone, asynchronous on `stream`.  Replicated top levels: in-place ncclAllReduce(sum) of d_arena[tail .. arena).
  * Top levels distributed by column blocks (option "dist_top"): OWNER-DIRECTED -- a rank works only on the column blocks it owns after the

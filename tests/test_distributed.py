@@ -306,6 +306,56 @@ def test_factor_multi_distributed_top(case, world, dist_top, wt):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case,world,dist_top,elem", [((40, 40, 40, 6, 64), 4, 1, 8), ("lapl_3375x3375", 8, 0, 8), ((30, 30, 30, 5, 32), 4, 1, 4)])
+def test_rank_arenas_back_only_their_own_panels(case, world, dist_top, elem):
+    """Per-rank arenas (cholamd_device_alloc_arena): the address range is complete, memory of its own only under the rank's panels and the shared
+    top (the other ranks' panels alias one scratch chunk).  The multi-rank factorisation over them -- local communicator, the rank objects share the
+    GPU -- equals the single-GPU factor; on a problem large enough for the 2 MB backing steps the ranks other than 0 take a fraction of the arena."""
+    import cholesky_amd as ca
+    from cholesky_amd import parallel
+    from cholesky_amd.device import factor_multi
+    plan = ca.Plan(*case_paths(case)[:3]) if isinstance(case, str) else ca.Problem(*case).plan()
+    one = ca.Device(plan, 0)
+    if elem == 8:
+        ref_t = one.new_arena()
+        one.fill(ref_t)
+        one.factor(ref_t)
+    else:
+        ref_t = one.new_arena_f32()
+        one.fill_f32(ref_t)
+        one.factor_f32(ref_t)
+    one.sync()
+    assert one.info() == (0, 0)
+    ref = ref_t.cpu().numpy()
+    del ref_t
+    tail = parallel.tail_offset(plan, world)
+    devs, arenas = [], []
+    for r in range(world):
+        dev = ca.Device(plan, 0)
+        dev.set_option("dist_top", dist_top)
+        dev.set_partition(r, world)
+        a = dev.alloc_arena(elem)
+        (dev.fill if elem == 8 else dev.fill_f32)(a)
+        devs.append(dev)
+        arenas.append(a)
+    full = plan.arena_doubles * elem
+    assert arenas[0].backed_bytes == full  # rank 0 gathers and solves: everything
+    if full > (1 << 30):
+        assert all(a.backed_bytes < 0.6 * full for a in arenas[1:])
+    factor_multi(devs, arenas, local=True)
+    for dev in devs:
+        assert dev.info() == (0, 0)
+    parts = [a.numpy() for a in arenas]
+    for r in range(1, world):
+        assert np.array_equal(parts[r][tail:], parts[0][tail:])
+    scale = max(1.0, np.abs(ref).max())
+    tol = 1e-12 if elem == 8 else 2e-5
+    assert np.abs(_assemble(plan, parts, world, ref) - ref).max() <= tol * scale
+    for a in arenas:
+        a.free()
+
+
+@pytest.mark.gpu
 def test_rccl_one_rank_allreduce_and_sharded_entry():
     """libcholamd's RCCL binding runs: unique id, ncclCommInitRank, an in-place ncclAllReduce on the stream, and
     cholamd_factor_sharded (world 1 = the plain level loop) through the communicator-taking entry point."""
