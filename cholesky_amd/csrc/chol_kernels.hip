@@ -2537,13 +2537,19 @@ __global__ __launch_bounds__(256) void k_solve_trsv(const TL *__restrict__ base,
   }
   if (col0 + tid < n) x[col0 + tid] = sxs[tid];
 }
+// rows of a wide separator under a span that one workgroup of k_solve_panel folds / gathers.  The spans of the top separators are the solve's chain and
+// at the root there is ONE separator: with 512-row chunks a span step of the 10^4-column root kept 10 CUs busy on average
+#ifndef SPANEL_BW_ROWS
+#define SPANEL_BW_ROWS 128
+#endif
+#define SPANEL_FW_ROWS 256
 template <bool BWD, class TL>
 __global__ __launch_bounds__(256) void k_solve_panel(const TL *__restrict__ base, const chol_trsv_desc *__restrict__ descs, double *__restrict__ y, int col0)
 {
   __shared__ double sx[SSPAN];
   const chol_trsv_desc d = descs[blockIdx.x];
   const int r0 = col0 + SSPAN;
-  const int rows = BWD ? CHOL_SOLVE_BW_ROWS : 256;
+  const int rows = BWD ? SPANEL_BW_ROWS : SPANEL_FW_ROWS;
   if (d.n <= r0 + (int)blockIdx.y * rows) return;
   const TL *Lm = base + d.a_off;
   double *x = y + d.x_off;
@@ -2564,25 +2570,27 @@ __global__ __launch_bounds__(256) void k_solve_panel(const TL *__restrict__ base
     if (r < n) x[r] -= acc;
   } else {
     const int lane = tid & 63, wave = tid >> 6;
-    constexpr int PER = CHOL_SOLVE_BW_ROWS / 64;
-    const int row0 = r0 + blockIdx.y * CHOL_SOLVE_BW_ROWS;
+    constexpr int PER = SPANEL_BW_ROWS / 64;
+    const int row0 = r0 + blockIdx.y * SPANEL_BW_ROWS;
     double xa[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int i = row0 + lane + 64 * u;
       xa[u] = i < n ? x[i] : 0.0;
     }
-    for (int c = wave; c < SSPAN; c += 16) { // four columns per round: 4 PER loads in flight per lane (one column at a time was one memory round trip per column,
-                                            // sixty-four in a row per wave)
-      TL a[4][PER];
+    constexpr int CPR = 32 / PER; // columns per round: 32 loads in flight per lane (one column at a time was one memory round trip per column, sixty-four
+                                  // in a row per wave)
+    static_assert(SSPAN % (4 * CPR) == 0, "columns per round");
+    for (int c = wave; c < SSPAN; c += 4 * CPR) {
+      TL a[CPR][PER];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < CPR; ++q) {
         const TL *Ac = Lm + (int64_t)(col0 + c + 4 * q) * lda;
 #pragma unroll
         for (int u = 0; u < PER; ++u) a[q][u] = Ac[min(row0 + lane + 64 * u, n - 1)];
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < CPR; ++q) {
         double acc = 0.0;
 #pragma unroll
         for (int u = 0; u < PER; ++u) acc += (double)a[q][u] * xa[u];
@@ -2692,7 +2700,7 @@ template <class TL> static int launch_solve_trsv_t(const TL *base, const chol_tr
     const int sp = backward ? nspan - 1 - i : i, col0 = sp * SSPAN;
     const int below = max_n - (col0 + SSPAN); // rows under the span in the widest separator
     if (backward) {
-      if (below > 0) hipLaunchKernelGGL((k_solve_panel<true, TL>), dim3(n, (below + CHOL_SOLVE_BW_ROWS - 1) / CHOL_SOLVE_BW_ROWS), dim3(256), 0, st, base, descs, y, col0);
+      if (below > 0) hipLaunchKernelGGL((k_solve_panel<true, TL>), dim3(n, (below + SPANEL_BW_ROWS - 1) / SPANEL_BW_ROWS), dim3(256), 0, st, base, descs, y, col0);
       hipLaunchKernelGGL((k_solve_trsv<true, TL>), dim3(n), dim3(256), 0, st, base, descs, W, y, col0);
     } else {
       hipLaunchKernelGGL((k_solve_trsv<false, TL>), dim3(n), dim3(256), 0, st, base, descs, W, y, col0);
