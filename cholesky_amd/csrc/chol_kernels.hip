@@ -1176,6 +1176,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
 
   if (wave == 0) {
     // ================================================================== factor wave
+    __builtin_amdgcn_s_setprio(3); // the block's chain runs on this wave: first at whatever it shares with the workgroup's other waves (lapl_3375: 176.2 -> 175.2 us, 4 of 4 A/B rounds)
     if (FOLLOW && fa.n_ext > 0) { // loads and barriers of the external panel steps (it owns no tile)
       d4 tdummy[RR_RSLOTS], sdummy[3];
       int idummy[RR_SLOTS];
@@ -1248,6 +1249,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       STAMPK(6);
     }
     STAMP_FLUSH;
+    __builtin_amdgcn_s_setprio(0);
   } else {
     // ================================================================== tile waves
     d4 tile[RR_RSLOTS];
