@@ -214,6 +214,38 @@ def test_fused_tasks_replay_reference_main_loop(case, ca, runs):
     assert sizes.sum() == plan.n
 
 
+def test_fused_task_refuses_a_tile_without_storage(ca, runs):
+    """A block instance of the arena above the parent block stores only the 16-row tiles a filled tile touches: a Filled record
+    that points into a tile without storage is an argument error, not a write somewhere else."""
+    import torch
+    from cholesky_amd import CholamdError
+    from cholesky_amd._lib import Filled
+    blas = ca.blas
+    plan = runs["lapl_3375x3375"]["plan"]
+    off = plan.sep_offsets
+    tree = plan.tree
+    found = None
+    for b in plan.blocks:  # a compacted block with a tile that is not stored
+        r, c = int(b[0]), int(b[1])
+        if r == c or plan.heap_of(r) == plan.heap_of(c) // 2:
+            continue
+        tm = plan.block_tile_map(r, c)
+        gone = np.nonzero(tm < 0)[0]
+        if len(gone) and (tm >= 0).any():
+            found = (r, c, int(gone[0]))
+            break
+    assert found is not None
+    r, c, t = found
+    arena = torch.zeros(plan.arena_doubles, dtype=torch.float64, device="cuda")
+    rA, rB = blas.plan_region(plan, arena.data_ptr(), c, c), blas.plan_region(plan, arena.data_ptr(), r, c)
+    n_c = int(plan.sep_sizes[c - 1])
+    fa = [Filled(0, c, c, 0, 0, int(off[c - 1]), int(off[c - 1]), int(off[c - 1]) + n_c - 1, int(off[c - 1]) + n_c - 1)]
+    lo = int(off[r - 1]) + 16 * t
+    fb = [Filled(0, r, c, 0, 0, lo, int(off[c - 1]), lo + 3, int(off[c - 1]) + n_c - 1)]
+    with pytest.raises(CholamdError, match="does not store"):
+        blas.fused_dtrsm(rA, rB, fa, fb, 0, 0)
+
+
 def _ntiles_table(case):
     """clusters[sep][interval].volume - 1 for every separator, parsed from the clusters fixture."""
     table = {}
