@@ -169,6 +169,12 @@ class Plan:
         check(self.L.cholamd_plan_level_work_volume_opts(self.h, level, int(merge_targets), int(mt_min_tiles), out.ctypes.data), "cholamd_plan_level_work_volume_opts")
         return tuple(int(v) for v in out)
 
+    def level_mt_fill(self, level):
+        """(macro-tile tasks, tasks with all 64 x 64 elements valid, valid elements x depth, tile elements x depth) of one level's lists."""
+        out = np.zeros(4, dtype=np.int64)
+        check(self.L.cholamd_plan_level_mt_fill(self.h, level, out.ctypes.data), "cholamd_plan_level_mt_fill")
+        return tuple(int(v) for v in out)
+
     def program_check(self, follow=True, workers=64):
         """Host-side self-check of the one-launch program (raises CholamdError on a dead-lock or a mismatch)."""
         check(self.L.cholamd_plan_program_check(self.h, int(follow), int(workers)), "cholamd_plan_program_check")

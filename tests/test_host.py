@@ -358,3 +358,15 @@ def test_merged_targets_cover_the_same_work_with_fewer_tasks(dims, ca):
         assert b[6] + b[7] <= a[6] + a[7] and b[8] <= a[8]   # update tasks (16x16 + macro tiles: a merged target may move from one list to the other), strips
         shorter += (a[6] + a[7] - b[6] - b[7]) + (a[8] - b[8])
     assert shorter > 0
+
+
+def test_macro_tile_fill_statistics(ca):
+    """cholamd_plan_level_mt_fill: how full the 64 x 64 macro tiles of a level's update lists are (the statistic behind option merge_targets:
+    a generated problem with 32-row cluster tiles is half empty without the merging)."""
+    plan = ca.Problem(30, 30, 30, 4, 32).plan()
+    tasks = full = valid = total = 0
+    for lvl in range(plan.levels):
+        t, f, v, w = plan.level_mt_fill(lvl)
+        assert 0 <= f <= t and 0 <= v <= w
+        tasks, full, valid, total = tasks + t, full + f, valid + v, total + w
+    assert tasks > 0 and valid / total > 0.6
