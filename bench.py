@@ -40,7 +40,10 @@ SUSTAINED_FP64_MFMA_TFLOPS = 53.5  # highest executed fp64 MFMA rate measured on
 SUSTAINED_NOTE = ("highest executed v_mfma_f64_16x16x4_f64 rate measured on this pool: the macro-tile update kernel on one 8192^2 SYRK target at K = 432 "
                   "(scripts/mt_bench.hip); register-operand loops on all 256 CUs reach 47.7-50.5 (scripts/mfma_peak.hip, scripts/mfma32_probe.hip; "
                   "profiles/r3/mfma_peak/): 68 % of `peak`; `frac` stays against `peak`")
-PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r3", "summary.json")  # scripts/profile_summary.py over the rocprofv3 passes of this command
+PROFILE_ROUND = "r4" if os.path.exists(os.path.join(ROOT, "profiles", "r4", "summary.json")) else "r3"
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", PROFILE_ROUND, "summary.json")  # scripts/profile_summary.py over the rocprofv3 passes of this command
+# the large-front regime reported beside the metric in the default single-GPU run: key -> (N, levels, tile, mixed)
+LARGE_FRONT = (("gen_60_8", (60, 8, 64, False)), ("gen_100_10", (100, 10, 64, False)), ("gen_100_10_mixed", (100, 10, 64, True)))
 
 
 def stored_rows(plan, r, c, rows):
@@ -58,7 +61,7 @@ def profile_numbers(kernel, case, mixed, options=()):
         key = case + (":mixed" if mixed else "") + ("".join(":" + o for o in sorted(options)) if options else "")
         k = runs[key]["kernels"][kernel]
         return {"hbm_bytes_per_launch": k.get("hbm_bytes_per_launch_corrected"), "avg_launch_us": k.get("avg_launch_us"),
-                "mfma_busy_frac": k.get("mfma_busy_frac"), "source": "profiles/r3/summary.json: " + runs[key].get("source", "")}
+                "mfma_busy_frac": k.get("mfma_busy_frac"), "source": f"profiles/{PROFILE_ROUND}/summary.json: " + runs[key].get("source", "")}
     except Exception:
         return {}
 
@@ -118,6 +121,74 @@ def cpu_baseline(files, flops, budget_s=12.0):
     }
 
 
+def large_front(ca, torch, stream, specs=LARGE_FRONT, steps=2, warmup=1):
+    """Measurement records (benchline.large_front_entry) of the large-front regime on this GPU: whole numeric factorisations of generated
+    N^3 Laplacians, each timed with device synchronisation on both sides on a re-filled arena, one more under the library's per-launch HIP
+    events for the dominant kernel's share; fp64: one solve, mixed: the fp64 iterative refinement of one right-hand side."""
+    from cholesky_amd import benchline
+    out, plans = {}, {}
+    for key, (gn, glv, gtile, mixed) in specs:
+        if (gn, glv, gtile) not in plans:
+            plans.clear()  # one large plan alive at a time
+            plans[(gn, glv, gtile)] = ca.Problem(gn, gn, gn, glv, gtile).plan()
+        plan = plans[(gn, glv, gtile)]
+        dev = ca.Device(plan, torch.cuda.current_device())
+        a = dev.new_arena_f32() if mixed else dev.new_arena()
+        fill, factor = (dev.fill_f32, dev.factor_f32) if mixed else (dev.fill, dev.factor)
+        step_s = []
+        for i in range(warmup + steps):
+            fill(a, stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            factor(a, stream)
+            torch.cuda.synchronize()
+            if i >= warmup:
+                step_s.append(time.perf_counter() - t0)
+        info = dev.info()
+        if info[0] != 0:
+            sys.exit(f"bench.py: large_front {key}: factorisation failed: info {info}")
+        bvec = torch.from_numpy(ca.Problem(gn, gn, gn, glv, gtile).rhs()).cuda()
+        xvec = torch.empty_like(bvec)
+        refine = solve = None
+        if mixed:
+            dev.solve_refine(a, bvec, xvec, 30, 1e-11, stream)  # warm-up (work lists, CSR upload)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            it, rel = dev.solve_refine(a, bvec, xvec, 30, 1e-11, stream)
+            torch.cuda.synchronize()
+            refine = {"corrections": it, "relres": rel, "ms": round((time.perf_counter() - t0) * 1e3, 3), "tol": 1e-11}
+        else:
+            dev.solve(a, bvec, xvec, stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dev.solve(a, bvec, xvec, stream)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3
+            r = torch.empty_like(bvec)
+            dev.residual(bvec, xvec, r, stream)
+            torch.cuda.synchronize()
+            solve = {"ms": round(ms, 3), "relres": float(r.norm() / bvec.norm())}
+        fill(a, stream)
+        dev.sync(stream)
+        dev.set_timing(1)
+        factor(a, stream)
+        dev.sync(stream)
+        timing = dev.get_timing_ex()
+        dev.set_timing(0)
+        calls, flops = plan.counts()
+        case = f"gen:{gn}:{glv}" + (f":{gtile}" if gtile != 64 else "")
+        kinds = {"potrf": float(flops[0]), "trsm": float(flops[1]), "update": float(flops[2] + flops[3])}
+        fused = timing["trsm"][1] == 0
+        dom = max(("potrf", "trsm", "update"), key=lambda k: timing[k][0])
+        out[key] = {"case": case, "mixed": mixed, "step_s": step_s, "info": list(info), "event_pair_ms": dev.event_overhead_ms(stream),
+                    "plan": {"n": plan.n, "flops": plan.flops, "alg_bytes": plan.alg_bytes, "arena_bytes": plan.arena_doubles * (4 if mixed else 8), "flops_by_kind": kinds},
+                    "timing": {k: list(v) for k, v in timing.items()}, "refinement": refine, "solve": solve,
+                    "profile": profile_numbers(benchline.kernel_names(mixed, True, fused)[dom].split(" + ")[0], case, mixed)}
+        del a, dev, bvec, xvec
+        torch.cuda.empty_cache()
+    return out
+
+
 def launch_ranks(n):
     """--gpus n without a launcher: start n fresh rank processes (torch.distributed.run, one per GPU) as children of
     this process, which has not touched the GPU, and return their exit code."""
@@ -135,7 +206,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--case", default="lapl_3375x3375",
+    ap.add_argument("--case", default=None,
                     help="a reference fixture (default: the metric's configuration) or gen:N:levels[:tile] = a generated N^3 7-point "
                          "Laplacian with geometric nested dissection (e.g. gen:100:10, BASELINE config 5's matrix; no cpu_baseline)")
     ap.add_argument("--precision", default="fp64", choices=["fp64", "mixed"],
@@ -143,9 +214,15 @@ def main():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="cholamd_device_set_option switch for this run (e.g. program=0: level-by-level launches), repeatable; recorded in config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--large-front", type=int, default=None, help="1: add the `large_front` object (60^3 fp64, 100^3 fp64 + mixed on this GPU) to the line; "
+                                                                   "default: on for the metric's own configuration (no --case / --precision / --option, one GPU), else off")
     ap.add_argument("--sustained", type=int, default=2000, help="extra figure beside the metric: the same step for this many factorisations (0 = skip)")
     ap.add_argument("--in-flight", type=int, default=4, help="extra figure (not the metric): independent factorisations kept this many at a time on device objects / streams of their own; 0 or 1 = skip")
     args = ap.parse_args()
+    if args.large_front is None:
+        args.large_front = int(args.case is None and args.gpus == 1 and args.precision == "fp64" and not args.option)
+    if args.case is None:
+        args.case = "lapl_3375x3375"
     if args.gpus < 1 or args.gpus & (args.gpus - 1):
         sys.exit("bench.py: --gpus must be a power of two (the separator tree is cut at level log2(gpus))")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -389,6 +466,10 @@ def main():
         }
         if not args.no_cpu_baseline and not generated:  # rank 0's host, at every world size
             rec["cpu_baseline"] = cpu_baseline(files, plan.flops)
+        if args.large_front and world == 1:
+            del arenas[:]
+            torch.cuda.empty_cache()
+            rec["large_front"] = large_front(ca, torch, stream)
         print(json.dumps(benchline.assemble(rec)))
     if world > 1:
         dist.barrier()

@@ -12,6 +12,8 @@ Record (`rec`, plain Python types):
   rccl_ranks (ncclCommCount of the library's communicator, None at world 1), exchange = text
   profile = profile_numbers() of the dominant kernel ({} when no committed profile matches), cpu_baseline, concurrent,
   refinement, sustained (optional dicts, passed through)
+  large_front (optional) = {key: record of large_front_entry()}: the large-front regime (generated 60^3 / 100^3 Laplacians, fp64 and
+  mixed) measured in the same run on one GPU -- the fixtures of the metric never reach a front that is "a real dense contraction"
 """
 
 PEAK_FP64_TFLOPS = 78.6    # MI355X dense fp64 (vector = matrix) peak, public spec; the microarch guide lists no fp64 row
@@ -35,6 +37,49 @@ def dominant(timing):
             if best is None or ms > best[0]:
                 best = (ms, k, r)
     return best[1], best[2]
+
+
+def large_front_entry(rec):
+    """One entry of the line's `large_front` object, from a measurement record:
+      case, mixed, steps, step_s (list: wall-clock of each timed factorisation, device-synchronised on both sides),
+      plan = {n, flops, alg_bytes, arena_bytes, flops_by_kind}, timing = {kind: [ms, launches]} of ONE factorisation (HIP events of the
+      library around each launch), event_pair_ms, info, refinement (mixed: {corrections, relres, ms}), solve (fp64: {ms, relres}),
+      profile = profile_numbers() of the dominant kernel ({} when no committed counter pass matches)
+    value = F_ref / mean step (GF/s); the dominant kernel kind's ALGORITHMIC flops (the reference's BLAS calls of that kind) over its summed
+    launch time against the dense MFMA peak of the arithmetic type."""
+    mixed = bool(rec.get("mixed"))
+    steps = [float(t) for t in rec["step_s"]]
+    if not steps or min(steps) <= 0.0:
+        raise ValueError("large_front: no timed step")
+    plan, timing = rec["plan"], rec["timing"]
+    mean_s = sum(steps) / len(steps)
+    peak = PEAK_FP32_TFLOPS if mixed else PEAK_FP64_TFLOPS
+    kinds = dict(plan["flops_by_kind"])
+    fused = timing.get("trsm", [0.0, 0])[1] == 0
+    if fused:
+        kinds["potrf"] = kinds["potrf"] + kinds["trsm"]
+    dom = max((k for k in ("potrf", "trsm", "update")), key=lambda k: timing.get(k, [0.0, 0])[0])
+    ms, n_launch = timing[dom]
+    kernel_s = max((ms - float(rec.get("event_pair_ms", 0.0)) * n_launch) * 1e-3, 1e-9)
+    achieved = kinds[dom] / kernel_s * 1e-12
+    prof = rec.get("profile") or {}
+    out = {
+        "case": rec["case"], "dtype": "f32 factor + f64 iterative refinement" if mixed else "f64", "n": plan["n"],
+        "value": round(plan["flops"] / mean_s * 1e-9, 3), "unit": "GF/s", "ms_per_step": round(mean_s * 1e3, 4), "steps": len(steps),
+        "F_ref_flops": plan["flops"], "B_alg_bytes": plan["alg_bytes"], "arena_bytes": plan.get("arena_bytes"), "factor_info": list(rec.get("info", (0, 0))),
+        "whole_step_frac_of_peak": round(plan["flops"] / mean_s * 1e-12 / peak, 5),
+        "roofline": {"bound": "mfma", "kernel": kernel_names(mixed, True, fused)[dom].split(" + ")[0], "kind": dom,
+                     "achieved": round(achieved, 4), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 5),
+                     "kernel_ms_per_step": round(kernel_s * 1e3, 4), "launches_per_step": n_launch, "alg_flops_of_kind": kinds[dom],
+                     "kernel_ms_per_step_events_raw": {k: round(timing.get(k, [0.0, 0])[0], 4) for k in KINDS},
+                     "mfma_busy_frac_rocprof": prof.get("mfma_busy_frac"), "hbm_bytes_per_launch_rocprof": prof.get("hbm_bytes_per_launch"),
+                     "avg_launch_us_rocprof": prof.get("avg_launch_us"), "profile_source": prof.get("source")},
+    }
+    if rec.get("refinement") is not None:
+        out["refinement"] = rec["refinement"]
+    if rec.get("solve") is not None:
+        out["solve"] = rec["solve"]
+    return out
 
 
 def assemble(rec):
@@ -129,4 +174,9 @@ def assemble(rec):
         out["concurrent"] = rec["concurrent"]
     if rec.get("cpu_baseline") is not None:  # rank 0's host, whatever the world size
         out["cpu_baseline"] = rec["cpu_baseline"]
+    if rec.get("large_front"):  # the large-front regime beside the metric (never in `value`)
+        out["large_front"] = {k: large_front_entry(v) for k, v in rec["large_front"].items()}
+        out["large_front"]["note"] = ("generated N^3 7-point Laplacians (cholamd_generate_laplacian: gen:N:levels), one GPU, same run: whole numeric factorisation "
+                                      "timed per step with device synchronisation on both sides, F_ref flops; `roofline` = the dominant kernel kind's algorithmic "
+                                      "flops over its summed launch time (HIP events of the library around every launch) against the dense MFMA peak")
     return out

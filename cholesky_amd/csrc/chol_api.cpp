@@ -158,8 +158,10 @@ static int build_levels(cholamd_device *d)
     // co-resident workgroups.  The list is simulated here, for every plan and option set, with FOUR resident workgroups and counters
     // raised only on job completion (stricter than the device): a program that cannot make progress that way is not used -- the
     // level-by-level lists below are.  (A GPU shared with other kernels or streams only delays jobs: every wait is bounded by ~2 s.)
-    const bool live = chol_program_check(d->plan, &d->opt, 4) == 0;
-    if (live && chol_build_program(d->plan, &d->opt, &w, &g) == 0) {
+    const bool built = chol_build_program(d->plan, &d->opt, &w, &g) == 0;
+    const bool live = built && chol_program_check_built(d->plan, &d->opt, 4, &w, &g) == 0;
+    if (built && !live) { chol_level_work_free(&w); chol_program_free(&g); }
+    if (live) {
       int rc = upload_level(d->prog, w);
       std::vector<int> tot(g.ctr_total, g.ctr_total + g.n_ctr);
       int ncu = 256;
@@ -335,9 +337,14 @@ static void owned_ranges(const cholamd_device *d, std::vector<std::pair<int64_t,
     if (!out.empty() && out.back().second == lo) out.back().second = hi; else out.push_back({ lo, hi });
   }
 }
-// zero what the rank owns (the other ranks' panels are never read on this rank; in a sharded arena they alias one scratch chunk)
+// zero what the rank owns (the other ranks' panels are never read on this rank; in a sharded arena they alias one scratch chunk).  A plain
+// allocation is cleared whole: whole-arena consumers on a rank other than 0 (writers, arena_to_dense, the debug replay) then read zeros
+// where the rank stores nothing
 static int clear_owned(cholamd_device *d, void *arena, size_t elem, hipStream_t st)
 {
+  bool sharded = false;
+  for (const auto &v : d->vmm) if (v.va == arena) sharded = true;
+  if (!sharded) { HIPCHK(hipMemsetAsync(arena, 0, (size_t)d->plan->arena * elem, st)); return 0; }
   std::vector<std::pair<int64_t, int64_t>> r;
   owned_ranges(d, r);
   for (auto &x : r) HIPCHK(hipMemsetAsync((char *)arena + (size_t)x.first * elem, 0, (size_t)(x.second - x.first) * elem, st));
@@ -405,9 +412,21 @@ extern "C" int cholamd_device_alloc_arena(cholamd_device *d, int elem_bytes, voi
     pos = b.second;
   }
   if ((e = alias(pos, total)) != hipSuccess) return fail(e, "hipMemMap (scratch)");
-  hipMemAccessDesc acc = {};
-  acc.location.type = hipMemLocationTypeDevice; acc.location.id = d->dev; acc.flags = hipMemAccessFlagsProtReadWrite;
-  if ((e = hipMemSetAccess(A.va, total, &acc, 1)) != hipSuccess) return fail(e, "hipMemSetAccess");
+  // access for the rank's own device AND for every peer that can reach it: the local communicator's ordered sum, its peer copies and
+  // the gather to rank 0 read other ranks' arenas from their owners' devices, and hipDeviceEnablePeerAccess does not cover memory
+  // mapped with hipMemMap
+  std::vector<hipMemAccessDesc> acc;
+  int ndev = 0;
+  (void)hipGetDeviceCount(&ndev);
+  for (int q = 0; q < ndev; q++) {
+    int can = q == d->dev;
+    if (!can && hipDeviceCanAccessPeer(&can, q, d->dev) != hipSuccess) can = 0;
+    if (!can) continue;
+    hipMemAccessDesc a1 = {};
+    a1.location.type = hipMemLocationTypeDevice; a1.location.id = q; a1.flags = hipMemAccessFlagsProtReadWrite;
+    acc.push_back(a1);
+  }
+  if ((e = hipMemSetAccess(A.va, total, acc.data(), acc.size())) != hipSuccess) return fail(e, "hipMemSetAccess");
   d->vmm.push_back(A);
   *dptr = A.va;
   if (backed_bytes) *backed_bytes = (int64_t)backed;
@@ -1618,7 +1637,21 @@ template <class T> __global__ void k_sum_owned(T *arena, const T *stage, const s
     arena[d.off + i] = s;
   }
 }
-template <class T> static int exchange_owned(cholamd_device *d, T *arena, const std::vector<xpiece> &px, cholamd_comm *c, hipStream_t st)
+// The rank-ordered sum of what exchange_owned() received: it must reach the stream AFTER the sends and receives, and those reach it only
+// when the OUTERMOST RCCL group ends -- a caller that groups the exchanges of several ranks (factor_multi_t) posts them all with
+// `defer_sum` and calls this once its group has ended.
+template <class T> static int exchange_owned_sum(cholamd_device *d, T *arena, const std::vector<xpiece> &px, hipStream_t st)
+{
+  int64_t mx = 0; unsigned mine = 0;
+  for (const xpiece &x : px) if (x.owner == d->rank) { mx = x.count > mx ? x.count : mx; mine++; }
+  if (!mine) return 0;
+  HIPCHK(hipSetDevice(d->dev));
+  const int64_t bx = (mx + 255) / 256;
+  hipLaunchKernelGGL(k_sum_owned<T>, dim3((unsigned)(bx < 1024 ? bx : 1024), mine), dim3(256), 0, st, arena, (const T *)d->xstage, (const sum_desc *)d->xdesc, d->world, d->rank);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+template <class T> static int exchange_owned(cholamd_device *d, T *arena, const std::vector<xpiece> &px, cholamd_comm *c, hipStream_t st, bool defer_sum)
 {
   const ncclDataType_t ty = sizeof(T) == 8 ? ncclDouble : ncclFloat;
   int64_t need = 0; std::vector<sum_desc> mine;
@@ -1649,28 +1682,28 @@ template <class T> static int exchange_owned(cholamd_device *d, T *arena, const 
     if (r != ncclSuccess) { (void)ncclGroupEnd(); chol_set_error("ncclSend/ncclRecv failed: %s", ncclGetErrorString(r)); return CHOLAMD_ERR_COMM; }
   }
   NCCLCHK(ncclGroupEnd());
-  if (!mine.empty()) {
-    int64_t mx = 0;
-    for (const sum_desc &m : mine) mx = m.count > mx ? m.count : mx;
-    const int64_t bx = (mx + 255) / 256;
-    hipLaunchKernelGGL(k_sum_owned<T>, dim3((unsigned)(bx < 1024 ? bx : 1024), (unsigned)mine.size()), dim3(256), 0, st, arena, (const T *)stage, (const sum_desc *)d->xdesc, d->world, d->rank);
-    HIPCHK(hipGetLastError());
-  }
-  return 0;
+  return defer_sum ? 0 : exchange_owned_sum<T>(d, arena, px, st);
 }
-template <class T> static int exchange_tail_t(cholamd_device *d, T *arena, const std::vector<level_dev> &lv, cholamd_comm *c, hipStream_t st)
+// defer_sum: the caller holds an RCCL group open around this call and runs exchange_sum_t() after closing it
+template <class T> static int exchange_tail_t(cholamd_device *d, T *arena, const std::vector<level_dev> &lv, cholamd_comm *c, hipStream_t st, bool defer_sum = false)
 {
   HIPCHK(hipSetDevice(d->dev));
   if (comm_matches(d, c)) return CHOLAMD_ERR_ARG;
   if (!c->comm) { chol_set_error("a local communicator exchanges through cholamd_factor_multi only"); return CHOLAMD_ERR_ARG; }
   std::vector<xpiece> px;
   exchange_pieces(d, lv, px);
-  if (!px.empty()) return exchange_owned<T>(d, arena, px, c, st);
+  if (!px.empty()) return exchange_owned<T>(d, arena, px, c, st, defer_sum);
   int64_t tail, count;
   tail_of(d, &tail, &count);
   if (count <= 0) return 0;
   NCCLCHK(ncclAllReduce(arena + tail, arena + tail, (size_t)count, sizeof(T) == 8 ? ncclDouble : ncclFloat, ncclSum, c->comm, st));
   return 0;
+}
+template <class T> static int exchange_sum_t(cholamd_device *d, T *arena, const std::vector<level_dev> &lv, hipStream_t st)
+{ // second half of exchange_tail_t(..., defer_sum = true)
+  std::vector<xpiece> px;
+  exchange_pieces(d, lv, px);
+  return px.empty() ? 0 : exchange_owned_sum<T>(d, arena, px, st);
 }
 extern "C" int cholamd_exchange_tail(cholamd_device *d, double *d_arena, cholamd_comm *c, void *stream)
 {
@@ -1838,10 +1871,12 @@ template <class T> static int factor_multi_t(cholamd_device *const *devs, T *con
   else {
     NCCLCHK(ncclGroupStart());
     for (int g = 0; g < n; g++) {
-      int rc = exchange_tail_t<T>(devs[g], arenas[g], levels_of(g), comms[g], stream_of(streams, g));
+      int rc = exchange_tail_t<T>(devs[g], arenas[g], levels_of(g), comms[g], stream_of(streams, g), true);
       if (rc) { (void)ncclGroupEnd(); return rc; }
     }
     NCCLCHK(ncclGroupEnd());
+    // the owners' sums go behind the sends and receives, which entered the streams only now (the end of the outermost group)
+    for (int g = 0; g < n; g++) { int rc = exchange_sum_t<T>(devs[g], arenas[g], levels_of(g), stream_of(streams, g)); if (rc) return rc; }
   }
   // top levels: every rank runs its phases up to its next broadcast phase; the broadcasts of all ranks form one group
   for (int lvl = split - 1; lvl >= 0; lvl--) {

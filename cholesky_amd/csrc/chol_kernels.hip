@@ -610,29 +610,49 @@ __device__ __forceinline__ double rsqrt_nr(double d)
   return fma(y, q, y);
 }
 
-// 16x16 lower Cholesky, one row per lane (row = lane & 15; the four 16-lane groups of the wave
-// compute the same thing).  a[c] = A(row, c) on entry (c <= row used), L(row, c) on exit.
-// myinv = 1 / L(row, row).  Returns the first non-positive pivot (1-based) or 0.
+// acc += m[lane K of this lane's 16-lane row] * nt: the multiplier of a column step straight out of the lane that holds it (DPP
+// row_newbcast, the one DPP form double-precision instructions take).  hipcc pads no hazards inside an asm statement: a VGPR written
+// by the VALU needs two wait states before a DPP instruction reads it as its shuffled operand -- the first use of m in a column step
+// carries them (m may have been produced by a compiler-inserted copy just ahead of the statement)
+template <int K, bool FIRST> __device__ __forceinline__ void fmac_bcast(double &acc, double m, double nt)
+{
+  if (FIRST) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "v"(nt), "n"(K));
+  else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "v"(nt), "n"(K));
+}
+// one column step of chol16_rows
+template <int J> __device__ __forceinline__ void chol16_col(double (&a)[TS], double (&dd)[TS], double &myinv, int r15, int addr)
+{
+  const double d = readlane_f64(a[J], J);
+  dd[J] = d;
+  // the unscaled column J of the tile into EVERY 16-lane row (lane l reads lane l & 15 through the LDS crossbar, no memory): the passenger
+  // rows take their multipliers from it like the tile's own rows.  Issued ahead of the rsqrt chain, which hides its round trip
+  const int mlo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(a[J])), mhi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(a[J]));
+  const double m = __hiloint2double(mhi, mlo);
+  const double rv = rsqrt_nr(d); // the same value in every lane: stays in a vector register
+  myinv = (r15 == J) ? rv : myinv;
+  a[J] = a[J] * rv; // L(row, J); row J: d / sqrt(d)
+  const double nt = -(a[J] * rv);
+#define CHOL16_FM(K_) if constexpr (K_ > J && K_ < TS) fmac_bcast<K_, K_ == J + 1>(a[K_], m, nt);
+  CHOL16_FM(1) CHOL16_FM(2) CHOL16_FM(3) CHOL16_FM(4) CHOL16_FM(5) CHOL16_FM(6) CHOL16_FM(7) CHOL16_FM(8)
+  CHOL16_FM(9) CHOL16_FM(10) CHOL16_FM(11) CHOL16_FM(12) CHOL16_FM(13) CHOL16_FM(14) CHOL16_FM(15)
+#undef CHOL16_FM
+  __builtin_amdgcn_sched_barrier(0); // one column at a time
+}
+// 16x16 lower Cholesky, one row per lane (row = lane & 15 for the tile's rows; a 16-lane group may carry other rows -- the identity, a
+// panel tile -- through the same column operations: they come out multiplied by L^-T).  a[c] = A(row, c) on entry (c <= row used),
+// L(row, c) on exit.  myinv = 1 / L(row, row).  Returns the first non-positive pivot (1-based) or 0.
+// Round 4: the column multipliers L(k, j) used to travel through scalar registers (two v_readlane per multiplier and column, 300 per tile);
+// now every 16-lane row gets the tile's column by one ds_bpermute pair per column and the multiply-adds read their multiplier from lane
+// k of their own row (DPP).  Same products, same sums, bit-identical results; scripts/chol16_bench.hip: 2396 -> 1800 ticks per tile.
 __device__ __forceinline__ int chol16_rows(double (&a)[TS], double &myinv, int r15)
 {
   myinv = 0.0;
   double dd[TS]; // the pivots (wave uniform: SGPRs)
-#pragma unroll
-  for (int j = 0; j < TS; ++j) {
-    const double d = readlane_f64(a[j], j);
-    dd[j] = d;
-    double akj[TS];
-#pragma unroll
-    for (int k = j + 1; k < TS; ++k) akj[k] = readlane_f64(a[j], k); // unscaled column j, overlaps the rsqrt chain
-    const double rv = rsqrt_nr(d);
-    const double r = readlane_f64(rv, 0); // wave uniform: keep it in SGPRs
-    myinv = (r15 == j) ? rv : myinv;
-    a[j] = a[j] * r; // L(row, j); row j: d / sqrt(d)
-    const double t = a[j] * r;
-#pragma unroll
-    for (int k = j + 1; k < TS; ++k) a[k] = fma(-t, akj[k], a[k]);
-    __builtin_amdgcn_sched_barrier(0); // bound the live range of the broadcast scalars to one column
-  }
+  const int addr = r15 << 2;
+  chol16_col<0>(a, dd, myinv, r15, addr); chol16_col<1>(a, dd, myinv, r15, addr); chol16_col<2>(a, dd, myinv, r15, addr); chol16_col<3>(a, dd, myinv, r15, addr);
+  chol16_col<4>(a, dd, myinv, r15, addr); chol16_col<5>(a, dd, myinv, r15, addr); chol16_col<6>(a, dd, myinv, r15, addr); chol16_col<7>(a, dd, myinv, r15, addr);
+  chol16_col<8>(a, dd, myinv, r15, addr); chol16_col<9>(a, dd, myinv, r15, addr); chol16_col<10>(a, dd, myinv, r15, addr); chol16_col<11>(a, dd, myinv, r15, addr);
+  chol16_col<12>(a, dd, myinv, r15, addr); chol16_col<13>(a, dd, myinv, r15, addr); chol16_col<14>(a, dd, myinv, r15, addr); chol16_col<15>(a, dd, myinv, r15, addr);
   // A pivot that is not positive (or NaN) turns its column, and through the rank-1 update every later column of every row, into
   // NaN: the LAST pivot tells whether any failed, and only then is the first one looked for (sixteen compare / select rounds
   // on the scalar unit otherwise sit on the pivot chain of every step)

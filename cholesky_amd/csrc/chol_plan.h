@@ -287,6 +287,7 @@ void chol_program_free(chol_program *prog);
 /* host-side self-check: every wait is satisfiable by the signals of jobs the queue order lets run (simulated with `workers`
  * resident workgroups), counters total up, the jobs cover the work of the per-level lists */
 int chol_program_check(const struct cholamd_plan *p, const chol_sched_opts *opts, int workers);
+int chol_program_check_built(const struct cholamd_plan *p, const chol_sched_opts *opts, int workers, const chol_level_work *w, const chol_program *g);
 int chol_build_level_work(const struct cholamd_plan *p, const chol_sched_opts *opts /* NULL: defaults */, int level, int rank, int world, chol_level_work *out);
 void chol_level_work_free(chol_level_work *w);
 int chol_owner_of(const struct cholamd_plan *p, int label, int world); /* -1: shared top of the tree */

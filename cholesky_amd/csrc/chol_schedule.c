@@ -1541,6 +1541,17 @@ int chol_program_check(const plan_t *p, const chol_sched_opts *opts, int workers
   chol_program g;
   int rc = chol_build_program(p, opts, &w, &g);
   if (rc) return rc;
+  rc = chol_program_check_built(p, opts, workers, &w, &g);
+  chol_level_work_free(&w);
+  chol_program_free(&g);
+  return rc;
+}
+/* the same on a program the caller has built (and keeps): build_levels() checks the program it is about to upload */
+int chol_program_check_built(const plan_t *p, const chol_sched_opts *opts, int workers, const chol_level_work *wp, const chol_program *gp)
+{
+  const chol_level_work w = *wp;
+  const chol_program g = *gp;
+  int rc = 0;
   int *val = calloc(g.n_ctr > 0 ? g.n_ctr : 1, sizeof(int));
   char *state = calloc(g.n_job > 0 ? g.n_job : 1, 1); /* 0 queued, 1 running, 2 done */
   int next = 0, running = 0, done = 0;
@@ -1610,8 +1621,6 @@ int chol_program_check(const plan_t *p, const chol_sched_opts *opts, int workers
     }
     free(a); free(b);
   }
-  chol_level_work_free(&w);
-  chol_program_free(&g);
   return rc;
 }
 int cholamd_plan_program_check(const cholamd_plan *p, int follow, int workers)

@@ -325,7 +325,12 @@ int chol_plan_finish(plan_t *p, int nz, const int *a_row, const int *a_col, cons
     /* symbolic update of the ancestors' blocks */
     for (int h = h0; h <= h1; h++) {
       int s = p->tree[h];
-      if (chol_ntiles(p, s, t) != 1) { chol_set_error("separator %d not a single tile when eliminated", s); return CHOLAMD_ERR_INVARIANT; }
+      if (chol_ntiles(p, s, t) != 1) {
+        chol_set_error("separator %d not a single tile when eliminated", s);
+        for (int b = 0; b < p->nblk; b++) { free(F[b].f); free(keep[b]); }
+        free(F); free(keep); free(px); free(py);
+        return CHOLAMD_ERR_INVARIANT;
+      }
       for (int hp = h / 2; hp >= 1; hp /= 2) {
         int par = p->tree[hp];
         const fillmat *Fb = &F[BIDX(p, par, s)];

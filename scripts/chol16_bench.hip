@@ -94,6 +94,52 @@ __device__ __forceinline__ void chol16_dpp_nop(double (&a)[TS])
   chol16_dpp_nop_col<12>(a); chol16_dpp_nop_col<13>(a); chol16_dpp_nop_col<14>(a); chol16_dpp_nop_col<15>(a);
 }
 
+// ---- variant D: DPP multipliers; the tile's unscaled column goes to every 16-lane row through ds_bpermute_b32 (lane l reads lane l & 15),
+//      issued ahead of the rsqrt chain that hides its round trip; the pivot's reciprocal root stays in a vector register
+__device__ __forceinline__ double bperm_row0(double v, int addr)
+{
+  const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+template <int J> __device__ __forceinline__ void chol16_bp_col(double (&a)[TS], int addr)
+{
+  const double d = readlane_f64(a[J], J);
+  const double m = bperm_row0(a[J], addr); // unscaled column J of the tile in every row; off the rsqrt chain
+  const double rv = rsqrt_nr(d);
+  a[J] = a[J] * rv;
+  const double nt = -(a[J] * rv);
+#define FM(K) if constexpr (K > J && K < TS) fmac_bcast<K, K == J + 1>(a[K], m, nt);
+  FM(1) FM(2) FM(3) FM(4) FM(5) FM(6) FM(7) FM(8) FM(9) FM(10) FM(11) FM(12) FM(13) FM(14) FM(15)
+#undef FM
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void chol16_bp(double (&a)[TS], int lane)
+{
+  const int addr = (lane & 15) << 2;
+  chol16_bp_col<0>(a, addr); chol16_bp_col<1>(a, addr); chol16_bp_col<2>(a, addr); chol16_bp_col<3>(a, addr);
+  chol16_bp_col<4>(a, addr); chol16_bp_col<5>(a, addr); chol16_bp_col<6>(a, addr); chol16_bp_col<7>(a, addr);
+  chol16_bp_col<8>(a, addr); chol16_bp_col<9>(a, addr); chol16_bp_col<10>(a, addr); chol16_bp_col<11>(a, addr);
+  chol16_bp_col<12>(a, addr); chol16_bp_col<13>(a, addr); chol16_bp_col<14>(a, addr); chol16_bp_col<15>(a, addr);
+}
+// ---- variant E: as A (readlane multipliers) with the pivot's reciprocal root kept in a vector register (no readlane of r)
+__device__ __forceinline__ void chol16_readlane_v(double (&a)[TS])
+{
+#pragma unroll
+  for (int j = 0; j < TS; ++j) {
+    const double d = readlane_f64(a[j], j);
+    double akj[TS];
+#pragma unroll
+    for (int k = j + 1; k < TS; ++k) akj[k] = readlane_f64(a[j], k);
+    const double rv = rsqrt_nr(d);
+    a[j] = a[j] * rv;
+    const double t = a[j] * rv;
+#pragma unroll
+    for (int k = j + 1; k < TS; ++k) a[k] = fma(-t, akj[k], a[k]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 template <int V> __global__ void k(const double *A, double *out, unsigned long long *t, int iters)
 {
   __shared__ double s[2 * TS][TS + 1];
@@ -106,7 +152,7 @@ template <int V> __global__ void k(const double *A, double *out, unsigned long l
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int c = 0; c < TS; ++c) a[c] = s[lane & 31][c];
-    if (V == 0) chol16_readlane(a); else if (V == 1) chol16_dpp(a); else chol16_dpp_nop(a);
+    if (V == 0) chol16_readlane(a); else if (V == 1) chol16_dpp(a); else if (V == 2) chol16_dpp_nop(a); else if (V == 3) chol16_bp(a, lane); else chol16_readlane_v(a);
     if (lane < 2 * TS) {
 #pragma unroll
       for (int c = 0; c < TS; ++c) s[lane][c] = (it + 1 < iters) ? s[lane][c] : a[c]; // keeps the loop honest; the last pass stores the result
@@ -152,26 +198,36 @@ __global__ void k_empty(const double *A, double *out, unsigned long long *t, int
 }
 int main()
 {
-  double hA[TS * TS], hO[3][2 * TS * TS];
+  double hA[TS * TS], hO[5][2 * TS * TS];
   for (int i = 0; i < TS; i++)
     for (int j = 0; j < TS; j++) hA[i * TS + j] = (i == j ? 6.0 + 0.1 * i : -1.0 / (1.0 + abs(i - j))); // row-major [row][col], SPD
   double *A, *o; unsigned long long *t, h;
   hipMalloc(&A, sizeof hA); hipMalloc(&o, sizeof hO[0]); hipMalloc(&t, 8);
   hipMemcpy(A, hA, sizeof hA, hipMemcpyHostToDevice);
   const int iters = 500;
-  double cyc[4];
-  for (int v = 0; v < 4; v++) {
+  double cyc[6];
+  for (int v = 0; v < 6; v++) {
     for (int r = 0; r < 2; r++) {
       if (v == 0) hipLaunchKernelGGL(k<0>, dim3(1), dim3(64), 0, 0, A, o, t, iters);
       else if (v == 1) hipLaunchKernelGGL(k<1>, dim3(1), dim3(64), 0, 0, A, o, t, iters);
       else if (v == 2) hipLaunchKernelGGL(k<2>, dim3(1), dim3(64), 0, 0, A, o, t, iters);
+      else if (v == 3) hipLaunchKernelGGL(k<3>, dim3(1), dim3(64), 0, 0, A, o, t, iters);
+      else if (v == 4) hipLaunchKernelGGL(k<4>, dim3(1), dim3(64), 0, 0, A, o, t, iters);
       else hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, 0, A, o, t, iters);
       hipDeviceSynchronize();
     }
     hipMemcpy(&h, t, 8, hipMemcpyDeviceToHost);
-    if (v < 3) hipMemcpy(hO[v], o, sizeof hO[0], hipMemcpyDeviceToHost);
+    if (v < 5) hipMemcpy(hO[v], o, sizeof hO[0], hipMemcpyDeviceToHost);
     cyc[v] = (double)h / iters;
   }
+  { double dLd = 0, dId = 0, dLe = 0, dIe = 0;
+    for (int r = 0; r < TS; r++) for (int c = 0; c < TS; c++) {
+      if (c <= r) { dLd = fmax(dLd, fabs(hO[0][r * TS + c] - hO[3][r * TS + c])); dLe = fmax(dLe, fabs(hO[0][r * TS + c] - hO[4][r * TS + c])); }
+      if (c >= r) { dId = fmax(dId, fabs(hO[0][(TS + r) * TS + c] - hO[3][(TS + r) * TS + c])); dIe = fmax(dIe, fabs(hO[0][(TS + r) * TS + c] - hO[4][(TS + r) * TS + c])); }
+    }
+    printf("ticks per tile (loop overhead %.0f subtracted): dpp + bpermute mirror %.0f (max |dL| %.1e, |dLinv| %.1e), readlane with vector r %.0f (max |dL| %.1e, |dLinv| %.1e)\n",
+           cyc[5], cyc[3] - cyc[5], dLd, dId, cyc[4] - cyc[5], dLe, dIe);
+    cyc[3] = cyc[5]; }
   double dL = 0, dI = 0, dLc = 0;
   for (int r = 0; r < TS; r++)
     for (int c = 0; c < TS; c++) {
