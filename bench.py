@@ -265,6 +265,12 @@ def main():
     for kv in args.option:
         k, v = kv.split("=")
         dev.set_option(k, int(v))
+    if os.environ.get("CHOLAMD_SAVE_MAPS"):  # profiled runs (scripts/gpu_batch.sh): the address map of this process, so that the frames of a crash
+        try:                                  # under the profiler can be attributed to a library afterwards (profiles/r4/README.md, the rc=139 of round 3)
+            with open("/proc/self/maps") as src, open(os.environ["CHOLAMD_SAVE_MAPS"], "w") as dst:
+                dst.write(src.read())
+        except OSError:
+            pass
     split = parallel.split_level(world)
     tail_off = parallel.tail_offset(plan, world)  # first panel of the shared top of the tree
     comm = None

@@ -581,6 +581,24 @@ __device__ unsigned long long g_walk[12][20][8]; // [wave][step][point]: absolut
 #define STAMP_FLUSH2
 #endif
 
+// -DCHOL_POLLS (scripts/stamp_potrf.hip): counts instead of clock stamps -- how often the factor wave found its look-ahead tiles late and how
+// many polls that cost, how often it waited for the tile waves' counter; no s_memtime round trips, so the waves keep their pace
+#ifdef CHOL_POLLS
+__device__ unsigned long long g_polls[8];
+#define POLL_DECL unsigned long long pc_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
+#define POLL_ADD(i, v) pc_[i] += (v)
+#define POLL_FLUSH do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) g_polls[i_] = pc_[i_]; } while (0)
+__device__ unsigned long long g_wpolls[12][8]; // tile waves: poll iterations (a 64-cycle sleep + an LDS round trip each) at fL, cRaw, the step's barrier, fP
+#define POLL_WAIT(i, flag, target) do { while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < (target)) { pc_[i] += 1; __builtin_amdgcn_s_sleep(1); } asm volatile("" ::: "memory"); } while (0)
+#define POLL_WFLUSH do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) g_wpolls[wave][i_] = pc_[i_]; } while (0)
+#else
+#define POLL_WAIT(i, flag, target) lds_wait_ge(flag, target)
+#define POLL_WFLUSH
+#define POLL_DECL
+#define POLL_ADD(i, v)
+#define POLL_FLUSH
+#endif
+
 __device__ __forceinline__ double readlane_f64(double v, int l)
 {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
@@ -644,15 +662,26 @@ template <int J> __device__ __forceinline__ void chol16_col(double (&a)[TS], dou
 // Round 4: the column multipliers L(k, j) used to travel through scalar registers (two v_readlane per multiplier and column, 300 per tile);
 // now every 16-lane row gets the tile's column by one ds_bpermute pair per column and the multiply-adds read their multiplier from lane
 // k of their own row (DPP).  Same products, same sums, bit-identical results; scripts/chol16_bench.hip: 2396 -> 1800 ticks per tile.
-__device__ __forceinline__ int chol16_rows(double (&a)[TS], double &myinv, int r15)
+// `mid` runs ahead of column CHOL16_HOOK_COL: the caller's LDS reads issued there complete under the rest of the factorisation.
+#ifndef CHOL16_HOOK_COL
+#define CHOL16_HOOK_COL 14
+#endif
+struct chol16_no_hook { __device__ __forceinline__ void operator()() const {} };
+template <int J, class H> __device__ __forceinline__ void chol16_col_h(double (&a)[TS], double (&dd)[TS], double &myinv, int r15, int addr, H &mid)
+{
+  if constexpr (J == CHOL16_HOOK_COL) { mid(); __builtin_amdgcn_sched_barrier(0); }
+  chol16_col<J>(a, dd, myinv, r15, addr);
+}
+template <class H = chol16_no_hook>
+__device__ __forceinline__ int chol16_rows(double (&a)[TS], double &myinv, int r15, H &&mid = H())
 {
   myinv = 0.0;
   double dd[TS]; // the pivots (wave uniform: SGPRs)
   const int addr = r15 << 2;
-  chol16_col<0>(a, dd, myinv, r15, addr); chol16_col<1>(a, dd, myinv, r15, addr); chol16_col<2>(a, dd, myinv, r15, addr); chol16_col<3>(a, dd, myinv, r15, addr);
-  chol16_col<4>(a, dd, myinv, r15, addr); chol16_col<5>(a, dd, myinv, r15, addr); chol16_col<6>(a, dd, myinv, r15, addr); chol16_col<7>(a, dd, myinv, r15, addr);
-  chol16_col<8>(a, dd, myinv, r15, addr); chol16_col<9>(a, dd, myinv, r15, addr); chol16_col<10>(a, dd, myinv, r15, addr); chol16_col<11>(a, dd, myinv, r15, addr);
-  chol16_col<12>(a, dd, myinv, r15, addr); chol16_col<13>(a, dd, myinv, r15, addr); chol16_col<14>(a, dd, myinv, r15, addr); chol16_col<15>(a, dd, myinv, r15, addr);
+  chol16_col_h<0>(a, dd, myinv, r15, addr, mid); chol16_col_h<1>(a, dd, myinv, r15, addr, mid); chol16_col_h<2>(a, dd, myinv, r15, addr, mid); chol16_col_h<3>(a, dd, myinv, r15, addr, mid);
+  chol16_col_h<4>(a, dd, myinv, r15, addr, mid); chol16_col_h<5>(a, dd, myinv, r15, addr, mid); chol16_col_h<6>(a, dd, myinv, r15, addr, mid); chol16_col_h<7>(a, dd, myinv, r15, addr, mid);
+  chol16_col_h<8>(a, dd, myinv, r15, addr, mid); chol16_col_h<9>(a, dd, myinv, r15, addr, mid); chol16_col_h<10>(a, dd, myinv, r15, addr, mid); chol16_col_h<11>(a, dd, myinv, r15, addr, mid);
+  chol16_col_h<12>(a, dd, myinv, r15, addr, mid); chol16_col_h<13>(a, dd, myinv, r15, addr, mid); chol16_col_h<14>(a, dd, myinv, r15, addr, mid); chol16_col_h<15>(a, dd, myinv, r15, addr, mid);
   // A pivot that is not positive (or NaN) turns its column, and through the rank-1 update every later column of every row, into
   // NaN: the LAST pivot tells whether any failed, and only then is the first one looked for (sixteen compare / select rounds
   // on the scalar unit otherwise sit on the pivot chain of every step)
@@ -844,7 +873,7 @@ __device__ __forceinline__ void tile_of_index(int idx, int T, int &ti, int &tj)
 #define RR_OFF_SOL (RR_MAXT * TS * TS)
 #define RR_OFF_DG (RR_OFF_SOL + 2 * RR_MAXT * TS * TS)
 #define RR_OFF_LW (RR_OFF_DG + 2 * TS * TS)
-#define RR_OFF_CONV (RR_OFF_LW + 2 * 2 * TS * (TS + 1))
+#define RR_OFF_CONV (RR_OFF_LW + 2 * 4 * TS * (TS + 1))
 #define RR_OFF_OV (RR_OFF_CONV + 2 * TS * (TS + 1))
 #define RR_OFF_IJ (RR_OFF_OV + RR_NHEAVY * TS * TS)
 #define RR_OFF_FLAG (RR_OFF_IJ + (RR_SLOTS * RR_NW + 16 + 3) / 4)
@@ -1132,7 +1161,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
   double (*const sRaw)[TS * TS] = (double (*)[TS * TS])(smem);                         // [RR_MAXT] raw (fully updated, unsolved) tiles of the next panel column
   double (*const sSol)[RR_MAXT][TS * TS] = (double (*)[RR_MAXT][TS * TS])(smem + RR_OFF_SOL); // [2] solved panel P of step k (parity of k)
   double (*const sDg)[TS * TS] = (double (*)[TS * TS])(smem + RR_OFF_DG);              // [2] diagonal tiles on their way to the factor wave (parity of j)
-  double (*const sLW)[2 * TS][TS + 1] = (double (*)[2 * TS][TS + 1])(smem + RR_OFF_LW); // [2] parity of k: rows 0-15 = L(k,k) [r][c], rows 16-31 = L(k,k)^-T [k][c] = Linv(c,k)
+  double (*const sLW)[4 * TS][TS + 1] = (double (*)[4 * TS][TS + 1])(smem + RR_OFF_LW); // [2] parity of k, one row per lane of the factor wave: rows 0-15 = L(k,k) [r][c], rows 16-31 = L(k,k)^-T [k][c] = Linv(c,k) (32-63: the duplicates lanes 32-63 carry; written so that the publication needs no exec mask)
   double (*const sConv)[TS + 1] = (double (*)[TS + 1])(smem + RR_OFF_CONV);            // [2 TS] factor wave: accumulator layout -> row per lane; rows 16-31 = identity
   double (*const sOv)[TS * TS] = (double (*)[TS * TS])(smem + RR_OFF_OV);              // [RR_NHEAVY] slot RR_RSLOTS of the heavy waves
   unsigned short *const sIJ = (unsigned short *)(smem + RR_OFF_IJ);                    // [RR_SLOTS * RR_NW + 16]
@@ -1206,11 +1235,11 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
     }
     __builtin_amdgcn_s_setprio(3);
     lds_wait_ge(cUpd, RR_NW); // prologue of the tile waves done: (0,0), (1,1) are in sDg, column 0 in sRaw
-    int cupd_seen = RR_NW; // last value of cUpd read
     d4 dk; // diagonal tile of the current step, accumulator layout
 #pragma unroll
     for (int q = 0; q < 4; ++q) dk[q] = sDg[0][q * 64 + lp0];
     STAMP_DECL;
+    POLL_DECL;
     for (int k = 0; k < T; ++k) {
       STAMPK(0);
       // ---- a. factor (k,k), one row per lane.  Lanes 16-31 carry the rows of the identity through the same
@@ -1221,54 +1250,64 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       for (int q = 0; q < 4; ++q) sConv[r15][g + 4 * q] = dk[q];
 #pragma unroll
       for (int c = 0; c < TS; ++c) a[c] = sConv[lane & 31][c];
+      // sLW / sSol of this step's parity were last read in step k-2: every tile wave must have left it before they are written again.
+      // The counter is read here, with the rows (by the end of the Cholesky it is a step old, and it is monotonic): a wait after the
+      // Cholesky only where this value does not say so yet
+      const int cupd_early = __hip_atomic_load(cUpd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       STAMPK(1);
       if (TR && fa.xstamp && lane == 0 && k < 24) fa.xstamp[72 + k] = __builtin_amdgcn_s_memrealtime(); // diagnostic build: the factor wave starts column k
-      const int bad = chol16_rows(a, unused, r15);
+      // ---- b. the two look-ahead tiles of step k-1's trailing update -- (k+1,k) raw and (k+1,k+1) -- reach LDS while this step's
+      //         Cholesky runs (their owners do them first): they are requested HALF WAY through it, the flag pair ahead of the tiles in
+      //         the same batch of LDS reads (LDS executes a wave's accesses in order), so that their round trip is over when the
+      //         Cholesky ends; only a flag that was not up yet at that point costs a poll and a second read of the tiles
+      const bool more = k + 1 < T;
+      const int kn = more ? k + 1 : k;
+      long long fl = 0;
+      d4 raw, dn;
+      const int bad = chol16_rows(a, unused, r15, [&]() {
+        fl = __hip_atomic_load((long long *)fA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // fA and fD: one 64-bit word
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { raw[q] = sRaw[kn][q * 64 + lp0]; dn[q] = sDg[kn & 1][q * 64 + lp0]; }
+      });
       STAMPK(2);
       if (bad && k * TS + bad <= n && lane == 0) {
         if (atomicCAS(&info[0], 0, d.col0 + k * TS + bad) == 0) info[1] = d.sep;
       }
       const int par = k & 1;
-      // sLW / sSol of this parity were last read in step k-2: every tile wave has left it (usually known from
-      // the value read a step ago: the counter is monotonic)
-      if (cupd_seen < RR_NW * k) cupd_seen = lds_wait_ge_v(cUpd, RR_NW * k);
-      if (lane < 2 * TS) {
+      if (__builtin_amdgcn_readfirstlane(cupd_early) < RR_NW * k) { POLL_ADD(2, 1); lds_wait_ge(cUpd, RR_NW * k); }
+      // ---- c. publish L(k,k) and L(k,k)^-T (every lane writes its row: no exec mask) and, in the same batch, read the inverse back as
+      //         the MFMA operand of the look-ahead solve: one LDS round trip for both
 #pragma unroll
-        for (int c = 0; c < TS; ++c) sLW[par][lane][c] = a[c]; // L: entries above the diagonal are finite junk nobody uses
-      }
-      lds_set(fL, k + 1, lane);
-      STAMPK(3);
-      if (k + 1 >= T) break;
-      // ---- b. the two look-ahead tiles of step k-1's trailing update are in LDS (their owners do them first; by now they
-      //         have been for a while): the flag pair is read ahead of the tiles in the same batch of LDS reads (LDS executes a
-      //         wave's accesses in order), and only a flag that was not up yet costs a poll and a second read of the tiles
-      const long long fl = __hip_atomic_load((long long *)fA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // fA and fD: one 64-bit word
-      asm volatile("" ::: "memory");
-      d4 raw, dn;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { raw[q] = sRaw[k + 1][q * 64 + lp0]; dn[q] = sDg[(k + 1) & 1][q * 64 + lp0]; }
-      // ---- c. solve (k+1, k) and publish it
+      for (int c = 0; c < TS; ++c) sLW[par][lane][c] = a[c]; // L: entries above the diagonal are finite junk nobody uses
       double wv[4];
 #pragma unroll
       for (int st = 0; st < 4; ++st) wv[st] = sLW[par][TS + 4 * st + g][r15];
+      lds_set(fL, k + 1, lane);
+      STAMPK(3);
+      if (!more) break;
       if (__builtin_amdgcn_readfirstlane((int)fl) < k + 1 || __builtin_amdgcn_readfirstlane((int)(fl >> 32)) < k + 1) {
+        POLL_ADD(0, 1);
         lds_wait_both_ge(fA, k + 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) { raw[q] = sRaw[k + 1][q * 64 + lp0]; dn[q] = sDg[(k + 1) & 1][q * 64 + lp0]; }
       }
       STAMPK(4);
+      // ---- d. solve (k+1, k); the tile goes to LDS for the tile waves, and -- the writes in flight -- into the diagonal tile
+      //         (k+1,k+1) -= P P^T (both operands are the accumulator registers of P); fP once the writes have landed
       const d4 p = solve16(raw, wv);
 #pragma unroll
       for (int q = 0; q < 4; ++q) sSol[par][k + 1][q * 64 + lp0] = p[q];
-      lds_set(fP, k + 1, lane);
-      STAMPK(5);
-      // ---- d. (k+1,k+1) -= P P^T: both operands are the accumulator registers of P
 #pragma unroll
       for (int st = 0; st < 4; ++st) dn = __builtin_amdgcn_mfma_f64_16x16x4f64(p[st], -p[st], dn, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0); // the MFMAs are issued before the wait inside lds_set (it is no memory operation: the scheduler would sink them below it)
+      lds_set(fP, k + 1, lane);
+      STAMPK(5);
       dk = dn;
       STAMPK(6);
     }
     STAMP_FLUSH;
+    POLL_FLUSH;
     __builtin_amdgcn_s_setprio(0);
   } else {
     // ================================================================== tile waves
@@ -1345,6 +1384,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
     lds_inc(cUpd, lane);
     PSTAMP(4); // columns 0 and 1 parked
     STAMP_DECL;
+    POLL_DECL;
     for (int k = 0; k < T; ++k) {
       STAMPK(0);
       int lp = lp0; // opaque once per step: keeps per-slot LDS addresses from being hoisted and spilled
@@ -1354,9 +1394,9 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       const int par = k & 1;
       const int mk = __builtin_amdgcn_readfirstlane(sMask[k * RR_NW + w]); // what this wave does in the step (arrives with the first poll)
       // ---- 1. panel solve out of LDS (needs L(k,k) and every raw tile of column k)
-      lds_wait_ge(fL, k + 1);
+      POLL_WAIT(0, fL, k + 1);
       STAMPK(1);
-      lds_wait_ge(cRaw, (k + 1) * (T - 1) - k * (k + 1) / 2);
+      POLL_WAIT(1, cRaw, (k + 1) * (T - 1) - k * (k + 1) / 2);
       STAMPK(2);
       if (mk & ((1 << RR_M_SOLVE0) | (1 << RR_M_SOLVE1))) {
         // panel tile i goes to heavy wave i mod 9 (at most two each: T <= 17); the light waves keep the
@@ -1402,9 +1442,9 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       // ---- 2. the whole panel is solved
       STAMPK(3);
       lds_inc(cSol, lane);
-      lds_wait_ge(cSol, RR_NW * (k + 1));
+      POLL_WAIT(2, cSol, RR_NW * (k + 1));
       STAMPK(4);
-      if (k + 1 < T) lds_wait_ge(fP, k + 1);
+      if (k + 1 < T) POLL_WAIT(3, fP, k + 1);
       STAMPK(5);
       // ---- 3. trailing update of the live slots [0, top], walked downwards: column k+1 first
       const double *const sS = &sSol[par][0][0];
@@ -1506,6 +1546,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       }
     }
     if (w == STAMP_WAVE) { STAMP_FLUSH2; }
+    POLL_WFLUSH;
   }
 }
 

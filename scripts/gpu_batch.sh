@@ -43,6 +43,7 @@ profiles) # every rocprofv3 pass behind profiles/rN/summary.json: key | bench ar
           [ -z "$key" ] && continue
           [ -n "$PROFILE_KEYS" ] && ! echo " $PROFILE_KEYS " | grep -q " $key " && continue
           d=$out/$key; mkdir -p $d
+          export CHOLAMD_SAVE_MAPS=$d/proc_maps.txt   # bench.py writes /proc/self/maps there: a crash under the profiler can be attributed to a library
           (cd /tmp && run stats_$key 500 rocprofv3 --kernel-trace --stats --output-format csv -d $d/stats -o s -- python3 $GRAFT_REPO_ROOT/bench.py $bargs --steps $nsteps --warmup 2 --no-cpu-baseline --sustained 0 > $d/bench_under_rocprof.json 2> $d/stats.err) || tail -3 $d/stats.err
           (cd /tmp && run pmc_$key 500 rocprofv3 --kernel-trace --pmc $SQ $mops GRBM_GUI_ACTIVE --output-format csv -d $d/pmc_SQ -o p -- python3 $GRAFT_REPO_ROOT/bench.py $bargs --steps $nsteps --warmup 2 --no-cpu-baseline --sustained 0 > $d/pmc_SQ.json 2> $d/pmc_SQ.err) || tail -3 $d/pmc_SQ.err
           if [ "$traffic" = "1" ]; then for c in FETCH_SIZE WRITE_SIZE; do
@@ -55,8 +56,8 @@ lapl_3375_levels|--case lapl_3375x3375 --option program=0 --in-flight 0|20|SQ_IN
 gen_40_6|--case gen:40:6|5|SQ_INSTS_VALU_MFMA_MOPS_F64|0
 gen_60_8|--case gen:60:8|3|SQ_INSTS_VALU_MFMA_MOPS_F64|1
 gen_60_8_mixed|--case gen:60:8 --precision mixed|3|SQ_INSTS_VALU_MFMA_MOPS_F32|0
-gen_100_10_mixed|--case gen:100:10 --precision mixed|2|SQ_INSTS_VALU_MFMA_MOPS_F32|0
-gen_100_10|--case gen:100:10|2|SQ_INSTS_VALU_MFMA_MOPS_F64|0
+gen_100_10_mixed|--case gen:100:10 --precision mixed|2|SQ_INSTS_VALU_MFMA_MOPS_F32|1
+gen_100_10|--case gen:100:10|2|SQ_INSTS_VALU_MFMA_MOPS_F64|1
 LIST
         ;;
 super)  for sb in 1 2 3 4; do for c in gen:40:6 gen:60:8; do

@@ -38,6 +38,16 @@ int main(int argc, char **argv)
     double err = 0; for (int j = 0; j < n; j++) for (int i = j; i < n; i++) err = fmax(err, fabs(L[i + (size_t)j * n] - G[i + (size_t)j * n]));
     printf("n=%d band=%d: %.2f us (best of 6, one workgroup, events), max |L - L_host| = %.2e\n", n, band, best * 1e3, err);
   }
+#ifdef CHOL_POLLS
+  { unsigned long long pc[8];
+    hipMemcpyFromSymbol(pc, HIP_SYMBOL(g_polls), sizeof pc);
+    unsigned long long wp[12][8];
+    hipMemcpyFromSymbol(wp, HIP_SYMBOL(g_wpolls), sizeof wp);
+    printf("tile waves, poll iterations over the block (fL / cRaw / barrier / fP):");
+    for (int w = 1; w < 12; w++) printf(" w%d %llu/%llu/%llu/%llu", w - 1, wp[w][0], wp[w][1], wp[w][2], wp[w][3]);
+    printf("\n");
+    printf("n=%d steps=%d: look-ahead tiles late in %llu steps (%llu polls of ~64 cycles + an LDS round trip each); waited for the tile waves' counter in %llu steps (%llu polls)\n", n, (n + 15) / 16, pc[0], pc[1], pc[2], pc[3]); }
+#endif
 #ifdef CHOL_STAMPS
   unsigned long long st[16];
   hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof st);

@@ -58,3 +58,46 @@ def test_rank_count_must_match():
     rec["timing"] = rec["timing"][:1]
     with pytest.raises(ValueError):
         benchline.assemble(rec)
+
+
+def lf_record(mixed):
+    # one factorisation's event times: the macro-tile update kernel carries the step
+    timing = {"potrf": [12.0, 40], "trsm": [9.0, 30], "update": [400.0, 41], "other": [0.0, 0], "exchange": [0.0, 0], "bcast": [0.0, 0]}
+    rec = {"case": "gen:100:10", "mixed": mixed, "step_s": [0.48, 0.47], "info": [0, 0], "event_pair_ms": 0.005,
+           "plan": {"n": 1000000, "flops": 2.0e13, "alg_bytes": 8.1e10, "arena_bytes": 3.3e10 if not mixed else 1.65e10,
+                    "flops_by_kind": {"potrf": 1.0e11, "trsm": 9.0e11, "update": 1.9e13}},
+           "timing": timing, "profile": {"mfma_busy_frac": 0.61, "hbm_bytes_per_launch": 2.4e9, "avg_launch_us": 9800.0, "source": "profiles/r4/summary.json: x"}}
+    if mixed:
+        rec["refinement"] = {"corrections": 3, "relres": 1.3e-13, "ms": 64.0, "tol": 1e-11}
+    else:
+        rec["solve"] = {"ms": 22.0, "relres": 3e-15}
+    return rec
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_large_front_entry(mixed):
+    e = benchline.large_front_entry(lf_record(mixed))
+    json.dumps(e)
+    assert e["value"] == pytest.approx(2.0e13 / 0.475 * 1e-9, rel=1e-6) and e["unit"] == "GF/s" and e["ms_per_step"] == pytest.approx(475.0)
+    rf = e["roofline"]
+    assert rf["kernel"] == ("k32_update_mt" if mixed else "k_update_mt") and rf["kind"] == "update"
+    assert rf["peak"] == (157.3 if mixed else 78.6)
+    # the update kind's algorithmic flops over its summed launch time (event-pair reading taken off every launch)
+    assert rf["achieved"] == pytest.approx(1.9e13 / ((400.0 - 41 * 0.005) * 1e-3) * 1e-12, rel=1e-3)
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3)
+    assert rf["mfma_busy_frac_rocprof"] == 0.61 and rf["hbm_bytes_per_launch_rocprof"] == 2.4e9
+    assert ("refinement" in e) == mixed and ("solve" in e) == (not mixed)
+    with pytest.raises(ValueError):
+        benchline.large_front_entry(dict(lf_record(mixed), step_s=[]))
+
+
+def test_line_carries_large_front():
+    rec = record(1, program=True)
+    rec["large_front"] = {"gen_100_10": lf_record(False), "gen_100_10_mixed": lf_record(True)}
+    out = benchline.assemble(rec)
+    json.dumps(out)
+    lf = out["large_front"]
+    assert set(lf) == {"gen_100_10", "gen_100_10_mixed", "note"}
+    assert lf["gen_100_10"]["dtype"] == "f64" and lf["gen_100_10_mixed"]["refinement"]["relres"] < 1e-10
+    assert out["value"] == pytest.approx(1.48552e8 / 2.1e-4 * 1e-9, rel=1e-6)  # the metric is untouched
+    assert "large_front" not in benchline.assemble(record(1, program=True))
