@@ -122,12 +122,28 @@ static void free_levels(cholamd_device *d)
   d->jobs = nullptr; d->pwaits = nullptr; d->exts = nullptr; d->pctr = nullptr; d->pctr_total = nullptr;
   d->prog_ready = false;
 }
-static int upload_level(level_dev &l, const chol_level_work &w)
+static int upload_level(level_dev &l, const chol_level_work &w, bool with_tables = true)
 {
   l.n_potrf = w.n_potrf; l.n_trsm = w.n_trsm; l.n_task = w.n_task; l.n_src = w.n_src;
   l.phase.assign(w.phase, w.phase + w.n_phase);
   l.bcast.assign(w.bcast, w.bcast + w.n_bcast);
-  int rc = upload_vec(&l.potrf, w.potrf, (size_t)w.n_potrf);
+  // the POTRF descriptors travel with their role tables (chol_potrf_table) behind them in one buffer: desc.tab = byte offset from the descriptor itself
+  int rc = 0;
+  if (w.n_potrf > 0 && with_tables && !std::getenv("CHOLAMD_NO_ROLE_TABLES")) { // the switch: A/B and the parity test against the in-kernel construction
+    const size_t dbytes = ((size_t)w.n_potrf * sizeof(chol_potrf_desc) + 15) / 16 * 16;
+    std::vector<unsigned char> buf(dbytes + (size_t)w.n_potrf * CHOL_RR_TAB_BYTES);
+    for (int i = 0; i < w.n_potrf; i++) {
+      chol_potrf_desc pd = w.potrf[i];
+      if (pd.n <= CHOL_RR_MAXN) {
+        const size_t at = dbytes + (size_t)i * CHOL_RR_TAB_BYTES;
+        pd.tab = (int)(at - (size_t)i * sizeof(chol_potrf_desc)); // relative to the descriptor itself: launches take sub-ranges of the array
+        chol_potrf_table(pd.n, pd.sky, buf.data() + at);
+      }
+      std::memcpy(buf.data() + (size_t)i * sizeof(chol_potrf_desc), &pd, sizeof pd);
+    }
+    HIPCHK(hipMalloc((void **)&l.potrf, buf.size()));
+    HIPCHK(hipMemcpy(l.potrf, buf.data(), buf.size(), hipMemcpyHostToDevice));
+  } else rc = upload_vec(&l.potrf, w.potrf, (size_t)w.n_potrf);
   if (!rc) rc = upload_vec(&l.trsm, w.trsm, (size_t)w.n_trsm);
   if (!rc) rc = upload_vec(&l.task, w.task, (size_t)w.n_task);
   if (!rc) rc = upload_vec(&l.task_mt, w.task_mt, (size_t)w.n_task_mt);
@@ -768,7 +784,7 @@ static int ensure_f32(cholamd_device *d)
   for (int lvl = 0; lvl < L; lvl++) {
     chol_level_work w;
     int rc = chol_build_level_work(d->plan, &o, lvl, d->rank, d->world, &w);
-    if (!rc) rc = upload_level(d->lv32[lvl], w);
+    if (!rc) rc = upload_level(d->lv32[lvl], w, false); // the fp32 kernels have no role tables
     chol_level_work_free(&w);
     if (rc) { for (auto &l : d->lv32) free_level(l); d->lv32.clear(); return rc; }
   }

@@ -555,8 +555,8 @@ __global__ __launch_bounds__(256) void k_update_mt(double *__restrict__ base, co
 // first, so the factor wave works on step k+1 while the tile waves finish the updates of step k.
 // ================================================================================================
 #define TS 16
-#define RR_MAXT 17
-#define RR_NHEAVY 9  /* tile waves that do not share a SIMD with the factor wave */
+#define RR_MAXT CHOL_RR_MAXT
+#define RR_NHEAVY CHOL_RR_NHEAVY /* tile waves that do not share a SIMD with the factor wave */
 // In-kernel cycle stamps of the factor wave: diagnostic builds only (-DCHOL_STAMPS, scripts/stamp_potrf.hip)
 #ifdef CHOL_STAMPS
 __device__ unsigned long long g_stamps[16];
@@ -771,28 +771,9 @@ __device__ __forceinline__ void own_block_row(const double (&a)[TS], int r15, do
   }
 }
 
-// Owner of tile `idx` of the column-major enumeration.  Hardware waves 0, 4, 8 share a SIMD and fp64 MFMA
-// shares the DP units with the factor wave's scalar chain, so the two tile waves on that SIMD (tile-wave
-// indices 3 and 7, "light") get 3 tiles for every 5 of the nine others: tiles are dealt in rounds of
-// 11, 9, 11, 9, 11 (= 51 per cycle; 153 tiles = 3 cycles -> 15 per heavy wave, 9 per light wave).
-// Slots grow with idx for every wave, so a wave's active tiles (column > k) are a suffix of its slots.
-#ifndef RR_HEAVY_ONLY
-#define RR_HEAVY_ONLY 36 /* pivot blocks with at most this many register tiles (T <= 10) leave the factor wave's SIMD to the factor wave */
-#endif
-__device__ __forceinline__ void rr_owner(int idx, int ntl2, int &w, int &slot)
-{
-  if (ntl2 <= RR_HEAVY_ONLY) { const int off = idx % RR_NHEAVY; w = off + off / 3; slot = idx / RR_NHEAVY; return; }
-  const int cyc = idx / 51, pos = idx % 51;
-  const int round = pos < 11 ? 0 : pos < 20 ? 1 : pos < 31 ? 2 : pos < 40 ? 3 : 4;
-  const int off = pos - (round == 0 ? 0 : round == 1 ? 11 : round == 2 ? 20 : round == 3 ? 31 : 40);
-  if (off < RR_NHEAVY) { // heavy waves in order: tile-wave indices 0,1,2,4,5,6,8,9,10
-    w = off + off / 3;
-    slot = cyc * 5 + round;
-  } else {
-    w = off == RR_NHEAVY ? 3 : 7;
-    slot = cyc * 3 + round / 2;
-  }
-}
+// Owner of a tile: chol_rr_owner (chol_plan.h, shared with the host, which builds the role tables with the schedule)
+#define RR_HEAVY_ONLY CHOL_RR_HEAVY_ONLY
+__device__ __forceinline__ void rr_owner(int idx, int ntl2, int &w, int &slot) { chol_rr_owner(idx, ntl2, &w, &slot); }
 // position of a tile wave among the heavy ones (-1 for the two light waves)
 __device__ __forceinline__ int rr_heavy_index(int w) { return (w & 3) == 3 ? -1 : w - (w >> 2); }
 // number of indices in [0, cnt) that rr_owner() gives to tile wave w (hw = rr_heavy_index(w)): the wave's
@@ -828,13 +809,7 @@ __device__ __forceinline__ void tile_solve2(d4 u0, d4 u1, const double (&Lr)[3],
   }
 }
 
-// tile index -> (i, j) of the column-major enumeration of the lower triangle of a T x T tile grid
-__device__ __forceinline__ void tile_of_index(int idx, int T, int &ti, int &tj)
-{
-  int j = 0;
-  while (j < T && idx >= T - j) { idx -= T - j; ++j; }
-  if (j >= T) { ti = -1; tj = 1 << 20; } else { ti = j + idx; tj = j; }
-}
+__device__ __forceinline__ void tile_of_index(int idx, int T, int &ti, int &tj) { chol_rr_tile_of_index(idx, T, &ti, &tj); }
 
 // ------------------------------------------------------------------------------------------------
 // POTRF role (potrf_rr_body; k_potrf_rr, k_potrf_trsm): register-resident, one 768-thread workgroup per
@@ -865,8 +840,8 @@ __device__ __forceinline__ void tile_of_index(int idx, int T, int &ti, int &tj)
 // All hand-offs are LDS words polled relaxed behind `s_waitcnt lgkmcnt(0)`; no s_barrier inside the loop
 // (the factor wave would have to take part in it), nothing that drains vmcnt on the critical chain.
 // ------------------------------------------------------------------------------------------------
-#define RR_NW 11     /* tile waves */
-#define RR_SLOTS 12  /* most tiles a tile wave owns: columns >= 2 of a 17 x 17 tile grid, 120 tiles (see rr_owner) */
+#define RR_NW CHOL_RR_NW       /* tile waves */
+#define RR_SLOTS CHOL_RR_SLOTS /* most tiles a tile wave owns: columns >= 2 of a 17 x 17 tile grid, 120 tiles (see rr_owner) */
 #define RR_RSLOTS 11 /* ... of which live in registers; slot 11 (n > 256 only, columns 2-3: dead after step 2) lives in LDS */
 #define RR_THREADS ((RR_NW + 1) * 64)
 /* LDS image of the POTRF role, in doubles */
@@ -881,8 +856,8 @@ __device__ __forceinline__ void tile_of_index(int idx, int T, int &ti, int &tj)
 #define RR_OFF_MASK (RR_OFF_KM + (RR_SLOTS * RR_NW + 7) / 8) /* per (step, wave): the slots that have work in the step, the panel tiles to solve */
 #define RR_OFF_SKY (RR_OFF_MASK + (RR_MAXT * RR_NW + 1) / 2)  /* the block's tile-level skyline (24 bytes) */
 #define RR_SMEM_DOUBLES (RR_OFF_SKY + 3)
-#define RR_M_SOLVE0 12 /* step mask: bit s < 12 = slot s; bits 12, 13 = the wave's first / second panel tile of the step is not structurally zero */
-#define RR_M_SOLVE1 13
+#define RR_M_SOLVE0 CHOL_RR_M_SOLVE0 /* step mask: bit s < 12 = slot s; bits 12, 13 = the wave's first / second panel tile of the step is not structurally zero */
+#define RR_M_SOLVE1 CHOL_RR_M_SOLVE1
 // Note (measured): waves of a workgroup are dealt to the four SIMDs round-robin, so waves 0, 4 and 8
 // share a SIMD, and fp64 MFMA runs on the same DP units as fp64 VALU: the tile waves' 64-cycle MFMAs
 // on the factor wave's SIMD stretch its scalar chain (chol16 3.4k -> 4.9k cycles).  Leaving waves 4 and
@@ -1186,19 +1161,31 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
 
 #define PSTAMP(i_) do { if (TR && fa.xstamp && fa.n_ext == 0 && tid == 64) fa.xstamp[24 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0) /* diagnostic build: the prologue of a block, tile wave 0 */
   PSTAMP(0);
-  for (int t = tid; t < RR_SLOTS * RR_NW; t += RR_THREADS) { sIJ[t] = (unsigned short)0xffff; sKm[t] = 0; }
-  for (int t = tid; t < RR_MAXT * RR_NW; t += RR_THREADS) sMask[t] = 0;
+  // The role tables -- which tile lives in which (slot, wave), the per-(step, wave) work masks -- are a function of the block's size and skyline
+  // alone: the schedule builds them once (chol_potrf_table) and they arrive behind the descriptor (d.tab); a descriptor without one (the BLAS-
+  // and task-level entry points) has them built here
+  const unsigned char *const tab = d.tab > 0 ? sky - __builtin_offsetof(chol_potrf_desc, sky) + d.tab : nullptr;
+  if (tab) {
+    static_assert((RR_MAXT * RR_NW) % 1 == 0 && RR_THREADS >= RR_MAXT * RR_NW + RR_SLOTS * RR_NW / 2 + RR_SLOTS * RR_NW / 4, "one pass copies the tables");
+    if (tid < RR_MAXT * RR_NW) sMask[tid] = ((const int *)(tab + CHOL_RR_TAB_MASK))[tid];
+    else if (tid < RR_MAXT * RR_NW + RR_SLOTS * RR_NW / 2) ((int *)sIJ)[tid - RR_MAXT * RR_NW] = ((const int *)(tab + CHOL_RR_TAB_IJ))[tid - RR_MAXT * RR_NW];
+    else if (tid < RR_MAXT * RR_NW + RR_SLOTS * RR_NW / 2 + RR_SLOTS * RR_NW / 4) ((int *)sKm)[tid - RR_MAXT * RR_NW - RR_SLOTS * RR_NW / 2] = ((const int *)(tab + CHOL_RR_TAB_KM))[tid - RR_MAXT * RR_NW - RR_SLOTS * RR_NW / 2];
+  } else {
+    for (int t = tid; t < RR_SLOTS * RR_NW; t += RR_THREADS) { sIJ[t] = (unsigned short)0xffff; sKm[t] = 0; }
+    for (int t = tid; t < RR_MAXT * RR_NW; t += RR_THREADS) sMask[t] = 0;
+  }
   if (tid < 24) sSky[tid] = sky[tid];
   if (tid < 8) sFlag[tid] = (tid == 6 || tid == 7) ? 1 : 0; // (1,0) and (1,1) are parked by the prologue
   if (tid < TS * TS) sConv[TS + (tid >> 4)][tid & 15] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
   __syncthreads();
   PSTAMP(1);
+  const int ntl2 = (T - 2) * (T - 1) / 2; // tiles of columns >= 2 (0 for T <= 2)
+  if (!tab) {
   // Columns 0 and 1 never live in registers (column 0 receives no update, column 1 exactly one): the
   // prologue parks them in LDS.  The tiles of columns >= 2 are dealt in REVERSE column-major order (last
   // column first), so at step k a wave's live tiles (column > k) are its slots [0, rr_count), evenly spread
   // over the waves, and walking the slots downwards visits column k+1 -- next step's panel, the look-ahead
   // tiles first -- before the rest
-  const int ntl2 = (T - 2) * (T - 1) / 2; // tiles of columns >= 2 (0 for T <= 2)
   for (int t = tid + 2 * T - 1; t < ntl; t += RR_THREADS) {
     int ti, tj, ow, os;
     tile_of_index(t, T, ti, tj);
@@ -1206,7 +1193,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
     sIJ[os * RR_NW + ow] = (unsigned short)(ti | (tj << 8));
     // skyline (leaf pivots): tile (i, j) receives P(i, k) P(j, k)^T, zero while k is left of either row's first tile
     const int kmin = max(sky[min(ti, 23)], sky[min(tj, 23)]);
-    sKm[os * RR_NW + ow] = kmin;
+    sKm[os * RR_NW + ow] = kmin | (tj < sky[min(ti, 23)] ? CHOL_RR_KM_ZERO : 0);
     // the steps in which the slot has work: its updates (steps kmin .. last) and its hand-over in step `last` -- an off-diagonal
     // tile is parked as a raw panel tile after step tj - 1, a diagonal tile goes to the factor wave one step earlier
     const int last = ti == tj ? tj - 2 : tj - 1;
@@ -1221,6 +1208,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
     }
   }
   __syncthreads();
+  }
   PSTAMP(2);
 
   if (wave == 0) {
@@ -1320,6 +1308,9 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
     int kmn[RR_SLOTS]; // per slot: the first step whose update of the tile can be non-zero (skyline of a leaf pivot; 0 otherwise)
 #pragma unroll
     for (int s = 0; s < RR_SLOTS; ++s) kmn[s] = __builtin_amdgcn_readfirstlane((int)sKm[s * RR_NW + w]);
+    unsigned zmask = 0; // slots whose tile is left of the skyline: zero in A, not loaded (wave uniform: a scalar branch per slot, no predicate in front of a load)
+#pragma unroll
+    for (int s = 0; s < RR_SLOTS; ++s) { zmask |= (kmn[s] & CHOL_RR_KM_ZERO) ? 1u << s : 0u; kmn[s] &= CHOL_RR_KM_ZERO - 1; }
 
     // ---- prologue: columns 0 and 1 go straight to LDS -- (0,0), (1,1) -> sDg, (i,0) -> sRaw[i],
     //      (i,1), i >= 2 -> sSol[1][i] (free until the panel solve of step 1) -- then the register tiles
@@ -1360,7 +1351,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
 #pragma unroll
     for (int s = 0; s < RR_RSLOTS; ++s) {
       d4 v = { 0.0, 0.0, 0.0, 0.0 };
-      if (ijp[s] != 0xffff) v = load_tile<PUB>(A, lda, n, ijp[s] & 0xff, ijp[s] >> 8, r15, g);
+      if (ijp[s] != 0xffff && !(zmask & (1u << s))) v = load_tile<PUB>(A, lda, n, ijp[s] & 0xff, ijp[s] >> 8, r15, g);
       tile[s] = v;
     }
     }

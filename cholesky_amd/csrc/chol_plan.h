@@ -68,11 +68,62 @@ typedef struct {
   int n, lda;
   int sep;            /* label (for info reporting) */
   int col0;           /* first column of this diagonal block inside its pivot (blocked big pivots) */
-  int ctr, pad;       /* program launch: the block's progress counter (columns published); counter ctr + 1: diagonal blocks published (L(k,k) and its inverse,
-                       * right after the block's 16x16 Cholesky -- what a strip needs to solve column tile k, ahead of the column's panel tiles) */
+  int ctr;            /* program launch: the block's progress counter (columns published) */
+  int tab;            /* > 0: byte offset, from this descriptor's own address, of the block's role table (chol_potrf_table: which
+                       * tile lives in which wave's register slot, the per-step work masks) -- built with the schedule instead of by every workgroup's
+                       * prologue; 0: the kernel builds it */
   unsigned char sky[24]; /* tile-level skyline of the block (leaf pivots; all zero otherwise): tile (i, j) of the block is structurally zero for
                           * j < sky[i] -- its trailing updates are skipped (chol_kernels.hip, potrf_rr_body) */
 } chol_potrf_desc;
+
+/* ---- the POTRF role's deal of tiles to waves and its per-step work masks (potrf_rr_body in chol_kernels.hip), shared by the kernel and
+ * by the host, which builds them with the schedule (chol_potrf_table) */
+#define CHOL_RR_MAXT 17   /* tile columns of the widest register-resident pivot block */
+#define CHOL_RR_NW 11     /* tile waves */
+#define CHOL_RR_NHEAVY 9  /* tile waves that do not share a SIMD with the factor wave */
+#define CHOL_RR_SLOTS 12  /* most tiles a tile wave owns */
+#ifndef CHOL_RR_HEAVY_ONLY
+#define CHOL_RR_HEAVY_ONLY 36 /* pivot blocks with at most this many register tiles (T <= 10) leave the factor wave's SIMD to the factor wave */
+#endif
+#define CHOL_RR_M_SOLVE0 12 /* step mask: bit s < 12 = slot s; bits 12, 13 = the wave's first / second panel tile of the step is not structurally zero */
+#define CHOL_RR_M_SOLVE1 13
+#define CHOL_RR_KM_ZERO 0x80 /* km: the tile is left of the block's skyline (zero in A: the prologue does not load it); the low bits: first step with a non-zero update */
+#define CHOL_RR_TAB_MASK 0                                              /* int [CHOL_RR_MAXT][CHOL_RR_NW] */
+#define CHOL_RR_TAB_IJ (CHOL_RR_MAXT * CHOL_RR_NW * 4)                   /* unsigned short [CHOL_RR_SLOTS][CHOL_RR_NW]: i | j << 8, 0xffff = empty */
+#define CHOL_RR_TAB_KM (CHOL_RR_TAB_IJ + CHOL_RR_SLOTS * CHOL_RR_NW * 2) /* unsigned char [CHOL_RR_SLOTS][CHOL_RR_NW] */
+#define CHOL_RR_TAB_BYTES ((CHOL_RR_TAB_KM + CHOL_RR_SLOTS * CHOL_RR_NW + 15) / 16 * 16)
+#ifdef __HIPCC__
+#define CHOL_HD __host__ __device__ __forceinline__
+#else
+#define CHOL_HD static inline
+#endif
+/* tile index -> (i, j) of the column-major enumeration of the lower triangle of a T x T tile grid */
+CHOL_HD void chol_rr_tile_of_index(int idx, int T, int *ti, int *tj)
+{
+  int j = 0;
+  while (j < T && idx >= T - j) { idx -= T - j; ++j; }
+  if (j >= T) { *ti = -1; *tj = 1 << 20; } else { *ti = j + idx; *tj = j; }
+}
+/* Owner of tile `idx` of the reverse column-major enumeration of the tiles of columns >= 2.  Hardware waves 0, 4, 8 share a SIMD and fp64 MFMA
+ * shares the DP units with the factor wave's scalar chain, so the two tile waves on that SIMD (tile-wave indices 3 and 7, "light") get 3 tiles
+ * for every 5 of the nine others: tiles are dealt in rounds of 11, 9, 11, 9, 11 (= 51 per cycle; 153 tiles = 3 cycles -> 15 per heavy wave, 9
+ * per light wave).  Slots grow with idx for every wave, so a wave's active tiles (column > k) are a suffix of its slots. */
+CHOL_HD void chol_rr_owner(int idx, int ntl2, int *w, int *slot)
+{
+  if (ntl2 <= CHOL_RR_HEAVY_ONLY) { const int off = idx % CHOL_RR_NHEAVY; *w = off + off / 3; *slot = idx / CHOL_RR_NHEAVY; return; }
+  const int cyc = idx / 51, pos = idx % 51;
+  const int round = pos < 11 ? 0 : pos < 20 ? 1 : pos < 31 ? 2 : pos < 40 ? 3 : 4;
+  const int off = pos - (round == 0 ? 0 : round == 1 ? 11 : round == 2 ? 20 : round == 3 ? 31 : 40);
+  if (off < CHOL_RR_NHEAVY) { /* heavy waves in order: tile-wave indices 0,1,2,4,5,6,8,9,10 */
+    *w = off + off / 3;
+    *slot = cyc * 5 + round;
+  } else {
+    *w = off == CHOL_RR_NHEAVY ? 3 : 7;
+    *slot = cyc * 3 + round / 2;
+  }
+}
+/* the role table of an n-column block with tile skyline sky[24] (CHOL_RR_TAB_BYTES bytes; chol_schedule.c) */
+void chol_potrf_table(int n, const unsigned char *sky, unsigned char *out);
 
 typedef struct {
   int64_t l_off;      /* pivot block (n x n, ld ldl) */

@@ -161,6 +161,34 @@ static void push_phase_f(builder *B, int kind, int first, int n, int force)
   chol_phase ph = { kind, first, n, 0, 0, 0, 0 };
   w->phase[w->n_phase++] = ph;
 }
+/* The POTRF role's tables for one block, exactly what potrf_rr_body's prologue would build (and builds, for descriptors without one): the tile
+ * of every (slot, wave), the first step with a non-zero update per slot (skyline), and per (step, wave) the slots that have work and the panel
+ * tiles to solve. */
+void chol_potrf_table(int n, const unsigned char *sky, unsigned char *out)
+{
+  int *mask = (int *)(out + CHOL_RR_TAB_MASK);
+  unsigned short *ij = (unsigned short *)(out + CHOL_RR_TAB_IJ);
+  unsigned char *km = out + CHOL_RR_TAB_KM;
+  memset(out, 0, CHOL_RR_TAB_BYTES);
+  for (int t = 0; t < CHOL_RR_SLOTS * CHOL_RR_NW; t++) ij[t] = 0xffff;
+  const int T = (n + CHOL_NB - 1) / CHOL_NB, ntl = T * (T + 1) / 2, ntl2 = (T - 2) * (T - 1) / 2;
+  for (int t = 2 * T - 1; t < ntl; t++) {
+    int ti, tj, ow, os;
+    chol_rr_tile_of_index(t, T, &ti, &tj);
+    chol_rr_owner(ntl - 1 - t, ntl2, &ow, &os);
+    ij[os * CHOL_RR_NW + ow] = (unsigned short)(ti | (tj << 8));
+    const int si = sky[ti < 23 ? ti : 23], sj = sky[tj < 23 ? tj : 23], kmin = si > sj ? si : sj;
+    km[os * CHOL_RR_NW + ow] = (unsigned char)(kmin | (tj < si ? CHOL_RR_KM_ZERO : 0));
+    const int last = ti == tj ? tj - 2 : tj - 1;
+    for (int k = kmin < last ? kmin : last; k <= last; k++) mask[k * CHOL_RR_NW + ow] |= 1 << os;
+  }
+  for (int k = 0; k < T; k++)
+    for (int i = k + 2; i < T; i++)
+      if (sky[i < 23 ? i : 23] <= k) {
+        const int hv = i % CHOL_RR_NHEAVY;
+        mask[k * CHOL_RR_NW + hv + hv / 3] |= 1 << (i < k + 2 + CHOL_RR_NHEAVY ? CHOL_RR_M_SOLVE0 : CHOL_RR_M_SOLVE1);
+      }
+}
 static void push_potrf(builder *B, chol_potrf_desc d)
 {
   chol_level_work *w = B->w;

@@ -311,3 +311,31 @@ def test_alternative_launch_paths_keep_parity(opts, ca, golden):
 def test_unknown_option_is_refused(ca, runs):
     with pytest.raises(ca.CholamdError):
         runs["lapl_9x9"]["dev"].set_option("no_such_switch", 1)
+
+
+@pytest.mark.parametrize("case", ["lapl_400x400", "lapl_3375x3375"])
+def test_role_tables_of_the_schedule_equal_the_kernels_own(case, ca, monkeypatch):
+    """The POTRF role's tables (tile -> slot and wave, per-step work masks) come with the descriptors (chol_potrf_table, built with the
+    schedule); a descriptor without one has them built by the workgroup's prologue.  Same tables, so bit-identical factors, for the program
+    launch and the level-by-level launches."""
+    import torch
+    m, o, c, _ = case_paths(case)
+    plan = ca.Plan(m, o, c)
+    for opts in ({}, {"program": 0}):
+        res = []
+        for no_tables in (False, True):
+            if no_tables:
+                monkeypatch.setenv("CHOLAMD_NO_ROLE_TABLES", "1")
+            else:
+                monkeypatch.delenv("CHOLAMD_NO_ROLE_TABLES", raising=False)
+            dev = ca.Device(plan, 0)
+            for k, v in opts.items():
+                dev.set_option(k, v)
+            a = dev.new_arena()
+            dev.fill(a)
+            dev.factor(a)
+            dev.sync()
+            assert dev.info()[0] == 0
+            res.append(a.clone())
+        assert torch.equal(res[0], res[1]), opts
+    monkeypatch.delenv("CHOLAMD_NO_ROLE_TABLES", raising=False)

@@ -370,3 +370,65 @@ def test_macro_tile_fill_statistics(ca):
         assert 0 <= f <= t and 0 <= v <= w
         tasks, full, valid, total = tasks + t, full + f, valid + v, total + w
     assert tasks > 0 and valid / total > 0.6
+
+
+def _role_table_reference(n, sky):
+    """Independent restatement of the POTRF role's deal and step masks (chol_kernels.hip, potrf_rr_body): tiles of columns >= 2 of the T x T
+    lower tile grid in reverse column-major order to 9 heavy + 2 light waves; per (step, wave) the slots with work, the panel tiles to solve."""
+    NW, NH, SLOTS, MAXT = 11, 9, 12, 17
+    T = (n + 15) // 16
+    tiles = [(i, j) for j in range(T) for i in range(j, T)]
+    ntl, ntl2 = len(tiles), (T - 2) * (T - 1) // 2
+    mask = np.zeros((MAXT, NW), dtype=np.int32)
+    ij = np.full((SLOTS, NW), 0xFFFF, dtype=np.uint16)
+    km = np.zeros((SLOTS, NW), dtype=np.uint8)
+
+    def owner(idx):
+        if ntl2 <= 36:
+            off = idx % NH
+            return off + off // 3, idx // NH
+        cyc, pos = divmod(idx, 51)
+        starts = [0, 11, 20, 31, 40, 51]
+        rnd = max(r for r in range(5) if pos >= starts[r])
+        off = pos - starts[rnd]
+        if off < NH:
+            return off + off // 3, cyc * 5 + rnd
+        return (3 if off == NH else 7), cyc * 3 + rnd // 2
+
+    for t in range(2 * T - 1, ntl):
+        ti, tj = tiles[t]
+        w, s = owner(ntl - 1 - t)
+        ij[s, w] = ti | (tj << 8)
+        kmin = max(sky[min(ti, 23)], sky[min(tj, 23)])
+        km[s, w] = kmin | (0x80 if tj < sky[min(ti, 23)] else 0)  # bit 7: left of the skyline, zero in A
+        last = tj - 2 if ti == tj else tj - 1
+        for k in range(min(kmin, last), last + 1):
+            mask[k, w] |= 1 << s
+    for k in range(T):
+        for i in range(k + 2, T):
+            if sky[min(i, 23)] <= k:
+                hv = i % NH
+                mask[k, hv + hv // 3] |= 1 << (12 if i < k + 2 + NH else 13)
+    return mask, ij, km
+
+
+@pytest.mark.parametrize("n,band", [(16, 0), (33, 0), (98, 0), (144, 0), (160, 0), (176, 0), (259, 3), (272, 2), (272, 0)])
+def test_potrf_role_table(n, band):
+    """The table the schedule ships behind a POTRF descriptor (chol_potrf_table) against the restatement above."""
+    from cholesky_amd import _lib
+    L = C.CDLL(_lib.LIB_PATH)
+    sky = np.zeros(24, dtype=np.uint8)
+    if band:
+        sky[:] = [max(0, i - band) for i in range(24)]
+    out = np.zeros(2048, dtype=np.uint8)
+    L.chol_potrf_table.restype = None
+    L.chol_potrf_table(C.c_int(n), sky.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    mask, ij, km = _role_table_reference(n, [int(v) for v in sky])
+    got_mask = out[:17 * 11 * 4].view(np.int32).reshape(17, 11)
+    got_ij = out[17 * 11 * 4:17 * 11 * 4 + 12 * 11 * 2].view(np.uint16).reshape(12, 11)
+    got_km = out[17 * 11 * 4 + 12 * 11 * 2:17 * 11 * 4 + 12 * 11 * 3].reshape(12, 11)
+    assert np.array_equal(got_ij, ij) and np.array_equal(got_km, km) and np.array_equal(got_mask, mask)
+    # every tile of columns >= 2 has exactly one (slot, wave)
+    T = (n + 15) // 16
+    owned = sorted(int(v) for v in got_ij.ravel() if v != 0xFFFF)
+    assert owned == sorted(i | (j << 8) for j in range(2, T) for i in range(j, T))
