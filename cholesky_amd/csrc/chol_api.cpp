@@ -664,7 +664,7 @@ extern "C" int cholamd_device_program_trace(cholamd_device *d, double *d_arena, 
           fprintf(fp, " items %llu own-tiles-wait-over %.1f rounds:", x[1], x[0] ? (double)(x[0] - t0) * 0.01 : -1.0);
           for (unsigned long long i = 0; i < x[1] && i < 44; i++) if (x[2 + i]) fprintf(fp, " %llu:%.1f", i, (double)(x[2 + i] - t0) * 0.01);
         }
-        if (kind == 0 && x[24]) { fprintf(fp, " | prologue (entry, LDS init, masks, tiles requested, columns 0-1 parked):"); for (int k = 0; k < 5; k++) fprintf(fp, " %.1f", x[24 + k] ? (double)(x[24 + k] - t0) * 0.01 : -1.0); }
+        if (kind == 0 && x[24]) { fprintf(fp, " | prologue (entry, LDS init, tables, slot tables read, columns 0-1 requested, tiles requested, columns 0-1 parked):"); const int ord[7] = { 0, 1, 2, 5, 6, 3, 4 }; for (int k = 0; k < 7; k++) fprintf(fp, " %.1f", x[24 + ord[k]] ? (double)(x[24 + ord[k]] - t0) * 0.01 : -1.0); }
         fprintf(fp, kind == 0 ? " | column started:" : " | POTRF column seen:");
         for (int k = 0; k < 24; k++) if (x[72 + k]) fprintf(fp, " %d:%.1f", k, (double)(x[72 + k] - t0) * 0.01);
         fprintf(fp, kind == 0 ? " | column published:" : " | column tile on the channel:");

@@ -852,7 +852,7 @@ __device__ __forceinline__ void tile_of_index(int idx, int T, int &ti, int &tj) 
 #define RR_OFF_OV (RR_OFF_CONV + 2 * TS * (TS + 1))
 #define RR_OFF_IJ (RR_OFF_OV + RR_NHEAVY * TS * TS)
 #define RR_OFF_FLAG (RR_OFF_IJ + (RR_SLOTS * RR_NW + 16 + 3) / 4)
-#define RR_OFF_KM (RR_OFF_FLAG + 4)                       /* per (slot, wave): first step whose update can be non-zero (skyline) */
+#define RR_OFF_KM (RR_OFF_FLAG + 5)                       /* per (slot, wave): first step whose update can be non-zero (skyline) */
 #define RR_OFF_MASK (RR_OFF_KM + (RR_SLOTS * RR_NW + 7) / 8) /* per (step, wave): the slots that have work in the step, the panel tiles to solve */
 #define RR_OFF_SKY (RR_OFF_MASK + (RR_MAXT * RR_NW + 1) / 2)  /* the block's tile-level skyline (24 bytes) */
 #define RR_SMEM_DOUBLES (RR_OFF_SKY + 3)
@@ -1148,6 +1148,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
   int *const cRaw = &sFlag[4]; // raw tiles parked in sRaw so far (column j contributes T - 1 - j)
   int *const fA = &sFlag[6];   // j: raw tile (j, j-1) is in sRaw[j]
   int *const fD = &sFlag[7];   // j: diagonal tile (j, j), updated through step j-2, is in sDg[j & 1]; (fA, fD) = one aligned 64-bit word
+  int *const f00 = &sFlag[8];  // 1: the prologue has parked tile (0,0) in sDg[0] -- all the factor wave's first Cholesky waits for
 
   double *A = base + d.a_off;
   double *W = ws + d.dinv_off;
@@ -1161,6 +1162,16 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
 
 #define PSTAMP(i_) do { if (TR && fa.xstamp && fa.n_ext == 0 && tid == 64) fa.xstamp[24 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0) /* diagnostic build: the prologue of a block, tile wave 0 */
   PSTAMP(0);
+  // a block that follows nobody requests its tiles of columns 0 and 1 before anything else: their round trip runs under the arrival of the role tables
+  d4 stage[3];
+  const bool stage_early = !(FOLLOW && fa.n_ext > 0) && wave != 0;
+  if (stage_early) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int u = min(wave - 1 + it * RR_NW, 2 * T - 2);
+      stage[it] = load_tile<PUB>(A, lda, n, u < T ? u : u - T + 1, u < T ? 0 : 1, r15, g);
+    }
+  }
   // The role tables -- which tile lives in which (slot, wave), the per-(step, wave) work masks -- are a function of the block's size and skyline
   // alone: the schedule builds them once (chol_potrf_table) and they arrive behind the descriptor (d.tab); a descriptor without one (the BLAS-
   // and task-level entry points) has them built here
@@ -1175,7 +1186,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
     for (int t = tid; t < RR_MAXT * RR_NW; t += RR_THREADS) sMask[t] = 0;
   }
   if (tid < 24) sSky[tid] = sky[tid];
-  if (tid < 8) sFlag[tid] = (tid == 6 || tid == 7) ? 1 : 0; // (1,0) and (1,1) are parked by the prologue
+  if (tid < 10) sFlag[tid] = 0; // (fA and fD go to 1 when the prologue has parked (1,0) and (1,1))
   if (tid < TS * TS) sConv[TS + (tid >> 4)][tid & 15] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
   __syncthreads();
   PSTAMP(1);
@@ -1222,7 +1233,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       if (TR && fa.stamp && lane == 0) *fa.stamp = __builtin_amdgcn_s_memrealtime(); // diagnostic build (k_program<true>): the followed columns are in
     }
     __builtin_amdgcn_s_setprio(3);
-    lds_wait_ge(cUpd, RR_NW); // prologue of the tile waves done: (0,0), (1,1) are in sDg, column 0 in sRaw
+    lds_wait_ge(f00, 1); // (0,0) is in sDg: the first Cholesky starts while the other waves' tiles are still on their way (the step's other inputs have flags of their own: fA, fD, cRaw, cUpd)
     d4 dk; // diagonal tile of the current step, accumulator layout
 #pragma unroll
     for (int q = 0; q < 4; ++q) dk[q] = sDg[0][q * 64 + lp0];
@@ -1311,12 +1322,12 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
     unsigned zmask = 0; // slots whose tile is left of the skyline: zero in A, not loaded (wave uniform: a scalar branch per slot, no predicate in front of a load)
 #pragma unroll
     for (int s = 0; s < RR_SLOTS; ++s) { zmask |= (kmn[s] & CHOL_RR_KM_ZERO) ? 1u << s : 0u; kmn[s] &= CHOL_RR_KM_ZERO - 1; }
+    PSTAMP(5); // slot tables read
 
     // ---- prologue: columns 0 and 1 go straight to LDS -- (0,0), (1,1) -> sDg, (i,0) -> sRaw[i],
     //      (i,1), i >= 2 -> sSol[1][i] (free until the panel solve of step 1) -- then the register tiles
     //      Every load of the prologue is issued before the first wait: three tiles of columns 0 / 1 per wave at
     //      most (2 T - 1 <= 33 tiles over 11 waves), then the register tiles.
-    d4 stage[3];
     if (FOLLOW && fa.n_ext > 0) {
       // A follower without waits of its own (no update job of an earlier phase writes its diagonal block: the parents of the
       // leaves) loads its own tiles first -- their round trip overlaps the wait for the first followed column -- and puts the
@@ -1343,11 +1354,7 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
       for (int s = FOLLOW_SLOTS; s < RR_RSLOTS; ++s) tile[s] = zero4; // not live across the followed columns
       lds_barrier();
     } else {
-#pragma unroll
-    for (int it = 0; it < 3; ++it) {
-      const int u = min(w + it * RR_NW, 2 * T - 2);
-      stage[it] = load_tile<PUB>(A, lda, n, u < T ? u : u - T + 1, u < T ? 0 : 1, r15, g);
-    }
+    PSTAMP(6);
 #pragma unroll
     for (int s = 0; s < RR_RSLOTS; ++s) {
       d4 v = { 0.0, 0.0, 0.0, 0.0 };
@@ -1364,6 +1371,8 @@ __device__ __forceinline__ void potrf_rr_body(double *__restrict__ base, double 
         double *park = ti == tj ? &sDg[ti][0] : tj == 0 ? &sRaw[ti][0] : &sSol[1][ti][0];
 #pragma unroll
         for (int q = 0; q < 4; ++q) park[q * 64 + lp0] = stage[it][q];
+        if (u == 0) lds_set(f00, 1, lane);
+        if (ti == 1) lds_set(tj == 0 ? fA : fD, 1, lane);
         if (tj == 0 && ti > 0) lds_inc(cRaw, lane);
       }
     }
