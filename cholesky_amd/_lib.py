@@ -121,6 +121,7 @@ def load():
     L.cholamd_gather_to_root.argtypes = [vp, vp, ci, vp, vp]
     L.cholamd_exchange_volume.argtypes = [vp, vp]
     L.cholamd_plan_exchange_volume.argtypes = [vp, ci, ci, ci, vp]
+    L.cholamd_plan_exchange_pieces.argtypes = [vp, ci, ci, ci, vp]
     L.cholamd_follow_rounds.argtypes = [ci, ci, ci, vp, vp]
     L.cholamd_plan_program_followers.argtypes = [vp, i64, vp]
     L.cholamd_plan_program_followers.restype = i64

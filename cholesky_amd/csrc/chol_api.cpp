@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
@@ -61,6 +62,8 @@ struct cholamd_device {
   int *progress = nullptr;  // fused launches: columns published per pivot block (epoch * 64 + columns); [nsep + 1] = TRSM workgroups finished
   int epoch = 0, done_total = 0;
   int64_t *a_dst = nullptr; double *a_val = nullptr; int *perm = nullptr; double *ytmp = nullptr;
+  // distributed top levels: the entries of A in the column blocks of the shared top THIS rank owns ([0]: by the fp64 schedule's blocks, [1]: the fp32 one's)
+  int64_t *top_dst[2] = { nullptr, nullptr }; double *top_val[2] = { nullptr, nullptr }; int64_t top_n[2] = { 0, 0 }; int top_gen[2] = { -1, -1 };
   bool timing = false;
   std::vector<timed_launch> tl;
   std::vector<hipEvent_t> pool;
@@ -254,6 +257,7 @@ extern "C" void cholamd_device_destroy(cholamd_device *d)
   (void)hipFree(d->ws32); (void)hipFree(d->csr_ptr); (void)hipFree(d->csr_col); (void)hipFree(d->csr_val); (void)hipFree(d->rvec); (void)hipFree(d->dxvec); (void)hipFree(d->partial);
   (void)hipFree(d->xstage); (void)hipFree(d->xdesc);
   (void)hipFree(d->ws); (void)hipFree(d->ws_solve); (void)hipFree(d->info); (void)hipFree(d->progress); (void)hipFree(d->a_dst); (void)hipFree(d->a_val); (void)hipFree(d->perm); (void)hipFree(d->ytmp);
+  for (int q = 0; q < 2; q++) { (void)hipFree(d->top_dst[q]); (void)hipFree(d->top_val[q]); }
   for (auto &t : d->tl) { d->pool.push_back(t.a); d->pool.push_back(t.b); }
   for (auto e : d->pool) (void)hipEventDestroy(e);
   delete d;
@@ -464,22 +468,23 @@ extern "C" int cholamd_device_free_arena(cholamd_device *d, void *dptr)
   return 0;
 }
 
+// Multi-GPU: which entries of A a rank's fill scatters.  Everything under the cut on every rank (the panels of the other ranks' subtrees are
+// never read).  The shared top of the tree (the tail of the arena) must start from A on exactly ONE rank per element, so that the sum over
+// the ranks after the local levels is A_top - all contributions: with replicated top levels (one all-reduce of the tail) that is rank 0; with
+// the top levels distributed by column blocks it is the block's OWNER -- the extend-add exchange then carries a block only from the ranks whose
+// subtrees reach it (chol_top_contributors), and rank 0 sends no more than any other rank.  `*below` = leading entries of (a_dst, a_val) to
+// scatter; (*tdst, *tval, *ntop) = further entries (device arrays).  f32: the fp32 schedule's column blocks.
+static void exchange_pieces(const cholamd_device *d, const std::vector<level_dev> &lv, std::vector<struct xpiece> &out);
+static int top_entries(cholamd_device *d, int f32, int64_t *below, const int64_t **tdst, const double **tval, int64_t *ntop);
 extern "C" int cholamd_device_fill(cholamd_device *d, double *d_arena, void *stream)
 {
   HIPCHK(hipSetDevice(d->dev));
   hipStream_t st = (hipStream_t)stream;
   { int rc = clear_owned(d, d_arena, sizeof(double), st); if (rc) return rc; }
-  // multi-GPU: the shared top of the tree (tail of the arena) starts from A on rank 0 only and from
-  // zero elsewhere, so that the sum over ranks after the local levels is A_top - all contributions
-  int64_t nnz = d->plan->nnz_a;
-  if (d->world > 1 && d->rank != 0) {
-    const int first_top = d->plan->nsep - (d->world - 1) + 1;
-    const int64_t tail = d->plan->panel_off[first_top];
-    int64_t lo = 0, hi = nnz;
-    while (lo < hi) { int64_t mid = (lo + hi) / 2; if (d->plan->a_dst[mid] < tail) lo = mid + 1; else hi = mid; }
-    nnz = lo;
-  }
-  HIPCHK((hipError_t)chol_launch_scatter(d_arena, d->a_dst, d->a_val, nnz, st));
+  int64_t below = 0, ntop = 0; const int64_t *tdst = nullptr; const double *tval = nullptr;
+  { int rc = top_entries(d, 0, &below, &tdst, &tval, &ntop); if (rc) return rc; }
+  HIPCHK((hipError_t)chol_launch_scatter(d_arena, d->a_dst, d->a_val, below, st));
+  if (ntop > 0) HIPCHK((hipError_t)chol_launch_scatter(d_arena, tdst, tval, ntop, st));
   return 0;
 }
 
@@ -796,14 +801,11 @@ extern "C" int cholamd_device_fill_f32(cholamd_device *d, float *d_arena32, void
   HIPCHK(hipSetDevice(d->dev));
   hipStream_t st = (hipStream_t)stream;
   { int rc = clear_owned(d, d_arena32, sizeof(float), st); if (rc) return rc; }
-  int64_t nnz = d->plan->nnz_a;
-  if (d->world > 1 && d->rank != 0) { // the shared top starts from A on rank 0 only (see cholamd_device_fill)
-    const int64_t tail = d->plan->panel_off[d->plan->nsep - (d->world - 1) + 1];
-    int64_t lo = 0, hi = nnz;
-    while (lo < hi) { int64_t mid = (lo + hi) / 2; if (d->plan->a_dst[mid] < tail) lo = mid + 1; else hi = mid; }
-    nnz = lo;
-  }
-  HIPCHK((hipError_t)chol32_launch_scatter(d_arena32, d->a_dst, d->a_val, nnz, st));
+  { int rc = ensure_f32(d); if (rc) return rc; } // the fp32 schedule's column blocks decide which entries of the shared top are this rank's
+  int64_t below = 0, ntop = 0; const int64_t *tdst = nullptr; const double *tval = nullptr;
+  { int rc = top_entries(d, 1, &below, &tdst, &tval, &ntop); if (rc) return rc; }
+  HIPCHK((hipError_t)chol32_launch_scatter(d_arena32, d->a_dst, d->a_val, below, st));
+  if (ntop > 0) HIPCHK((hipError_t)chol32_launch_scatter(d_arena32, tdst, tval, ntop, st));
   return 0;
 }
 static int launch_phase_f32(cholamd_device *d, const level_dev &l, const chol_phase &ph, float *d_arena32, hipStream_t st)
@@ -1632,24 +1634,70 @@ static int comm_matches(const cholamd_device *d, const cholamd_comm *c)
 // owner adds the world - 1 copies it received to its own in RANK ORDER (deterministic: the same sum in every run).  A rank receives
 // (world - 1) x (its owned blocks) and sends the blocks it does not own once: (world - 1) / world of the tail each way, against
 // 2 (world - 1) / world of it each way for the ring all-reduce -- and nothing is added twice on the way.
-struct xpiece { int64_t off, count, stage; int owner; };
+// PATH-AWARE (round 4): a rank's subtree reaches only the top separators on its own path to the root (the reference touches a C tile only
+// where the fill marks it, blas.rg:385-395, and the fill of a top block comes from the subtrees under it): its copy of every other
+// top panel is zero -- unless it is rank 0, whose arena starts from A there.  So a rank SENDS only the blocks of the separators on its
+// path (rank 0: all) and an owner RECEIVES only from the ranks under the block's separator and from rank 0 (chol_top_contributors);
+// both ends compute the same lists from the plan, nothing about them travels.
+struct xpiece { int64_t off, count, stage; int owner; unsigned contrib; };
 // the column blocks of the levels above the cut, with their owners (the broadcast lists of the distributed top levels); empty: replicated
 static void exchange_pieces(const cholamd_device *d, const std::vector<level_dev> &lv, std::vector<xpiece> &out)
 {
   out.clear();
   const int split = chol_split_level(d->world);
   for (int lvl = split - 1; lvl >= 0 && lvl < (int)lv.size(); lvl--)
-    for (const chol_bcast &b : lv[lvl].bcast) out.push_back({ b.off, b.count, 0, b.owner });
-  int64_t st = 0; // staging slots of the pieces this rank owns: world - 1 copies each, senders in rank order
-  for (xpiece &x : out) if (x.owner == d->rank) { x.stage = st; st += x.count * (d->world - 1); }
+    for (const chol_bcast &b : lv[lvl].bcast) out.push_back({ b.off, b.count, 0, b.owner, chol_top_contributors(b.heap, d->world) });
+  int64_t st = 0; // staging slots of the pieces this rank owns: one copy per contributing rank other than itself, senders in rank order
+  for (xpiece &x : out) if (x.owner == d->rank) { x.stage = st; st += x.count * __builtin_popcount(x.contrib & ~(1u << d->rank)); }
 }
-struct sum_desc { int64_t off, count, stage; };
+static int top_entries(cholamd_device *d, int f32, int64_t *below, const int64_t **tdst, const double **tval, int64_t *ntop)
+{
+  const cholamd_plan *p = d->plan;
+  *tdst = nullptr; *tval = nullptr; *ntop = 0;
+  if (d->world <= 1) { *below = p->nnz_a; return 0; }
+  const int64_t tail = p->panel_off[p->nsep - (d->world - 1) + 1];
+  int64_t lo = 0, hi = p->nnz_a;
+  while (lo < hi) { int64_t mid = (lo + hi) / 2; if (p->a_dst[mid] < tail) lo = mid + 1; else hi = mid; }
+  *below = lo;
+  if (d->top_gen[f32] != d->sched_gen) { // once per schedule
+    (void)hipFree(d->top_dst[f32]); (void)hipFree(d->top_val[f32]); d->top_dst[f32] = nullptr; d->top_val[f32] = nullptr; d->top_n[f32] = 0;
+    std::vector<xpiece> px;
+    exchange_pieces(d, f32 ? d->lv32 : d->lv, px);
+    if (px.empty()) d->top_n[f32] = d->rank == 0 ? -1 : 0; // replicated top levels: rank 0 scatters the whole tail
+    else {
+      std::vector<xpiece> mine;
+      for (const xpiece &x : px) if (x.owner == d->rank) mine.push_back(x);
+      std::sort(mine.begin(), mine.end(), [](const xpiece &a, const xpiece &b) { return a.off < b.off; });
+      std::vector<int64_t> td; std::vector<double> tv;
+      size_t q = 0;
+      for (int64_t e = lo; e < p->nnz_a; e++) { // a_dst ascends: one merge pass over the owned blocks
+        while (q < mine.size() && mine[q].off + mine[q].count <= p->a_dst[e]) q++;
+        if (q < mine.size() && p->a_dst[e] >= mine[q].off) { td.push_back(p->a_dst[e]); tv.push_back(p->a_val[e]); }
+      }
+      if (!td.empty()) {
+        int rc = upload_vec(&d->top_dst[f32], td.data(), td.size());
+        if (!rc) rc = upload_vec(&d->top_val[f32], tv.data(), tv.size());
+        if (rc) return rc;
+      }
+      d->top_n[f32] = (int64_t)td.size();
+    }
+    d->top_gen[f32] = d->sched_gen;
+  }
+  if (d->top_n[f32] < 0) *below = p->nnz_a;
+  else { *tdst = d->top_dst[f32]; *tval = d->top_val[f32]; *ntop = d->top_n[f32]; }
+  return 0;
+}
+struct sum_desc { int64_t off, count, stage; unsigned contrib, pad; };
 template <class T> __global__ void k_sum_owned(T *arena, const T *stage, const sum_desc *desc, int world, int rank)
-{ // arena[off + i] = sum over the ranks in rank order; rank r's copy: this rank's own arena for r == rank, else staging slot (r < rank ? r : r - 1)
+{ // arena[off + i] = sum over the ranks in rank order; rank r's copy: this rank's own arena for r == rank, else -- if r contributes -- the next staging slot
   const sum_desc d = desc[blockIdx.y];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.count; i += (int64_t)gridDim.x * blockDim.x) {
     T s = 0;
-    for (int r = 0; r < world; r++) s += r == rank ? arena[d.off + i] : stage[d.stage + (int64_t)(r < rank ? r : r - 1) * d.count + i];
+    int slot = 0;
+    for (int r = 0; r < world; r++) {
+      if (r == rank) s += arena[d.off + i];
+      else if (d.contrib & (1u << r)) { s += stage[d.stage + (int64_t)slot * d.count + i]; slot++; }
+    }
     arena[d.off + i] = s;
   }
 }
@@ -1671,7 +1719,7 @@ template <class T> static int exchange_owned(cholamd_device *d, T *arena, const 
 {
   const ncclDataType_t ty = sizeof(T) == 8 ? ncclDouble : ncclFloat;
   int64_t need = 0; std::vector<sum_desc> mine;
-  for (const xpiece &x : px) if (x.owner == d->rank) { need += x.count * (d->world - 1); mine.push_back({ x.off, x.count, x.stage }); }
+  for (const xpiece &x : px) if (x.owner == d->rank) { need += x.count * __builtin_popcount(x.contrib & ~(1u << d->rank)); mine.push_back({ x.off, x.count, x.stage, x.contrib, 0 }); }
   if ((size_t)need * sizeof(T) > d->xstage_bytes) {
     HIPCHK(hipStreamSynchronize(st));
     (void)hipFree(d->xstage); d->xstage = nullptr; d->xstage_bytes = 0;
@@ -1690,11 +1738,11 @@ template <class T> static int exchange_owned(cholamd_device *d, T *arena, const 
     ncclResult_t r = ncclSuccess;
     if (x.owner == d->rank) {
       for (int q = 0, slot = 0; q < d->world && r == ncclSuccess; q++) {
-        if (q == d->rank) continue;
+        if (q == d->rank || !(x.contrib & (1u << q))) continue;
         r = ncclRecv(stage + x.stage + (int64_t)slot * x.count, (size_t)x.count, ty, q, c->comm, st);
         slot++;
       }
-    } else r = ncclSend(arena + x.off, (size_t)x.count, ty, x.owner, c->comm, st);
+    } else if (x.contrib & (1u << d->rank)) r = ncclSend(arena + x.off, (size_t)x.count, ty, x.owner, c->comm, st);
     if (r != ncclSuccess) { (void)ncclGroupEnd(); chol_set_error("ncclSend/ncclRecv failed: %s", ncclGetErrorString(r)); return CHOLAMD_ERR_COMM; }
   }
   NCCLCHK(ncclGroupEnd());
@@ -1733,7 +1781,7 @@ extern "C" int cholamd_exchange_volume(const cholamd_device *d, int64_t out[4])
   int64_t tail, count;
   tail_of(d, &tail, &count);
   out[0] = out[1] = 0; out[2] = count; out[3] = (int64_t)px.size();
-  for (const xpiece &x : px) { if (x.owner == d->rank) out[0] += x.count * (d->world - 1); else out[1] += x.count; }
+  for (const xpiece &x : px) { if (x.owner == d->rank) out[0] += x.count * __builtin_popcount(x.contrib & ~(1u << d->rank)); else if (x.contrib & (1u << d->rank)) out[1] += x.count; }
   if (px.empty() && d->world > 1) out[0] = out[1] = 2 * count * (d->world - 1) / d->world;
   return 0;
 }
@@ -1788,12 +1836,12 @@ extern "C" int cholamd_factor_sharded_f32(cholamd_device *d, float *d_arena32, c
 
 // ---- one process driving n ranks ----
 struct ptr_pack { void *p[CHOL_LOCAL_MAX]; };
-template <class T> __global__ void k_sum_ranks(ptr_pack P, int n, int dst, int64_t count)
-{ // P.p[dst][i] = sum over the ranks in rank order (a fixed order: run-to-run identical)
+template <class T> __global__ void k_sum_ranks(ptr_pack P, int n, T *dst, int64_t count)
+{ // dst[i] = sum over the n copies in the order of the pack (rank order: run-to-run identical); dst may be one of them
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
     T s = ((const T *)P.p[0])[i];
     for (int r = 1; r < n; r++) s += ((const T *)P.p[r])[i];
-    ((T *)P.p[dst])[i] = s;
+    dst[i] = s;
   }
 }
 static hipStream_t stream_of(void *const *streams, int g) { return streams ? (hipStream_t)streams[g] : nullptr; }
@@ -1810,7 +1858,7 @@ template <class T> static int local_exchange(cholamd_device *const *devs, T *con
     ptr_pack P;
     for (int g = 0; g < n; g++) { P.p[g] = arenas[g] + tail; if (g) HIPCHK(hipStreamWaitEvent(stream_of(streams, 0), G->ev[g], 0)); }
     const int64_t blocks = (count + 255) / 256;
-    hipLaunchKernelGGL(k_sum_ranks<T>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream_of(streams, 0), P, n, 0, count);
+    hipLaunchKernelGGL(k_sum_ranks<T>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream_of(streams, 0), P, n, arenas[0] + tail, count);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(G->ev[n], stream_of(streams, 0)));
     for (int g = 1; g < n; g++) {
@@ -1830,10 +1878,11 @@ template <class T> static int local_exchange(cholamd_device *const *devs, T *con
     for (int g = 0; g < n; g++) if (g != o) HIPCHK(hipStreamWaitEvent(stream_of(streams, o), G->ev[g], 0));
     for (const xpiece &x : px) {
       if (x.owner != o) continue;
-      ptr_pack P;
-      for (int g = 0; g < n; g++) P.p[g] = arenas[g] + x.off;
+      ptr_pack P; // the copies that can be non-zero (the same set the RCCL path sends) and the owner's own, in rank order
+      int np = 0;
+      for (int g = 0; g < n; g++) if (g == o || (x.contrib & (1u << g))) P.p[np++] = arenas[g] + x.off;
       const int64_t blocks = (x.count + 255) / 256;
-      hipLaunchKernelGGL(k_sum_ranks<T>, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, stream_of(streams, o), P, n, o, x.count);
+      hipLaunchKernelGGL(k_sum_ranks<T>, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, stream_of(streams, o), P, np, arenas[o] + x.off, x.count);
       HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(G->ev[n + o], stream_of(streams, o)));

@@ -228,7 +228,20 @@ typedef struct {
 } chol_phase;
 /* kind 6 (distributed top levels): broadcast of the column blocks [first, first + n) of the level's bcast list: every rank receives
  * `count` doubles at arena offset `off` from rank `owner` */
-typedef struct { int64_t off, count; int owner, pad; } chol_bcast;
+typedef struct { int64_t off, count; int owner, heap; } chol_bcast; /* heap: heap index of the top separator the block belongs to */
+/* ranks whose copy of a column block of top separator `heap` (tree level < log2(world)) can be non-zero before the extend-add exchange: the ranks
+ * whose subtrees hang under the separator -- their updates are the only ones that reach it (A's entries of the block start on its owner:
+ * cholamd_device_fill, which receives nothing from itself).  Bit r = rank r. */
+static inline unsigned chol_top_contributors(int heap, int world)
+{
+  int d = 0, l = 0;
+  while ((1 << d) < world) d++;
+  while ((heap >> (l + 1)) > 0) l++;
+  const int lo = (heap << (d - l)) - (1 << d), hi = ((heap + 1) << (d - l)) - (1 << d);
+  unsigned m = 0u;
+  for (int g = lo; g < hi; g++) m |= 1u << g;
+  return m;
+}
 
 /* schedule switches of one device object (chol_schedule.c): read from the environment once, at cholamd_device_create */
 #define CHOL_DIST_MIN 1024      /* dist_top = 2 (auto): the top levels are distributed when the root separator has this many columns */

@@ -518,7 +518,7 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
       const int mine = !dist || dist_owner(p, s, st, world) == rank;
       if (dist) { /* the column block travels from its owner to every rank once it is factored and solved */
         if (w->n_bcast == B->cap_b) { B->cap_b = B->cap_b ? 2 * B->cap_b : 16; w->bcast = realloc(w->bcast, B->cap_b * sizeof(chol_bcast)); }
-        chol_bcast bc = { p->panel_off[s] + colbase, (int64_t)nb * ld, dist_owner(p, s, st, world), 0 };
+        chol_bcast bc = { p->panel_off[s] + colbase, (int64_t)nb * ld, dist_owner(p, s, st, world), h };
         w->bcast[w->n_bcast++] = bc;
         B->tgt_sep = s;
       }
@@ -1789,8 +1789,9 @@ int cholamd_plan_level_work_volume_opts(const cholamd_plan *p, int level, int me
 
 /* Volume of the extend-add exchange for (rank, world) under dist_top = 0 / 1 / 2 (auto), in arena elements: out[0] received, out[1]
  * sent, out[2] the tail, out[3] column-block pieces (0: replicated top levels, one all-reduce of the tail -- a ring moves
- * 2 (world - 1) / world of it each way).  Distributed top levels: a rank receives world - 1 copies of every column block it owns and
- * sends each block it does not own once, to the owner (chol_api.cpp, exchange_owned). */
+ * 2 (world - 1) / world of it each way).  Distributed top levels: a rank sends the column blocks it does not own of the top separators ON ITS
+ * OWN ROOT PATH once, to their owners (rank 0: of every top separator -- it holds A's entries), and receives, for every block it owns, one copy
+ * from each other rank under the block's separator and from rank 0 (chol_top_contributors; chol_api.cpp, exchange_owned). */
 int cholamd_plan_exchange_volume(const cholamd_plan *p, int rank, int world, int dist_top, int64_t out[4])
 {
   chol_sched_opts o;
@@ -1806,12 +1807,33 @@ int cholamd_plan_exchange_volume(const cholamd_plan *p, int rank, int world, int
     if (rc) return rc;
     for (int i = 0; i < w.n_bcast; i++) {
       out[3]++;
-      if (w.bcast[i].owner == rank) out[0] += w.bcast[i].count * (world - 1); else out[1] += w.bcast[i].count;
+      const unsigned c = chol_top_contributors(w.bcast[i].heap, world);
+      if (w.bcast[i].owner == rank) out[0] += w.bcast[i].count * __builtin_popcount(c & ~(1u << rank));
+      else if (c & (1u << rank)) out[1] += w.bcast[i].count;
     }
     chol_level_work_free(&w);
   }
   if (out[3] == 0 && world > 1) out[0] = out[1] = 2 * out[2] * (world - 1) / world;
   return 0;
+}
+
+int cholamd_plan_exchange_pieces(const cholamd_plan *p, int world, int dist_top, int max, int64_t (*out)[4])
+{
+  chol_sched_opts o;
+  chol_sched_opts_default(&o);
+  o.dist_top = dist_top;
+  const int d = chol_split_level(world);
+  if (world < 1 || (1 << d) != world || d > p->levels - 1) { chol_set_error("bad partition into %d", world); return CHOLAMD_ERR_ARG; }
+  int n = 0;
+  for (int lvl = d - 1; lvl >= 0; lvl--) {
+    chol_level_work w;
+    int rc = chol_build_level_work(p, &o, lvl, 0, world, &w);
+    if (rc) return rc;
+    for (int i = 0; i < w.n_bcast; i++, n++)
+      if (n < max) { out[n][0] = w.bcast[i].off; out[n][1] = w.bcast[i].count; out[n][2] = w.bcast[i].owner; out[n][3] = w.bcast[i].heap; }
+    chol_level_work_free(&w);
+  }
+  return n;
 }
 
 void chol_level_work_free(chol_level_work *w)

@@ -176,6 +176,9 @@ class Device:
     def factor_f32(self, arena32, stream=None):
         check(self.L.cholamd_factor_f32(self.h, self.ptr(arena32), _stream_ptr(stream)), "cholamd_factor_f32")
 
+    def factor_levels_f32(self, arena32, level_hi, level_lo, stream=None):
+        check(self.L.cholamd_factor_levels_f32(self.h, self.ptr(arena32), level_hi, level_lo, _stream_ptr(stream)), "cholamd_factor_levels_f32")
+
     def solve_f32(self, arena32, b, x, stream=None):
         check(self.L.cholamd_solve_f32(self.h, self.ptr(arena32), self.ptr(b), self.ptr(x), _stream_ptr(stream)), "cholamd_solve_f32")
 

@@ -156,6 +156,14 @@ class Plan:
         check(self.L.cholamd_plan_exchange_volume(self.h, rank, world, dist_top, out.ctypes.data), "cholamd_plan_exchange_volume")
         return tuple(int(v) for v in out)
 
+    def exchange_pieces(self, world, dist_top=2):
+        """The column-block pieces of that exchange as rows (arena offset, elements, owner rank, heap index of the top separator)."""
+        out = np.zeros((4096, 4), dtype=np.int64)
+        n = self.L.cholamd_plan_exchange_pieces(self.h, world, dist_top, len(out), out.ctypes.data)
+        if n < 0:
+            check(n, "cholamd_plan_exchange_pieces")
+        return out[:min(n, len(out))]
+
     def level_work_volume(self, level, rank=0, world=1, dist_top=2):
         """(POTRF columns, TRSM elements, update volume, broadcast entries, broadcast doubles, broadcast checksum) of one level's
         lists for (rank, world) with the top levels replicated (dist_top=0), distributed by column blocks (1) or automatic (2)."""

@@ -193,8 +193,14 @@ int cholamd_plan_level_mt_fill(const cholamd_plan *p, int level, int64_t out[4])
  * of the broadcast list (the same on every rank) */
 int cholamd_plan_level_work_volume(const cholamd_plan *p, int level, int rank, int world, int dist_top, int64_t out[6]);
 /* volume of the extend-add exchange of (rank, world) under dist_top 0 / 1 / 2 (auto), in arena elements: received, sent, the tail,
- * column-block pieces (0 pieces: the all-reduce of the replicated top levels) -- the host-side count behind cholamd_exchange_volume */
+ * column-block pieces (0 pieces: the all-reduce of the replicated top levels) -- the host-side count behind cholamd_exchange_volume.
+ * Path-aware since round 4: only the blocks of the top separators on the sender's own root path travel */
 int cholamd_plan_exchange_volume(const cholamd_plan *p, int rank, int world, int dist_top, int64_t out[4]);
+/* the column-block pieces of that exchange (the broadcast lists of the levels above the cut): out[i] = { arena offset, elements, owner rank, heap index
+ * of the top separator }, at most `max` of them; returns their number (< 0: error).  A rank sends piece i to its owner iff it does not own it and
+ * its subtree hangs under that separator: the reference touches a C tile only where the fill marks it (blas.rg:385-395), and the fill of a top
+ * block comes from A (scattered on the block's owner by cholamd_device_fill) and from the subtrees under it */
+int cholamd_plan_exchange_pieces(const cholamd_plan *p, int world, int dist_top, int max, int64_t (*out)[4]);
 /* host-side self-check of the one-launch program cholamd_factor() runs for small problems on one GPU (chol_build_program):
  * simulated with `workers` resident workgroups and every counter raised only on job completion, no job may starve; counters
  * total up; pivot blocks and TRSM rows equal those of the per-level lists.  0 = consistent, otherwise cholamd_last_error()
@@ -264,7 +270,10 @@ int cholamd_device_free(cholamd_device *d, double *dptr);
 int cholamd_device_upload(cholamd_device *d, double *d_dst, const double *h_src, int64_t doubles, void *stream);
 int cholamd_device_download(cholamd_device *d, double *h_dst, const double *d_src, int64_t doubles, void *stream);
 int cholamd_device_sync(cholamd_device *d, void *stream);
-/* A scatter on the device (fill_block, mmat.rg:1216-1224): zero d_arena, scatter tril(A). */
+/* A scatter on the device (fill_block, mmat.rg:1216-1224): zero d_arena, scatter tril(A).  A partitioned device (cholamd_device_set_partition)
+ * scatters every entry under the cut and, of the shared top of the tree, the entries exactly one rank must start from: all of them on rank 0 when the
+ * top levels are replicated, those of the column blocks the rank OWNS when they are distributed (option dist_top) -- fill after set_partition /
+ * set_option, with the schedule the factorisation will use. */
 int cholamd_device_fill(cholamd_device *d, double *d_arena, void *stream);
 /* The hot path: the whole level loop of mmat.rg:1227-1355 on d_arena, asynchronously on stream.  Small problems (every
  * pivot block <= 192 columns, no macro-tile phase: the reference's fixtures) run as ONE launch of resident workgroups that

@@ -130,32 +130,40 @@ def _gpu_worker(rank, world, port, case, q):
 @pytest.mark.parametrize("case,world", [("lapl_3375x3375", 2), ("lapl_3375x3375", 4), ("lapl_3375x3375", 8), ((24, 24, 24, 5, 32), 8), ((30, 30, 10, 5, 32), 4)])
 def test_owner_directed_exchange_volume(case, world):
     """The extend-add exchange under the distributed top levels is OWNER-DIRECTED (SURVEY 5 communication row, 8e
-    "Collective"): a rank receives world - 1 copies of exactly the column blocks it owns and sends each block it does not own once --
-    (world - 1) / world of the tail each way in total, half of what a ring all-reduce of the whole tail moves; with replicated top
-    levels (dist_top 0) it stays the all-reduce."""
+    "Collective") and, since round 4, PATH-AWARE (blas.rg:385-395: a C tile outside the fill is never touched): a rank
+    sends each column block it does not own once IF its subtree hangs under the block's separator (A's entries of a block start on its owner:
+    cholamd_device_fill), an owner receives one copy from every such rank.  Restated here from the piece list and the tree alone; with
+    replicated top levels (dist_top 0) it stays the all-reduce."""
     import cholesky_amd as ca
     plan = ca.Plan(*case_paths(case)[:3]) if isinstance(case, str) else ca.Problem(*case).plan()
     d = world.bit_length() - 1
     vols = [plan.exchange_volume(r, world, 1) for r in range(world)]
     tail = vols[0][2]
     assert all(v[2] == tail and v[3] == vols[0][3] and v[3] > 0 for v in vols)
-    # the pieces are the broadcast lists of the levels above the cut: owners and sizes from the same (checked) lists
-    owned = [0] * world
-    total = 0
-    for lvl in range(d):
-        n_b, doubles = plan.level_work_volume(lvl, 0, world, 1)[3:5]
-        total += doubles
-    for r in range(world):
-        recv, sent, _, _ = vols[r]
-        assert recv % (world - 1) == 0
-        owned[r] = recv // (world - 1)
-        assert sent == total - owned[r]                      # every block it does not own, once
-    assert sum(owned) == total                               # every column block has exactly one owner
-    assert 0.98 * tail <= total <= tail                      # the blocks cover the tail (bar the alignment gaps between panels)
-    assert sum(v[0] for v in vols) == sum(v[1] for v in vols) == (world - 1) * total
+    pieces = plan.exchange_pieces(world, 1)
+    assert len(pieces) == vols[0][3]
+    # the pieces are the broadcast lists of the levels above the cut: sizes from the same (checked) lists
+    total = sum(plan.level_work_volume(lvl, 0, world, 1)[4] for lvl in range(d))
+    assert int(pieces[:, 1].sum()) == total and 0.98 * tail <= total <= tail  # they cover the tail (bar the alignment gaps between panels)
+
+    def under(heap):  # ranks whose subtree root (heap index world + g) has `heap` on its path to the root
+        return {g for g in range(world) if any(((world + g) >> k) == heap for k in range(1, d + 1))}
+
+    recv, sent = [0] * world, [0] * world
+    for off, count, owner, heap in pieces.tolist():
+        assert 1 <= heap < world and 0 <= owner < world
+        for g in under(heap):
+            if g != owner:
+                sent[g] += count
+                recv[owner] += count
+    assert [v[0] for v in vols] == recv and [v[1] for v in vols] == sent
+    dense_sent = [total - int(pieces[pieces[:, 2] == r, 1].sum()) for r in range(world)]  # round 3: every block a rank does not own
+    assert all(sent[r] <= dense_sent[r] for r in range(world))
+    if world >= 4:  # most ranks are under few of the top separators (the root's panel, which every rank is under, is the largest)
+        assert sum(sent) < (0.8 if world == 4 else 0.6) * sum(dense_sent)
     ring = 2 * tail * (world - 1) // world                   # what the all-reduce moves per rank, each way
     assert all(plan.exchange_volume(r, world, 0) == (ring, ring, tail, 0) for r in range(world))
-    assert 2 * sum(v[0] for v in vols) <= world * ring * 1.0001  # over all ranks: half of what the ring all-reduce moves
+    assert 2 * sum(v[0] for v in vols) <= world * ring * 1.0001  # over all ranks: less than half of what the ring all-reduce moves
 
 
 @pytest.mark.gpu
@@ -427,3 +435,62 @@ def test_sharded_factorisation_over_rccl_two_gpus():
         assert p.exitcode == 0
     assert info == (0, 0)
     assert np.abs(_assemble(plan, parts, world, ref) - ref).max() <= 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,world,mixed", [("lapl_3375x3375", 8, False), ((24, 24, 24, 5, 32), 8, False), ((24, 24, 24, 5, 32), 4, True)])
+def test_only_the_ranks_under_a_top_separator_touch_its_blocks(case, world, mixed):
+    """What the path-aware exchange (exchange_owned: grouped ncclSend / ncclRecv, not runnable on a one-GPU box) relies on, checked on the device:
+    after the subtree levels, BEFORE the exchange, a rank's copy of a column block of the shared top is non-zero only if its subtree hangs under
+    the block's separator or it owns the block (whose entries of A its fill scattered); and the copies add up to what the single-GPU run holds
+    there at the same point (A_top minus every contribution of the levels under the cut)."""
+    import cholesky_amd as ca
+    from cholesky_amd import parallel
+    plan = ca.Plan(*case_paths(case)[:3]) if isinstance(case, str) else ca.Problem(*case).plan()
+    d = world.bit_length() - 1
+    L, split = plan.levels, parallel.split_level(world)
+    pieces = plan.exchange_pieces(world, 1).tolist()
+
+    def under(heap):
+        return {g for g in range(world) if any(((world + g) >> k) == heap for k in range(1, d + 1))}
+
+    def run(dev):
+        a = dev.new_arena_f32() if mixed else dev.new_arena()
+        (dev.fill_f32 if mixed else dev.fill)(a)
+        if mixed:
+            dev.factor_levels_f32(a, L - 1, split)
+        else:
+            dev.factor_levels(a, L - 1, split)
+        dev.sync()
+        assert dev.info() == (0, 0)
+        return a.cpu().numpy().astype(np.float64)
+
+    one = ca.Device(plan, 0)
+    one.set_option("dist_top", 1)
+    if mixed and not hasattr(one, "factor_levels_f32"):
+        pytest.skip("no level-range entry point for the fp32 factor in the Python mirror")
+    ref = run(one)
+    parts = []
+    for r in range(world):
+        dev = ca.Device(plan, 0)
+        dev.set_option("dist_top", 1)
+        dev.set_partition(r, world)
+        parts.append(run(dev))
+    if mixed:  # the fp32 schedule cuts its own column blocks (128 columns): its piece list is the device's
+        pieces = None
+    checked = 0
+    for off, count, owner, heap in (pieces or []):
+        tot = np.zeros(count)
+        for r in range(world):
+            blk = parts[r][off:off + count]
+            if r not in under(heap) and r != owner:
+                assert not blk.any(), (r, heap, owner)
+            tot += blk
+        assert np.abs(tot - ref[off:off + count]).max() <= 1e-12 * max(1.0, np.abs(ref[off:off + count]).max())
+        checked += 1
+    if not mixed:
+        assert checked == len(pieces) > 0
+    else:  # without the fp32 piece list: the tails add up to the single-GPU tail
+        tail = parallel.tail_offset(plan, world)
+        tot = sum(p[tail:] for p in parts)
+        assert np.abs(tot - ref[tail:]).max() <= 2e-5 * max(1.0, np.abs(ref[tail:]).max())
