@@ -358,11 +358,22 @@ def main():
     # dominant-kernel roofline: HIP events recorded by the library around every launch, on the
     # stream the kernels run on, in a separate pass over pre-filled arenas
     refine = None
-    if mixed and world > 1:  # the complete fp32 factor on rank 0 (the subtree panels of the other ranks travel there), refined there
+    if mixed and world > 1:  # the other half of the configuration, distributed like the factorisation: the fp32 factor stays on the ranks, every rank
+        # sweeps its own subtrees and solves the shared top redundantly, only vectors travel (cholamd_solve_refine_sharded; no gather to rank 0)
         last = arenas[(done + K - 1) % n_arenas] if K <= n_arenas else arenas[(K - 1) % n_arenas]
-        dev.gather_to_root(last, comm, stream)
+        if generated:
+            bvec = torch.from_numpy(ca.Problem(gn, gn, gn, glv, gtile).rhs()).cuda()
+        else:
+            bvec = torch.from_numpy(ca.plan.read_vector(os.path.join(os.path.dirname(files[0]), f"B_{plan.n}x1.mtx"), plan.n)).cuda()
+        xvec = torch.empty_like(bvec)
+        dev.solve_refine_sharded(last, bvec, xvec, comm, 30, 1e-11, stream)  # warm-up (work lists, CSR upload)
         fence()
-    if mixed and rank == 0:  # the other half of the configuration: one right-hand side solved to fp64 accuracy with the fp32 factor
+        t0 = time.perf_counter()
+        it, rel = dev.solve_refine_sharded(last, bvec, xvec, comm, 30, 1e-11, stream)
+        fence()
+        refine = {"corrections": it, "relres": rel, "ms": round((time.perf_counter() - t0) * 1e3, 3), "tol": 1e-11,
+                  "distributed": "factor left on the ranks; two vector all-reduces per solve (cholamd_solve_refine_sharded)"}
+    if mixed and rank == 0 and world == 1:  # the other half of the configuration: one right-hand side solved to fp64 accuracy with the fp32 factor
         if generated:
             bvec = torch.from_numpy(ca.Problem(gn, gn, gn, glv, gtile).rhs()).cuda()
         else:

@@ -122,6 +122,12 @@ def load():
     L.cholamd_exchange_volume.argtypes = [vp, vp]
     L.cholamd_plan_exchange_volume.argtypes = [vp, ci, ci, ci, vp]
     L.cholamd_plan_exchange_pieces.argtypes = [vp, ci, ci, ci, vp]
+    L.cholamd_plan_solve_counts.argtypes = [vp, ci, ci, ci, vp]
+    L.cholamd_solve_sharded.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.cholamd_solve_sharded_f32.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.cholamd_solve_refine_sharded.argtypes = [vp, vp, vp, vp, ci, C.c_double, vp, vp, vp, vp]
+    L.cholamd_solve_multi.argtypes = [vp, vp, vp, vp, vp, ci, vp]
+    L.cholamd_solve_refine_multi.argtypes = [vp, vp, vp, vp, ci, C.c_double, vp, vp, vp, ci, vp]
     L.cholamd_follow_rounds.argtypes = [ci, ci, ci, vp, vp]
     L.cholamd_plan_program_followers.argtypes = [vp, i64, vp]
     L.cholamd_plan_program_followers.restype = i64

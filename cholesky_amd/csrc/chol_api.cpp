@@ -53,6 +53,8 @@ struct cholamd_device {
   std::vector<level_dev> lv;
   std::vector<solve_dev> sv;
   bool solve_ready = false;
+  int solve_rank = 0, solve_world = 1; // the partition the solve lists were built for
+  int *zr_sub = nullptr; int n_zr_sub = 0; // distributed solve: (offset, length) ranges of the permuted vector this rank starts from zero in (other ranks' subtrees; the shared top on ranks other than 0)
   double *ws = nullptr;
   double *ws_solve = nullptr; // 16x16 inverses of the diagonal blocks of the arena being solved with
   int *info = nullptr;      // [0] first failing column, [1] separator; two slots of two ints: the program launch alternates between them (each launch clears the other
@@ -124,6 +126,13 @@ static void free_levels(cholamd_device *d)
   (void)hipFree(d->jobs); (void)hipFree(d->pwaits); (void)hipFree(d->exts); (void)hipFree(d->pctr); (void)hipFree(d->pctr_total);
   d->jobs = nullptr; d->pwaits = nullptr; d->exts = nullptr; d->pctr = nullptr; d->pctr_total = nullptr;
   d->prog_ready = false;
+}
+static void free_solve_lists(cholamd_device *d)
+{
+  for (auto &s : d->sv) { (void)hipFree(s.trsv); (void)hipFree(s.fw); (void)hipFree(s.bw); (void)hipFree(s.grp_start); (void)hipFree(s.grp_rows); (void)hipFree(s.bw_start); (void)hipFree(s.ifw); (void)hipFree(s.ibw); }
+  d->sv.clear();
+  (void)hipFree(d->zr_sub); d->zr_sub = nullptr; d->n_zr_sub = 0;
+  d->solve_ready = false;
 }
 static int upload_level(level_dev &l, const chol_level_work &w, bool with_tables = true)
 {
@@ -253,7 +262,7 @@ extern "C" void cholamd_device_destroy(cholamd_device *d)
     for (auto h : a.handles) (void)hipMemRelease(h);
     (void)hipMemAddressFree(a.va, a.total);
   }
-  for (auto &s : d->sv) { (void)hipFree(s.trsv); (void)hipFree(s.fw); (void)hipFree(s.bw); (void)hipFree(s.grp_start); (void)hipFree(s.grp_rows); (void)hipFree(s.bw_start); (void)hipFree(s.ifw); (void)hipFree(s.ibw); }
+  free_solve_lists(d);
   (void)hipFree(d->ws32); (void)hipFree(d->csr_ptr); (void)hipFree(d->csr_col); (void)hipFree(d->csr_val); (void)hipFree(d->rvec); (void)hipFree(d->dxvec); (void)hipFree(d->partial);
   (void)hipFree(d->xstage); (void)hipFree(d->xdesc);
   (void)hipFree(d->ws); (void)hipFree(d->ws_solve); (void)hipFree(d->info); (void)hipFree(d->progress); (void)hipFree(d->a_dst); (void)hipFree(d->a_val); (void)hipFree(d->perm); (void)hipFree(d->ytmp);
@@ -271,6 +280,7 @@ extern "C" int cholamd_device_set_partition(cholamd_device *d, int rank, int wor
     return CHOLAMD_ERR_ARG;
   }
   d->rank = rank; d->world = world;
+  free_solve_lists(d); // rebuilt for the new partition at the next solve
   return build_levels(d);
 }
 
@@ -694,13 +704,36 @@ extern "C" int cholamd_factor_info(cholamd_device *d, int *sep_out)
 }
 
 // ---- solve ----------------------------------------------------------------------------------
-static int build_solve(cholamd_device *d)
+__global__ void k_zero_ranges(double *y, const int *ranges, int nr)
+{ // ranges[2 i], ranges[2 i + 1] = offset, length; one block row per range
+  const int off = ranges[2 * blockIdx.y], len = ranges[2 * blockIdx.y + 1];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) y[off + i] = 0.0;
+}
+// the solve lists of the whole tree (rank 0 of 1: cholamd_solve / cholamd_solve_refine, also on a partitioned device whose arena holds the gathered
+// factor) or of one rank's share (the distributed solve); one set is kept, rebuilt when the other is asked for
+static int build_solve(cholamd_device *d, int rank = 0, int world = 1)
 {
   const int L = d->plan->levels;
+  if (d->solve_ready && d->solve_rank == rank && d->solve_world == world) return 0;
+  free_solve_lists(d);
+  d->solve_rank = rank; d->solve_world = world;
   d->sv.resize(L);
+  if (world > 1) { // what a rank of the distributed solve starts from zero: every position it does not own, the shared top unless it is rank 0
+    const cholamd_plan *p = d->plan;
+    std::vector<int> zr;
+    for (int s = 1; s <= p->nsep; s++) {
+      const int o = chol_owner_of(p, s, world);
+      if ((o >= 0 && o != rank) || (o < 0 && rank != 0)) {
+        if (!zr.empty() && zr[zr.size() - 2] + zr.back() == p->sep_off[s]) zr.back() += p->sep_size[s];
+        else { zr.push_back(p->sep_off[s]); zr.push_back(p->sep_size[s]); }
+      }
+    }
+    d->n_zr_sub = (int)zr.size() / 2;
+    if (!zr.empty()) { int rc = upload_vec(&d->zr_sub, zr.data(), zr.size()); if (rc) return rc; }
+  }
   for (int lvl = 0; lvl < L; lvl++) {
     chol_solve_level w;
-    int rc = chol_build_solve_level(d->plan, lvl, &w);
+    int rc = chol_build_solve_level_part(d->plan, lvl, rank, world, &w);
     if (rc) return rc;
     solve_dev &s = d->sv[lvl];
     s.n_trsv = w.n_trsv; s.n_grp = w.n_grp; s.n_fw = w.n_fw; s.n_bw = w.n_bw;
@@ -716,12 +749,14 @@ static int build_solve(cholamd_device *d)
     chol_solve_level_free(&w);
     if (rc) return rc;
   }
-  HIPCHK(hipMalloc((void **)&d->ytmp, (size_t)d->plan->n * sizeof(double)));
-  HIPCHK(hipMalloc((void **)&d->ws_solve, (size_t)(d->plan->ws_doubles > 0 ? d->plan->ws_doubles : 1) * sizeof(double)));
+  if (!d->ytmp) HIPCHK(hipMalloc((void **)&d->ytmp, (size_t)d->plan->n * sizeof(double)));
+  if (!d->ws_solve) HIPCHK(hipMalloc((void **)&d->ws_solve, (size_t)(d->plan->ws_doubles > 0 ? d->plan->ws_doubles : 1) * sizeof(double)));
   d->solve_ready = true;
   return 0;
 }
 
+// first position of the shared top of the tree in the permuted vector (the separators above the cut are the last labels: a contiguous tail, as in the arena)
+static int64_t top_vec_offset(const cholamd_device *d) { return d->solve_world > 1 ? d->plan->sep_off[d->plan->nsep - (d->solve_world - 1) + 1] : d->plan->n; }
 // the streamed solve (every panel read once) with a factor of element type TL; vectors and arithmetic are fp64
 static int lsolve_dinv(const double *a, const chol_trsv_desc *t, int n, int mx, double *W, hipStream_t st) { return chol_launch_solve_dinv(a, t, n, mx, W, st); }
 static int lsolve_dinv(const float *a, const chol_trsv_desc *t, int n, int mx, double *W, hipStream_t st) { return chol32_launch_solve_dinv(a, t, n, mx, W, st); }
@@ -729,33 +764,58 @@ static int lsolve_trsv(const double *a, const chol_trsv_desc *t, int n, int mx, 
 static int lsolve_trsv(const float *a, const chol_trsv_desc *t, int n, int mx, const double *W, double *y, int bw, hipStream_t st) { return chol32_launch_solve_trsv(a, t, n, mx, W, y, bw, st); }
 static int lsolve_off(const double *a, const chol_gemv_desc *g, const int *it, int n, double *y, int bw, hipStream_t st) { return chol_launch_solve_offdiag(a, g, it, n, y, bw, st); }
 static int lsolve_off(const float *a, const chol_gemv_desc *g, const int *it, int n, double *y, int bw, hipStream_t st) { return chol32_launch_solve_offdiag(a, g, it, n, y, bw, st); }
+// The streamed solve in three phases, so that a partitioned device can put the two vector reductions of the distributed solve between them:
+//   phase 0: y = P b (a rank of a partition: zero outside what it owns), the 16x16 inverses, forward sweep of the levels under the cut
+//            -> [sum of the shared top's part of y over the ranks]
+//   phase 1: forward and backward sweep of the levels above the cut (every rank: it holds the whole factored top), backward sweep under the cut;
+//            ranks other than 0 then clear the top's part again  -> [sum of y over the ranks: every rank has the whole permuted solution]
+//   phase 2: x = P^T y
+// A device that is not partitioned runs them back to back: the cut is at level 0.
+template <class TL> static int solve_phase(cholamd_device *d, const TL *d_arena, const double *d_b, double *d_x, int phase, hipStream_t st)
+{
+  const int L = d->plan->levels, n = d->plan->n, cut = d->solve_world > 1 ? chol_split_level(d->solve_world) : 0;
+  double *y = d->ytmp;
+  if (phase == 0) {
+    HIPCHK((hipError_t)chol_launch_permute(d_b, d->perm, y, n, 0, st));
+    if (d->n_zr_sub > 0) { hipLaunchKernelGGL(k_zero_ranges, dim3(16, d->n_zr_sub), dim3(256), 0, st, y, d->zr_sub, d->n_zr_sub); HIPCHK(hipGetLastError()); }
+    // the 16x16 inverses of this arena's diagonal blocks (the factorisation's workspace belongs to the last arena factored)
+    for (int lvl = 0; lvl < L; lvl++) {
+      const solve_dev &s = d->sv[lvl];
+      HIPCHK((hipError_t)lsolve_dinv(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, st));
+    }
+  }
+  if (phase <= 1) {
+    const int hi = phase == 0 ? L - 1 : cut - 1, lo = phase == 0 ? cut : 0;
+    for (int lvl = hi; lvl >= lo; lvl--) { // forward, mmat.rg:1395-1435: TRSV per separator, then its panel into the ancestors
+      const solve_dev &s = d->sv[lvl];
+      HIPCHK((hipError_t)lsolve_trsv(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, y, 0, st));
+      HIPCHK((hipError_t)lsolve_off(d_arena, s.bw, s.ifw, s.n_ifw, y, 0, st));
+    }
+  }
+  if (phase == 1) {
+    for (int lvl = 0; lvl < L; lvl++) { // backward, mmat.rg:1438-1479: gather from the ancestors, then TRSV^T
+      const solve_dev &s = d->sv[lvl];
+      HIPCHK((hipError_t)lsolve_off(d_arena, s.bw, s.ibw, s.n_ibw, y, 1, st));
+      HIPCHK((hipError_t)lsolve_trsv(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, y, 1, st));
+    }
+    if (d->solve_world > 1 && d->solve_rank != 0) { // the top's part of the solution is counted once in the sum that follows: rank 0's
+      const int64_t t0 = top_vec_offset(d);
+      HIPCHK(hipMemsetAsync(y + t0, 0, (size_t)(n - t0) * sizeof(double), st));
+    }
+  }
+  if (phase == 2) HIPCHK((hipError_t)chol_launch_permute(y, d->perm, d_x, n, 1, st));
+  return 0;
+}
 template <class TL> static int solve_streamed(cholamd_device *d, const TL *d_arena, const double *d_b, double *d_x, hipStream_t st)
 {
-  const int L = d->plan->levels, n = d->plan->n;
-  double *y = d->ytmp;
-  HIPCHK((hipError_t)chol_launch_permute(d_b, d->perm, y, n, 0, st));
-  // the 16x16 inverses of this arena's diagonal blocks (the factorisation's workspace belongs to the last arena factored)
-  for (int lvl = 0; lvl < L; lvl++) {
-    const solve_dev &s = d->sv[lvl];
-    HIPCHK((hipError_t)lsolve_dinv(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, st));
-  }
-  for (int lvl = L - 1; lvl >= 0; lvl--) { // forward, mmat.rg:1395-1435: TRSV per separator, then its panel into the ancestors
-    const solve_dev &s = d->sv[lvl];
-    HIPCHK((hipError_t)lsolve_trsv(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, y, 0, st));
-    HIPCHK((hipError_t)lsolve_off(d_arena, s.bw, s.ifw, s.n_ifw, y, 0, st));
-  }
-  for (int lvl = 0; lvl < L; lvl++) { // backward, mmat.rg:1438-1479: gather from the ancestors, then TRSV^T
-    const solve_dev &s = d->sv[lvl];
-    HIPCHK((hipError_t)lsolve_off(d_arena, s.bw, s.ibw, s.n_ibw, y, 1, st));
-    HIPCHK((hipError_t)lsolve_trsv(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, y, 1, st));
-  }
-  HIPCHK((hipError_t)chol_launch_permute(y, d->perm, d_x, n, 1, st));
+  { int rc = build_solve(d); if (rc) return rc; } // the whole tree: the arena holds the complete factor (single GPU, or gathered on this rank)
+  for (int ph = 0; ph < 3; ph++) { int rc = solve_phase(d, d_arena, d_b, d_x, ph, st); if (rc) return rc; }
   return 0;
 }
 extern "C" int cholamd_solve(cholamd_device *d, const double *d_arena, const double *d_b, double *d_x, void *stream)
 {
   HIPCHK(hipSetDevice(d->dev));
-  if (!d->solve_ready) { int rc = build_solve(d); if (rc) return rc; }
+  { int rc = build_solve(d); if (rc) return rc; }
   hipStream_t st = (hipStream_t)stream;
   if (!d->solve_reference_shape) return solve_streamed(d, d_arena, d_b, d_x, st);
   // the per-call kernels the BLAS-level entry points use (deterministic, slow at scale)
@@ -855,7 +915,7 @@ extern "C" int cholamd_factor_f32(cholamd_device *d, float *d_arena32, void *str
 extern "C" int cholamd_solve_f32(cholamd_device *d, const float *d_arena32, const double *d_b, double *d_x, void *stream)
 {
   HIPCHK(hipSetDevice(d->dev));
-  if (!d->solve_ready) { int rc = build_solve(d); if (rc) return rc; }
+  { int rc = build_solve(d); if (rc) return rc; }
   return solve_streamed(d, d_arena32, d_b, d_x, (hipStream_t)stream);
 }
 static int ensure_refine(cholamd_device *d)
@@ -897,7 +957,7 @@ extern "C" int cholamd_solve_refine(cholamd_device *d, const float *d_arena32, c
 {
   HIPCHK(hipSetDevice(d->dev));
   int rc = ensure_refine(d);
-  if (!rc && !d->solve_ready) rc = build_solve(d);
+  if (!rc) rc = build_solve(d);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   const int n = d->plan->n;
@@ -2036,5 +2096,153 @@ static int gather_factor_bytes(cholamd_device *const *devs, void *const *arenas,
     const int64_t len = (s < p->nsep ? p->panel_off[s + 1] : p->arena) - off;
     HIPCHK(hipMemcpyPeerAsync((char *)arenas[0] + (size_t)off * elem_bytes, devs[0]->dev, (const char *)arenas[g] + (size_t)off * elem_bytes, devs[g]->dev, (size_t)len * elem_bytes, streams ? (hipStream_t)streams[0] : nullptr));
   }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Distributed solve (mmat.rg:1394-1479 sharded like the factorisation).  After cholamd_factor_sharded / _multi a rank's arena holds
+// the panels of its own subtrees and the WHOLE factored top (replicated, or broadcast block by block under dist_top).  So: every rank sweeps its own
+// subtrees forward (the contributions to the top accumulate in its copy of the top's part of y, which starts from b on rank 0 and from zero
+// elsewhere), ONE sum of that part over the ranks, every rank solves the top forward and backward redundantly, sweeps its subtrees backward, and one
+// sum of the permuted vector (every position is non-zero on exactly one rank) gives every rank the solution.  Only vectors travel: (world - 1) top
+// separators' worth of doubles, then n doubles -- against the 17-33 GB of factor that cholamd_gather_to_root moved at 100^3.  The iterative
+// refinement runs the same loop on every rank (residual in fp64 against A, replicated; the corrections solved as above): identical iterates.
+// ---------------------------------------------------------------------------------------------
+template <class TL> static int solve_sharded_t(cholamd_device *d, const TL *d_arena, const double *d_b, double *d_x, cholamd_comm *c, hipStream_t st)
+{
+  HIPCHK(hipSetDevice(d->dev));
+  if (d->world == 1) return solve_streamed(d, d_arena, d_b, d_x, st);
+  int rc = build_solve(d, d->rank, d->world);
+  if (rc) return rc;
+  if (comm_matches(d, c)) return CHOLAMD_ERR_ARG;
+  if (!c->comm) { chol_set_error("a local communicator solves through cholamd_solve_multi only"); return CHOLAMD_ERR_ARG; }
+  const int64_t t0 = top_vec_offset(d), n = d->plan->n;
+  if ((rc = solve_phase(d, d_arena, d_b, d_x, 0, st))) return rc;
+  NCCLCHK(ncclAllReduce(d->ytmp + t0, d->ytmp + t0, (size_t)(n - t0), ncclDouble, ncclSum, c->comm, st));
+  if ((rc = solve_phase(d, d_arena, d_b, d_x, 1, st))) return rc;
+  NCCLCHK(ncclAllReduce(d->ytmp, d->ytmp, (size_t)n, ncclDouble, ncclSum, c->comm, st));
+  return solve_phase(d, d_arena, d_b, d_x, 2, st);
+}
+extern "C" int cholamd_solve_sharded(cholamd_device *d, const double *d_arena, const double *d_b, double *d_x, cholamd_comm *c, void *stream)
+{
+  return solve_sharded_t<double>(d, d_arena, d_b, d_x, c, (hipStream_t)stream);
+}
+extern "C" int cholamd_solve_sharded_f32(cholamd_device *d, const float *d_arena32, const double *d_b, double *d_x, cholamd_comm *c, void *stream)
+{
+  return solve_sharded_t<float>(d, d_arena32, d_b, d_x, c, (hipStream_t)stream);
+}
+extern "C" int cholamd_solve_refine_sharded(cholamd_device *d, const float *d_arena32, const double *d_b, double *d_x, int max_iter, double tol,
+                                            int *iters_out, double *relres_out, cholamd_comm *c, void *stream)
+{ // every rank calls it with the same b; every rank ends with the same x, iteration count and residual
+  HIPCHK(hipSetDevice(d->dev));
+  int rc = ensure_refine(d);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int n = d->plan->n;
+  if (max_iter < 0) max_iter = 0;
+  if ((rc = solve_sharded_t<float>(d, d_arena32, d_b, d_x, c, st))) return rc;
+  double rel = 0.0;
+  int it = 0;
+  for (;; ++it) {
+    if ((rc = residual_norm(d, d_b, d_x, d->rvec, &rel, st))) return rc;
+    if (!(rel > tol) || it >= max_iter) break; // also leaves on NaN (the same decision on every rank: the iterates are identical)
+    if ((rc = solve_sharded_t<float>(d, d_arena32, d->rvec, d->dxvec, c, st))) return rc;
+    HIPCHK((hipError_t)chol_launch_axpy1(d_x, d->dxvec, n, st));
+  }
+  if (iters_out) *iters_out = it;
+  if (relres_out) *relres_out = rel;
+  if (rel != rel) { chol_set_error("iterative refinement produced NaN (fp32 factorisation broke down)"); return CHOLAMD_ERR_ARG; }
+  return 0;
+}
+// one process driving n ranks: the two sums as an ordered device-side sum on rank 0's stream and peer copies back (local communicator), or grouped
+// ncclAllReduce calls (cholamd_comm_create_all)
+static int multi_sum_vec(cholamd_device *const *devs, cholamd_comm *const *comms, int n, void *const *streams, int64_t off, int64_t count)
+{ // devs[g]->ytmp[off, off + count) <- sum over the ranks, on every rank
+  if (count <= 0) return 0;
+  local_group *G = comms[0]->local;
+  if (!G) {
+    NCCLCHK(ncclGroupStart());
+    for (int g = 0; g < n; g++) {
+      ncclResult_t r = ncclAllReduce(devs[g]->ytmp + off, devs[g]->ytmp + off, (size_t)count, ncclDouble, ncclSum, comms[g]->comm, stream_of(streams, g));
+      if (r != ncclSuccess) { (void)ncclGroupEnd(); chol_set_error("ncclAllReduce failed: %s", ncclGetErrorString(r)); return CHOLAMD_ERR_COMM; }
+    }
+    NCCLCHK(ncclGroupEnd());
+    return 0;
+  }
+  for (int g = 0; g < n; g++) { HIPCHK(hipSetDevice(devs[g]->dev)); HIPCHK(hipEventRecord(G->ev[g], stream_of(streams, g))); }
+  HIPCHK(hipSetDevice(devs[0]->dev));
+  ptr_pack P;
+  for (int g = 0; g < n; g++) { P.p[g] = devs[g]->ytmp + off; if (g) HIPCHK(hipStreamWaitEvent(stream_of(streams, 0), G->ev[g], 0)); }
+  const int64_t blocks = (count + 255) / 256;
+  hipLaunchKernelGGL(k_sum_ranks<double>, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, stream_of(streams, 0), P, n, devs[0]->ytmp + off, count);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(G->ev[n], stream_of(streams, 0)));
+  for (int g = 1; g < n; g++) {
+    HIPCHK(hipSetDevice(devs[g]->dev));
+    HIPCHK(hipStreamWaitEvent(stream_of(streams, g), G->ev[n], 0));
+    HIPCHK(hipMemcpyPeerAsync(devs[g]->ytmp + off, devs[g]->dev, devs[0]->ytmp + off, devs[0]->dev, (size_t)count * sizeof(double), stream_of(streams, g)));
+    HIPCHK(hipEventRecord(G->ev[n + g], stream_of(streams, g)));
+  }
+  HIPCHK(hipSetDevice(devs[0]->dev));
+  for (int g = 1; g < n; g++) HIPCHK(hipStreamWaitEvent(stream_of(streams, 0), G->ev[n + g], 0)); // rank 0 goes on writing its vector
+  return 0;
+}
+template <class TL> static int solve_multi_t(cholamd_device *const *devs, const TL *const *arenas, const double *const *bs, double *const *xs, cholamd_comm *const *comms,
+                                             int n, void *const *streams)
+{
+  if (n < 1) { chol_set_error("no devices"); return CHOLAMD_ERR_ARG; }
+  if (n == 1) { HIPCHK(hipSetDevice(devs[0]->dev)); return solve_streamed(devs[0], arenas[0], bs[0], xs[0], stream_of(streams, 0)); }
+  local_group *G = comms[0] ? comms[0]->local : nullptr;
+  for (int g = 0; g < n; g++) {
+    if (devs[g]->world != n || devs[g]->rank != g) { chol_set_error("device %d is not partitioned as rank %d of %d", g, g, n); return CHOLAMD_ERR_ARG; }
+    if (comm_matches(devs[g], comms[g])) return CHOLAMD_ERR_ARG;
+    if (comms[g]->local != G || (!G && !comms[g]->comm)) { chol_set_error("the %d communicators are not of one kind", n); return CHOLAMD_ERR_ARG; }
+    HIPCHK(hipSetDevice(devs[g]->dev));
+    int rc = build_solve(devs[g], g, n);
+    if (rc) return rc;
+  }
+  const int64_t t0 = top_vec_offset(devs[0]), nn = devs[0]->plan->n;
+  for (int ph = 0; ph < 3; ph++) {
+    for (int g = 0; g < n; g++) {
+      HIPCHK(hipSetDevice(devs[g]->dev));
+      int rc = solve_phase(devs[g], arenas[g], bs[g], xs[g], ph, stream_of(streams, g));
+      if (rc) return rc;
+    }
+    if (ph < 2) { int rc = multi_sum_vec(devs, comms, n, streams, ph == 0 ? t0 : 0, ph == 0 ? nn - t0 : nn); if (rc) return rc; }
+  }
+  return 0;
+}
+extern "C" int cholamd_solve_multi(cholamd_device *const *devs, const double *const *arenas, const double *const *bs, double *const *xs, cholamd_comm *const *comms,
+                                   int n, void *const *streams)
+{
+  return solve_multi_t<double>(devs, arenas, bs, xs, comms, n, streams);
+}
+extern "C" int cholamd_solve_refine_multi(cholamd_device *const *devs, const float *const *arenas32, const double *const *bs, double *const *xs, int max_iter, double tol,
+                                          int *iters_out, double *relres_out, cholamd_comm *const *comms, int n, void *const *streams)
+{
+  if (n < 1) { chol_set_error("no devices"); return CHOLAMD_ERR_ARG; }
+  if (max_iter < 0) max_iter = 0;
+  for (int g = 0; g < n; g++) { HIPCHK(hipSetDevice(devs[g]->dev)); int rc = ensure_refine(devs[g]); if (rc) return rc; }
+  int rc = solve_multi_t<float>(devs, arenas32, bs, xs, comms, n, streams);
+  if (rc) return rc;
+  std::vector<const double *> rv(n);
+  std::vector<double *> dx(n);
+  for (int g = 0; g < n; g++) { rv[g] = devs[g]->rvec; dx[g] = devs[g]->dxvec; }
+  double rel = 0.0;
+  int it = 0;
+  for (;; ++it) {
+    for (int g = 0; g < n; g++) { // every rank forms the residual of its own (identical) iterate
+      double rg = 0.0;
+      HIPCHK(hipSetDevice(devs[g]->dev));
+      if ((rc = residual_norm(devs[g], bs[g], xs[g], devs[g]->rvec, &rg, stream_of(streams, g)))) return rc;
+      if (g == 0) rel = rg;
+    }
+    if (!(rel > tol) || it >= max_iter) break;
+    if ((rc = solve_multi_t<float>(devs, arenas32, rv.data(), dx.data(), comms, n, streams))) return rc;
+    for (int g = 0; g < n; g++) { HIPCHK(hipSetDevice(devs[g]->dev)); HIPCHK((hipError_t)chol_launch_axpy1(xs[g], devs[g]->dxvec, devs[g]->plan->n, stream_of(streams, g))); }
+  }
+  if (iters_out) *iters_out = it;
+  if (relres_out) *relres_out = rel;
+  if (rel != rel) { chol_set_error("iterative refinement produced NaN (fp32 factorisation broke down)"); return CHOLAMD_ERR_ARG; }
   return 0;
 }

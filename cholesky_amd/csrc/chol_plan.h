@@ -371,6 +371,7 @@ typedef struct {
 #define CHOL_SOLVE_FW_ROWS 256
 #define CHOL_SOLVE_BW_ROWS 512
 int chol_build_solve_level(const struct cholamd_plan *p, int level, chol_solve_level *out);
+int chol_build_solve_level_part(const struct cholamd_plan *p, int level, int rank, int world, chol_solve_level *out);
 void chol_solve_level_free(chol_solve_level *w);
 void chol_set_error(const char *fmt, ...);
 

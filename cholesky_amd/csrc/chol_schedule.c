@@ -1869,9 +1869,26 @@ static int block_runs(const chol_block *B, int lo, int hi, blk_run **out)
   return n;
 }
 
-int chol_build_solve_level(const plan_t *p, int level, chol_solve_level *w)
+int cholamd_plan_solve_counts(const cholamd_plan *p, int level, int rank, int world, int64_t out[5])
+{ /* host-side view of one rank's solve lists of a level: separators, (ancestor, separator) row runs, forward / backward row chunks, columns solved */
+  if (level < 0 || level >= p->levels || world < 1 || (world & (world - 1)) || rank < 0 || rank >= world || chol_split_level(world) > p->levels - 1) { chol_set_error("bad solve partition"); return CHOLAMD_ERR_ARG; }
+  chol_solve_level w;
+  int rc = chol_build_solve_level_part(p, level, rank, world, &w);
+  if (rc) return rc;
+  out[0] = w.n_trsv; out[1] = w.n_bw; out[2] = w.n_ifw; out[3] = w.n_ibw; out[4] = 0;
+  for (int i = 0; i < w.n_trsv; i++) out[4] += w.trsv[i].n;
+  chol_solve_level_free(&w);
+  return 0;
+}
+int chol_build_solve_level(const plan_t *p, int level, chol_solve_level *w) { return chol_build_solve_level_part(p, level, 0, 1, w); }
+/* the same for rank `rank` of `world` (distributed solve, mmat.rg:1394-1479 sharded like the factorisation): below the cut only the separators of
+ * the rank's own subtrees -- their TRSVs and their panels into every ancestor, the shared top included; the levels above the cut complete (every
+ * rank holds the whole factored top and solves it redundantly: only vectors travel) */
+int chol_build_solve_level_part(const plan_t *p, int level, int rank, int world, chol_solve_level *w)
 {
   memset(w, 0, sizeof *w);
+  const int cut = chol_split_level(world);
+#define SOLVE_MINE(s_) (world <= 1 || level < cut || chol_owner_of(p, (s_), world) == rank)
   const int h0 = 1 << level, h1 = (1 << (level + 1)) - 1, cnt = h1 - h0 + 1;
   int capb = cnt * (level > 0 ? level : 1);
   w->trsv = malloc(cnt * sizeof(chol_trsv_desc));
@@ -1879,6 +1896,7 @@ int chol_build_solve_level(const plan_t *p, int level, chol_solve_level *w)
   w->bw = malloc((size_t)capb * sizeof(chol_gemv_desc));
   for (int h = h0; h <= h1; h++) {
     int s = p->tree[h];
+    if (!SOLVE_MINE(s)) continue;
     chol_trsv_desc t = { p->panel_off[s], p->sep_size[s], p->panel_ld[s], p->sep_off[s], s, p->dinv_off[s] };
     if (p->sep_size[s] > w->max_n) w->max_n = p->sep_size[s];
     w->bw_start[w->n_trsv] = w->n_bw;
@@ -1914,6 +1932,7 @@ int chol_build_solve_level(const plan_t *p, int level, chol_solve_level *w)
         w->n_grp++;
         for (int h = hp << (level - pl); h < ((hp + 1) << (level - pl)); h++) {
           int s = p->tree[h];
+          if (!SOLVE_MINE(s)) continue;
           const chol_block *B = &p->blk[BIDX(p, par, s)];
           if (B->rows == 0 || B->cols == 0) continue;
           blk_run *rr; const int nr = block_runs(B, row0, row0 + 256, &rr);
@@ -1937,6 +1956,7 @@ int chol_build_solve_level(const plan_t *p, int level, chol_solve_level *w)
       for (int r0 = 0; r0 < w->bw[i].m; r0 += rows) { it[2 * k] = i; it[2 * k + 1] = r0; k++; }
     if (pass) { w->ibw = it; w->n_ibw = n; } else { w->ifw = it; w->n_ifw = n; }
   }
+#undef SOLVE_MINE
   return 0;
 }
 

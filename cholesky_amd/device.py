@@ -189,6 +189,20 @@ class Device:
                                           C.byref(it), C.byref(rel), _stream_ptr(stream)), "cholamd_solve_refine")
         return it.value, rel.value
 
+    def solve_sharded(self, arena, b, x, comm, stream=None):
+        """This rank's part of the distributed solve (cholamd_solve_sharded / _f32 by the arena's element type): only vectors travel."""
+        import torch
+        f32 = arena.elem_bytes == 4 if isinstance(arena, RankArena) else arena.dtype == torch.float32
+        fn = self.L.cholamd_solve_sharded_f32 if f32 else self.L.cholamd_solve_sharded
+        check(fn(self.h, self.ptr(arena), self.ptr(b), self.ptr(x), comm.h if comm is not None else None, _stream_ptr(stream)), "cholamd_solve_sharded")
+
+    def solve_refine_sharded(self, arena32, b, x, comm, max_iter=20, tol=1e-12, stream=None):
+        """cholamd_solve_refine_sharded: the fp64 refinement with the fp32 factor left on the ranks; returns (corrections, relres)."""
+        it, rel = C.c_int(0), C.c_double(0.0)
+        check(self.L.cholamd_solve_refine_sharded(self.h, self.ptr(arena32), self.ptr(b), self.ptr(x), max_iter, tol, C.byref(it), C.byref(rel),
+                                                  comm.h if comm is not None else None, _stream_ptr(stream)), "cholamd_solve_refine_sharded")
+        return int(it.value), float(rel.value)
+
     def residual(self, b, x, r=None, stream=None):
         """||b - A x|| / ||b|| in fp64 on the device (A = the matrix file's entries)."""
         rel = C.c_double(0.0)
@@ -272,3 +286,42 @@ def factor_multi(devs, arenas, local=True, streams=None):
     finally:
         for c in hc:
             L.cholamd_comm_destroy(c)
+
+
+def _multi_call(devs, local, body):
+    L = load()
+    n = len(devs)
+    hd = (C.c_void_p * n)(*[d.h for d in devs])
+    hc = (C.c_void_p * n)()
+    check((L.cholamd_comm_create_local if local else L.cholamd_comm_create_all)(hd, n, hc), "cholamd_comm_create")
+    try:
+        out = body(L, n, hd, hc)
+        for d in devs:
+            d.sync()
+        return out
+    finally:
+        for c in hc:
+            L.cholamd_comm_destroy(c)
+
+
+def solve_multi(devs, arenas, bs, xs, local=True):
+    """One process driving the n rank objects through the distributed solve (cholamd_solve_multi): the factor stays where
+    cholamd_factor_multi left it, every rank ends with the whole solution in xs[g]."""
+    def body(L, n, hd, hc):
+        ha = (C.c_void_p * n)(*[C.c_void_p(a.data_ptr()) for a in arenas])
+        hb = (C.c_void_p * n)(*[C.c_void_p(b.data_ptr()) for b in bs])
+        hx = (C.c_void_p * n)(*[C.c_void_p(x.data_ptr()) for x in xs])
+        check(L.cholamd_solve_multi(hd, ha, hb, hx, hc, n, None), "cholamd_solve_multi")
+    return _multi_call(devs, local, body)
+
+
+def solve_refine_multi(devs, arenas32, bs, xs, max_iter=20, tol=1e-12, local=True):
+    """cholamd_solve_refine_multi: fp64 refinement with the fp32 factor left on the ranks; returns (corrections, relres)."""
+    def body(L, n, hd, hc):
+        ha = (C.c_void_p * n)(*[C.c_void_p(a.data_ptr()) for a in arenas32])
+        hb = (C.c_void_p * n)(*[C.c_void_p(b.data_ptr()) for b in bs])
+        hx = (C.c_void_p * n)(*[C.c_void_p(x.data_ptr()) for x in xs])
+        it, rel = C.c_int(0), C.c_double(0.0)
+        check(L.cholamd_solve_refine_multi(hd, ha, hb, hx, max_iter, tol, C.byref(it), C.byref(rel), hc, n, None), "cholamd_solve_refine_multi")
+        return int(it.value), float(rel.value)
+    return _multi_call(devs, local, body)

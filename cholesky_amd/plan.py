@@ -156,6 +156,12 @@ class Plan:
         check(self.L.cholamd_plan_exchange_volume(self.h, rank, world, dist_top, out.ctypes.data), "cholamd_plan_exchange_volume")
         return tuple(int(v) for v in out)
 
+    def solve_counts(self, level, rank=0, world=1):
+        """(separators, row runs, forward chunks, backward chunks, columns solved) of one rank's solve lists of a level (cholamd_plan_solve_counts)."""
+        out = np.zeros(5, dtype=np.int64)
+        check(self.L.cholamd_plan_solve_counts(self.h, level, rank, world, out.ctypes.data), "cholamd_plan_solve_counts")
+        return tuple(int(v) for v in out)
+
     def exchange_pieces(self, world, dist_top=2):
         """The column-block pieces of that exchange as rows (arena offset, elements, owner rank, heap index of the top separator)."""
         out = np.zeros((4096, 4), dtype=np.int64)

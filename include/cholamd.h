@@ -429,6 +429,25 @@ int cholamd_gather_factor(cholamd_device *const *devs, double *const *arenas, in
 /* both for the fp32 factor */
 int cholamd_factor_multi_f32(cholamd_device *const *devs, float *const *arenas32, cholamd_comm *const *comms, int n, void *const *streams /* or NULL */);
 int cholamd_gather_factor_f32(cholamd_device *const *devs, float *const *arenas32, int n, void *const *streams /* or NULL */);
+/* Distributed solve (mmat.rg:1394-1479 sharded like the factorisation): every rank sweeps the separators of its own subtrees, the shared top of the
+ * tree -- which every rank holds completely after cholamd_factor_sharded / _multi -- is solved redundantly, and only VECTORS travel: one sum over the
+ * ranks of the top's part of the right-hand side after the forward sweep under the cut, one sum of the solution at the end (RCCL all-reduces;
+ * device-side ordered sums + peer copies over a local communicator).  Every rank passes the same b and ends with the same x.  _f32: an fp32 factor
+ * (solution to fp32-factor accuracy); cholamd_solve_refine_sharded: the fp64 iterative refinement of cholamd_solve_refine, every rank running the same
+ * loop on identical iterates (residual against A on every rank, corrections solved as above).  No cholamd_gather_to_root is needed for either. */
+/* host-side view of rank's share of the solve lists of one tree level: out = { separators, (ancestor, separator) row runs, forward row chunks, backward row
+ * chunks, columns solved }; below the cut the ranks' shares tile the undivided lists, above it every rank holds them whole */
+int cholamd_plan_solve_counts(const cholamd_plan *p, int level, int rank, int world, int64_t out[5]);
+int cholamd_solve_sharded(cholamd_device *d, const double *d_arena, const double *d_b, double *d_x, cholamd_comm *c, void *stream);
+int cholamd_solve_sharded_f32(cholamd_device *d, const float *d_arena32, const double *d_b, double *d_x, cholamd_comm *c, void *stream);
+int cholamd_solve_refine_sharded(cholamd_device *d, const float *d_arena32, const double *d_b, double *d_x, int max_iter, double tol,
+                                 int *iters_out, double *relres_out, cholamd_comm *c, void *stream);
+/* the same driven by one process for n rank objects (communicators of cholamd_comm_create_all or cholamd_comm_create_local); bs[g], xs[g]: rank g's
+ * device copies of b and x */
+int cholamd_solve_multi(cholamd_device *const *devs, const double *const *arenas, const double *const *bs, double *const *xs, cholamd_comm *const *comms,
+                        int n, void *const *streams);
+int cholamd_solve_refine_multi(cholamd_device *const *devs, const float *const *arenas32, const double *const *bs, double *const *xs, int max_iter, double tol,
+                               int *iters_out, double *relres_out, cholamd_comm *const *comms, int n, void *const *streams);
 
 /* ----------------------------------------------------------------------------------------- */
 /* L-B: task level -- the four fused leaf tasks of blas.rg.  A region is a block instance:     */

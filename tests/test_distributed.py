@@ -77,6 +77,94 @@ def test_partition_logic_gloo(case, world):
     assert ok_tail and ok_lists and ok_src and tail > 0
 
 
+def _solve_worker(rank, world, port, case, q):
+    """One rank of the distributed solve restated with dense numpy blocks of the oracle's L (the vector flow of cholamd_solve_sharded: own subtrees
+    forward, sum of the top's part of y, the top redundantly, own subtrees backward, sum of the solution), and its lists against the undivided ones."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cholesky_amd as ca
+    from oracle import oracle as orc
+    orc.use_own_kernels()
+    m, o, c, bfile = case_paths(case)
+    plan = ca.Plan(m, o, c)
+    O = orc.Oracle(m, o, c)
+    O.factor()
+    Lf = np.tril(O.dense())
+    pb = ca.plan.read_vector(bfile, plan.n)[plan.perm]
+    levels, d = plan.levels, world.bit_length() - 1
+    tree, off, size = plan.tree, plan.sep_offsets, plan.sep_sizes  # tree[h - 1] = label of heap index h; off / size by label - 1
+    rng = lambda s: slice(int(off[s - 1]), int(off[s - 1] + size[s - 1]))
+    mine = lambda h: (h.bit_length() - 1) < d or (h >> ((h.bit_length() - 1) - d)) - world == rank
+    y = np.zeros(plan.n)
+    for h in range(1, plan.nsep + 1):
+        if (mine(h) and (h.bit_length() - 1) >= d) or ((h.bit_length() - 1) < d and rank == 0):
+            y[rng(tree[h - 1])] = pb[rng(tree[h - 1])]
+
+    def forward(lvls):
+        for lv in lvls:
+            for h in range(1 << lv, 1 << (lv + 1)):
+                if not mine(h):
+                    continue
+                s = rng(tree[h - 1])
+                y[s] = np.linalg.solve(Lf[s, s], y[s])
+                a = h // 2
+                while a >= 1:
+                    ra = rng(tree[a - 1])
+                    y[ra] -= Lf[ra, s] @ y[s]
+                    a //= 2
+
+    def backward(lvls):
+        for lv in lvls:
+            for h in range(1 << lv, 1 << (lv + 1)):
+                if not mine(h):
+                    continue
+                s = rng(tree[h - 1])
+                a = h // 2
+                while a >= 1:
+                    ra = rng(tree[a - 1])
+                    y[s] -= Lf[ra, s].T @ y[ra]
+                    a //= 2
+                y[s] = np.linalg.solve(Lf[s, s].T, y[s])
+
+    t0 = int(off[tree[world - 2] - 1]) if world > 1 else plan.n  # the top separators (heap 1 .. world - 1) are the last labels: a contiguous tail
+    forward(range(levels - 1, d - 1, -1))
+    top = torch.from_numpy(y[t0:].copy())
+    dist.all_reduce(top)
+    y[t0:] = top.numpy()
+    forward(range(d - 1, -1, -1))
+    backward(range(0, levels))
+    if rank != 0:
+        y[t0:] = 0.0
+    full = torch.from_numpy(y.copy())
+    dist.all_reduce(full)
+    xo = O.solve(ca.plan.read_vector(bfile, plan.n))[plan.perm]
+    ok_x = bool(np.abs(full.numpy() - xo).max() <= 1e-10 * max(1.0, np.abs(xo).max()))
+    cnt = torch.tensor([plan.solve_counts(l, rank, world) for l in range(levels)], dtype=torch.int64)
+    whole = torch.tensor([plan.solve_counts(l) for l in range(levels)], dtype=torch.int64)
+    below = cnt.clone()
+    below[:d] = 0
+    dist.all_reduce(below)
+    ok_lists = bool(torch.equal(below[d:], whole[d:])) and bool(torch.equal(cnt[:d], whole[:d]))  # shares tile the lists under the cut, the top is whole on every rank
+    if rank == 0:
+        q.put((ok_x, ok_lists, t0))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,world", [("lapl_400x400", 2), ("lapl_400x400", 8), ("lapl_3375x3375", 2)])
+def test_distributed_solve_logic_gloo(case, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_solve_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    ok_x, ok_lists, t0 = q.get()
+    assert ok_x and ok_lists and t0 > 0
+
+
 @pytest.mark.parametrize("dims,world", [((20, 20, 20, 4, 32), 2), ((20, 20, 20, 4, 32), 4), ((30, 30, 10, 5, 32), 8)])
 def test_distributed_top_lists_tile_the_schedule(dims, world):
     """Generated problems with top separators of several column blocks: under dist_top the ranks' POTRF blocks, TRSM strips and
@@ -494,3 +582,54 @@ def test_only_the_ranks_under_a_top_separator_touch_its_blocks(case, world, mixe
         tail = parallel.tail_offset(plan, world)
         tot = sum(p[tail:] for p in parts)
         assert np.abs(tot - ref[tail:]).max() <= 2e-5 * max(1.0, np.abs(ref[tail:]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,world,dist_top", [("lapl_3375x3375", 2, 0), ("lapl_3375x3375", 8, 1), ((20, 20, 20, 4, 32), 4, 1), ((24, 24, 24, 5, 32), 8, 1),
+                                                 ((24, 24, 24, 5, 32), 4, 0)])
+def test_distributed_solve_over_the_local_communicator(case, world, dist_top):
+    """The solve sharded like the factorisation (mmat.rg:1394-1479): every rank sweeps its own subtrees, the top is solved
+    redundantly, only two vector sums travel (cholamd_solve_multi over the local communicator -- the rank objects share the one GPU); no rank
+    ever holds the other ranks' panels.  Against the single-GPU solve of the same right-hand side and, through the residual, against A."""
+    import torch
+    import cholesky_amd as ca
+    from cholesky_amd.device import factor_multi, solve_multi
+    if isinstance(case, str):
+        m, o, c, bfile = case_paths(case)
+        plan = ca.Plan(m, o, c)
+        bvec = ca.plan.read_vector(bfile, plan.n)
+    else:
+        prob = ca.Problem(*case)
+        plan = prob.plan()
+        bvec = prob.rhs()
+    one = ca.Device(plan, 0)
+    ref = one.new_arena()
+    one.fill(ref)
+    one.factor(ref)
+    d_b = torch.from_numpy(bvec).cuda()
+    x1 = torch.empty_like(d_b)
+    one.solve(ref, d_b, x1)
+    one.sync()
+    devs, arenas = [], []
+    for r in range(world):
+        dev = ca.Device(plan, 0)
+        dev.set_option("dist_top", dist_top)
+        dev.set_partition(r, world)
+        a = dev.new_arena()
+        dev.fill(a)
+        devs.append(dev)
+        arenas.append(a)
+    factor_multi(devs, arenas, local=True)
+    xs = [torch.full_like(d_b, float("nan")) for _ in range(world)]
+    solve_multi(devs, arenas, [d_b] * world, xs, local=True)
+    xr = x1.cpu().numpy()
+    scale = max(1.0, np.abs(xr).max())
+    for r in range(world):
+        assert np.abs(xs[r].cpu().numpy() - xr).max() <= 1e-10 * scale, r   # every rank ends with the whole solution
+    assert one.residual(d_b, xs[world - 1]) <= 1e-10
+    # a second right-hand side through the same lists, and the full-tree solve of a partitioned device is still there (gathered factor)
+    b2 = torch.from_numpy(np.cos(np.arange(plan.n) * 0.37) + 2.0).cuda()
+    solve_multi(devs, arenas, [b2] * world, xs, local=True)
+    one.solve(ref, b2, x1)
+    one.sync()
+    assert np.abs(xs[0].cpu().numpy() - x1.cpu().numpy()).max() <= 1e-10 * max(1.0, float(x1.abs().max()))

@@ -184,6 +184,16 @@ def test_mixed_precision_sharded_over_the_local_communicator(dims, world, dist_t
     factor_multi(devs, arenas, local=True)
     for dev in devs:
         assert dev.info() == (0, 0)
+    # the refinement with the fp32 factor LEFT on the ranks (cholamd_solve_refine_multi: only vectors travel), before anything is gathered
+    from cholesky_amd.device import solve_refine_multi
+    bvec = prob.rhs()
+    xo = O.solve(bvec)
+    d_b = torch.from_numpy(bvec).cuda()
+    xs = [torch.full_like(d_b, float("nan")) for _ in range(world)]
+    iters, rel = solve_refine_multi(devs, arenas, [d_b] * world, xs, max_iter=20, tol=1e-13, local=True)
+    assert rel <= 1e-12 and iters <= 8, (iters, rel)
+    for r in range(world):
+        assert np.abs(xs[r].cpu().numpy() - xo).max() <= TOL_X * max(1.0, np.abs(xo).max()), r
     L = _lib.load()
     n = world
     hd = (C.c_void_p * n)(*[d.h for d in devs])
@@ -196,10 +206,7 @@ def test_mixed_precision_sharded_over_the_local_communicator(dims, world, dist_t
     assert np.abs(full32 - r32).max() <= 2e-5 * scale
     Lo = np.tril(O.dense())
     assert np.abs(np.tril(plan.arena_to_dense(full32)) - Lo).max() <= 2e-5 * np.abs(Lo).max()
-    # refinement on rank 0 with the gathered fp32 factor
-    bvec = prob.rhs()
-    xo = O.solve(bvec)
-    d_b = torch.from_numpy(bvec).cuda()
+    # refinement on rank 0 with the gathered fp32 factor (the full-tree lists on a partitioned device)
     d_x = torch.empty_like(d_b)
     iters, rel = devs[0].solve_refine(arenas[0], d_b, d_x, max_iter=20, tol=1e-13)
     assert rel <= 1e-12 and iters <= 8, (iters, rel)
