@@ -633,3 +633,48 @@ def test_distributed_solve_over_the_local_communicator(case, world, dist_top):
     one.solve(ref, b2, x1)
     one.sync()
     assert np.abs(xs[0].cpu().numpy() - x1.cpu().numpy()).max() <= 1e-10 * max(1.0, float(x1.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dist_top", [1, 0])
+def test_one_process_two_gpus_over_rccl(dist_top):
+    """cholamd_factor_multi and cholamd_solve_multi with cholamd_comm_create_all (one process, one GPU per rank, RCCL between them) and the top levels
+    distributed: the path in which the owners' sums have to wait for the OUTERMOST RCCL group and the grouped ncclSend / ncclRecv of
+    the path-aware exchange run for real.  Needs two GPUs (skipped on the round's one-GPU boxes)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (the round's test box has one)")
+    import cholesky_amd as ca
+    from cholesky_amd.device import factor_multi, solve_multi
+    prob = ca.Problem(24, 24, 24, 5, 32)
+    plan = prob.plan()
+    one = ca.Device(plan, 0)
+    ref = one.new_arena()
+    one.fill(ref)
+    one.factor(ref)
+    d_b = torch.from_numpy(prob.rhs()).cuda(0)
+    x1 = torch.empty_like(d_b)
+    one.solve(ref, d_b, x1)
+    one.sync()
+    world = 2
+    devs, arenas, bs, xs = [], [], [], []
+    for r in range(world):
+        dev = ca.Device(plan, r)
+        dev.set_option("dist_top", dist_top)
+        dev.set_partition(r, world)
+        with torch.cuda.device(r):
+            a = dev.new_arena()
+            dev.fill(a)
+            bs.append(d_b.to(f"cuda:{r}"))
+            xs.append(torch.empty_like(bs[-1]))
+        devs.append(dev)
+        arenas.append(a)
+    factor_multi(devs, arenas, local=False)
+    for dev in devs:
+        assert dev.info() == (0, 0)
+    refh = ref.cpu().numpy()
+    parts = [a.cpu().numpy() for a in arenas]
+    assert np.abs(_assemble(plan, parts, world, refh) - refh).max() <= 1e-12 * max(1.0, np.abs(refh).max())
+    solve_multi(devs, arenas, bs, xs, local=False)
+    xr = x1.cpu().numpy()
+    for r in range(world):
+        assert np.abs(xs[r].cpu().numpy() - xr).max() <= 1e-10 * max(1.0, np.abs(xr).max())
