@@ -214,6 +214,9 @@ def main():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="cholamd_device_set_option switch for this run (e.g. program=0: level-by-level launches), repeatable; recorded in config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rank-arenas", type=int, default=0, help="--gpus N > 1: 1 = every rank's arenas by cholamd_device_alloc_arena (memory only under the rank's own "
+                                                               "panels and the shared top: 7.5 of 34.8 GB per rank at 100^3 / world 8); default 0 = plain allocations "
+                                                               "(no box with two GPUs has run the VMM arenas under RCCL yet: the driver's multi-GPU run keeps the plain ones)")
     ap.add_argument("--large-front", type=int, default=None, help="1: add the `large_front` object (60^3 fp64, 100^3 fp64 + mixed on this GPU) to the line; "
                                                                    "default: on for the metric's own configuration (no --case / --precision / --option, one GPU), else off")
     ap.add_argument("--sustained", type=int, default=2000, help="extra figure beside the metric: the same step for this many factorisations (0 = skip)")
@@ -283,7 +286,11 @@ def main():
     stream = torch.cuda.current_stream()
     per_arena = plan.arena_doubles * (4 if mixed else 8)
     n_arenas = max(1, min(K + W, int((8e9 if not generated else 4e10) // per_arena)))
-    arenas = [dev.new_arena_f32() if mixed else dev.new_arena() for _ in range(n_arenas)]
+    rank_arenas = bool(args.rank_arenas) and world > 1
+    if rank_arenas:
+        arenas = [dev.alloc_arena(4 if mixed else 8) for _ in range(n_arenas)]
+    else:
+        arenas = [dev.new_arena_f32() if mixed else dev.new_arena() for _ in range(n_arenas)]
     fill = dev.fill_f32 if mixed else dev.fill
 
     def refill():
@@ -462,7 +469,7 @@ def main():
         kernel0 = benchline.kernel_names(mixed, generated, all(t["trsm"][1] == 0 for t in timing_all))[benchline.dominant(timing_all)[0]].split(" + ")[0]
         rec = {
             "world": world, "steps": K, "warmup": W, "dt_s": dt, "case": args.case, "generated": generated, "mixed": mixed,
-            "options": args.option, "info": list(info),
+            "options": args.option + (["rank_arenas=1"] if rank_arenas else []), "info": list(info),
             "plan": {"n": plan.n, "levels": plan.levels, "nsep": plan.nsep, "flops": plan.flops, "alg_bytes": plan.alg_bytes,
                      "flops_by_kind": {"potrf": float(flops[0]), "trsm": float(flops[1]), "update": float(flops[2] + flops[3])},
                      "piv_entries": sum(n * (n + 1) // 2 for n in sizes.values()),
