@@ -2600,6 +2600,95 @@ __global__ __launch_bounds__(256) void k_solve_trsv(const TL *__restrict__ base,
   }
   if (col0 + tid < n) x[col0 + tid] = sxs[tid];
 }
+// The diagonal solve of one 256-column span out of an fp32 factor (round 4; the spans of the wide top separators are two thirds of a solve at 100^3: 101 per
+// direction, 23 / 26 us each in k_solve_trsv).  One thread per row (forward) / column (backward) of the span; EVERY entry of the span's triangle the thread
+// will need -- its row left of its own 16-block, or its column below it: up to 240 floats -- is requested before the first block is solved (a 256-thread
+// workgroup alone on its CU owns 512 registers per lane), and so is its block's 16x16 inverse.  Then sixteen block steps with ONE barrier each: the sixteen
+// lanes that hold block j's right-hand side form x_j = Linv_j r_j in registers (sixteen DPP multiply-adds: lane k of the row supplies r_k), publish it in
+// LDS, and every thread on the far side of the block subtracts its sixteen products.  No triangle in LDS, no shuffles, no second barrier: the next block's
+// lanes go on from their own registers.
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_solve_span32(const float *__restrict__ base, const chol_trsv_desc *__restrict__ descs, const double *__restrict__ Wall,
+                                                      double *__restrict__ y, int col0)
+{
+  __shared__ double sx[SSPAN];
+  const chol_trsv_desc d = descs[blockIdx.x];
+  if (d.n <= col0) return;
+  const int lda = d.lda, tid = threadIdx.x, myb = tid >> 4, l16 = tid & 15;
+  const int ns = min(d.n - col0, SSPAN), nb = (ns + TS - 1) / TS;
+  const float *Lm = base + d.a_off + col0 + (int64_t)col0 * lda; // element (0, 0) of the span's diagonal block
+  const double *Wb = Wall + d.dinv_off + (int64_t)(col0 / TS + min(myb, nb - 1)) * TS * TS; // Wb[k * 16 + c] = Linv(c, k) of the thread's own block
+  double *x = y + d.x_off + col0;
+  float lrow[(SSPAN / TS - 1) * TS], ltail[TS];
+  double wl[TS];
+  const bool live = tid < ns;
+  const int nfull = ns / TS; // blocks of sixteen whole rows; block nfull (if nfull < nb) is the ragged one
+#pragma unroll
+  for (int k = 0; k < TS; ++k) wl[k] = BWD ? Wb[l16 * TS + k] : Wb[k * TS + l16]; // forward: Linv(l, k); backward: Linv(k, l)
+  double r = live ? x[tid] : 0.0;
+  if (!BWD) { // row tid: the columns of the blocks in front of its own
+    const float *Lr = Lm + tid;
+#pragma unroll
+    for (int j = 0; j < SSPAN / TS - 1; ++j) {
+      if (live && j < myb) {
+#pragma unroll
+        for (int k = 0; k < TS; ++k) lrow[j * TS + k] = Lr[(int64_t)(j * TS + k) * lda];
+      } else {
+#pragma unroll
+        for (int k = 0; k < TS; ++k) lrow[j * TS + k] = 0.0f;
+      }
+    }
+  } else { // column tid: the rows of the blocks below its own (slot j - 1 = block j); sixteen consecutive floats per block: 16-byte loads
+    const float *Lc = Lm + (int64_t)min(tid, ns - 1) * lda;
+#pragma unroll
+    for (int j = 1; j < SSPAN / TS; ++j) {
+      if (live && j > myb && j < nfull) {
+#pragma unroll
+        for (int k4 = 0; k4 < TS; k4 += 4) {
+          const float4 v = *(const float4 *)&Lc[j * TS + k4];
+          lrow[(j - 1) * TS + k4] = v.x; lrow[(j - 1) * TS + k4 + 1] = v.y; lrow[(j - 1) * TS + k4 + 2] = v.z; lrow[(j - 1) * TS + k4 + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < TS; ++k) lrow[(j - 1) * TS + k] = 0.0f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < TS; ++k) { // the ragged last block: its rows past the span's end do not exist (clamped address, zero value)
+      const int row = nfull * TS + k;
+      const float v = Lc[min(row, ns - 1)];
+      ltail[k] = (live && nfull > myb && row < ns) ? v : 0.0f;
+    }
+  }
+#pragma unroll
+  for (int jb = 0; jb < SSPAN / TS; ++jb) {
+    const int j = BWD ? SSPAN / TS - 1 - jb : jb; // compile time: the register indices below are constants
+    if (j < nb) {
+      if (myb == j) { // the block's own sixteen lanes: x_j = Linv_j r_j (backward: its transpose), lane k of the row supplies r_k
+        double xj = 0.0;
+#define SPAN_FM(K_) fmac_bcast<K_, K_ == 0>(xj, r, wl[K_]);
+        SPAN_FM(0) SPAN_FM(1) SPAN_FM(2) SPAN_FM(3) SPAN_FM(4) SPAN_FM(5) SPAN_FM(6) SPAN_FM(7)
+        SPAN_FM(8) SPAN_FM(9) SPAN_FM(10) SPAN_FM(11) SPAN_FM(12) SPAN_FM(13) SPAN_FM(14) SPAN_FM(15)
+#undef SPAN_FM
+        r = xj;
+        sx[tid] = xj;
+      }
+      __syncthreads();
+      if (BWD ? myb < j : myb > j) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < TS; ++k) { // the value stays a float in its register until here: a conversion hoisted to the load would wait for it there
+          float v = (BWD && j == nfull) ? ltail[k] : lrow[(BWD ? j - 1 : j) * TS + k];
+          asm volatile("" : "+v"(v));
+          acc += (double)v * sx[j * TS + k];
+        }
+        r -= acc;
+      }
+    }
+  }
+  if (live) x[tid] = r;
+}
+
 // rows of a wide separator under a span that one workgroup of k_solve_panel folds / gathers.  The spans of the top separators are the solve's chain and
 // at the root there is ONE separator: with 512-row chunks a span step of the 10^4-column root kept 10 CUs busy on average
 #ifndef SPANEL_BW_ROWS
@@ -2755,6 +2844,18 @@ template <class TL> static int launch_solve_dinv_t(const TL *base, const chol_tr
   hipLaunchKernelGGL(k_solve_dinv<TL>, dim3(n, (max_n + TS - 1) / TS), dim3(64), 0, st, base, descs, W);
   return (int)hipGetLastError();
 }
+#ifndef SOLVE_SPAN32
+#define SOLVE_SPAN32 1 /* 0: the fp32 factor's spans through k_solve_trsv<., float> like the fp64 factor's (A/B) */
+#endif
+template <bool BWD> static void launch_span(const double *base, const chol_trsv_desc *descs, int n, const double *W, double *y, int col0, hipStream_t st)
+{
+  hipLaunchKernelGGL((k_solve_trsv<BWD, double>), dim3(n), dim3(256), 0, st, base, descs, W, y, col0);
+}
+template <bool BWD> static void launch_span(const float *base, const chol_trsv_desc *descs, int n, const double *W, double *y, int col0, hipStream_t st)
+{
+  if (SOLVE_SPAN32) hipLaunchKernelGGL((k_solve_span32<BWD>), dim3(n), dim3(256), 0, st, base, descs, W, y, col0);
+  else hipLaunchKernelGGL((k_solve_trsv<BWD, float>), dim3(n), dim3(256), 0, st, base, descs, W, y, col0);
+}
 template <class TL> static int launch_solve_trsv_t(const TL *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, hipStream_t st)
 { // all separators of a level; wide ones in spans of SSPAN columns: diagonal span by one workgroup each, the rows below by all CUs
   if (n <= 0) return 0;
@@ -2764,9 +2865,9 @@ template <class TL> static int launch_solve_trsv_t(const TL *base, const chol_tr
     const int below = max_n - (col0 + SSPAN); // rows under the span in the widest separator
     if (backward) {
       if (below > 0) hipLaunchKernelGGL((k_solve_panel<true, TL>), dim3(n, (below + SPANEL_BW_ROWS - 1) / SPANEL_BW_ROWS), dim3(256), 0, st, base, descs, y, col0);
-      hipLaunchKernelGGL((k_solve_trsv<true, TL>), dim3(n), dim3(256), 0, st, base, descs, W, y, col0);
+      launch_span<true>(base, descs, n, W, y, col0, st);
     } else {
-      hipLaunchKernelGGL((k_solve_trsv<false, TL>), dim3(n), dim3(256), 0, st, base, descs, W, y, col0);
+      launch_span<false>(base, descs, n, W, y, col0, st);
       if (below > 0) hipLaunchKernelGGL((k_solve_panel<false, TL>), dim3(n, (below + 255) / 256), dim3(256), 0, st, base, descs, y, col0);
     }
   }
