@@ -2689,6 +2689,82 @@ __global__ __launch_bounds__(256) void k_solve_span32(const float *__restrict__ 
   if (live) x[tid] = r;
 }
 
+// ---- column sums over a wave without the LDS crossbar (round 4) ----
+// The backward sweep needs sum_i L(i, c) x(i) with the rows i along the lanes (the coalesced direction of a column-major panel): a reduction over the 64
+// lanes per column.  Six __shfl_down stages per column are twelve ds_bpermute_b32 each, and the one LDS pipe of a CU bounded the whole backward sweep
+// (2.4 TB/s on the leaf level of 100^3, 1.47 ms of an 11 ms solve).  gfx950 swaps half-waves and 16-lane rows BETWEEN two registers in one VALU
+// instruction (v_permlane32_swap, v_permlane16_swap): two columns' partial sums fold into one register per stage, so sixteen columns cost 8 + 4 swaps-and-adds
+// and four registers of four 16-lane rows, each finished by four DPP rotations -- 84 VALU instructions on four SIMDs in place of 192 bpermutes on one pipe.
+typedef unsigned chol_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double fold32(double a, double b)
+{ // lanes 0-31: a(l) + a(l + 32); lanes 32-63: b(l - 32) + b(l)
+  const chol_u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const chol_u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ double fold16(double a, double b)
+{ // 16-lane rows: (a.row0 + a.row1, b.row0 + b.row1, a.row2 + a.row3, b.row2 + b.row3)
+  const chol_u2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const chol_u2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov64(double v)
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum16(double v)
+{ // every lane: the sum over its 16-lane row
+  v += dpp_mov64<0x128>(v); // row_ror:8
+  v += dpp_mov64<0x124>(v); // row_ror:4
+  v += dpp_mov64<0x4e>(v);  // quad_perm [2,3,0,1]
+  v += dpp_mov64<0xb1>(v);  // quad_perm [1,0,3,2]
+  return v;
+}
+// the sums over all 64 lanes of acc[0..15]: lane l with (l & 15) < 4 returns the sum of column wave_sum16_col(l); the other lanes return junk
+__device__ __forceinline__ int wave_sum16_col(int lane) { return 4 * (lane & 3) + ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1); }
+__device__ __forceinline__ double wave_sum16(const double (&acc)[16], int lane)
+{
+  double t[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { // rows of t[i]: columns 4 i + (0, 2, 1, 3)
+    const double s0 = fold32(acc[4 * i], acc[4 * i + 1]), s1 = fold32(acc[4 * i + 2], acc[4 * i + 3]);
+    t[i] = row_sum16(fold16(s0, s1));
+  }
+  const int i = lane & 3;
+  return i == 0 ? t[0] : i == 1 ? t[1] : i == 2 ? t[2] : t[3];
+}
+// y(c) -= sum over the chunk's rows of A(i, c) x(i) for the columns [0, ncols) of a column-major block: `A` points at (first row of the chunk, column 0),
+// `mrows` rows of the chunk exist (<= 64 PER), xa[u] = x(row lane + 64 u) (0 past the end).  Wave `wave` of four takes the columns 16 (wave + 4 k) ..+15:
+// 16 PER loads in flight per lane, one wave_sum16 and ONE atomic instruction (16 lanes) per sixteen columns.
+template <int PER, class TL>
+__device__ __forceinline__ void gather_columns(const TL *__restrict__ A, int lda, int mrows, int ncols, const double (&xa)[PER], double *__restrict__ yc, int lane, int wave)
+{
+  int ro[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) ro[u] = min(lane + 64 * u, mrows - 1);
+  for (int c0 = 16 * wave; c0 < ncols; c0 += 64) {
+    TL a[16][PER];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const TL *Ac = A + (int64_t)min(c0 + q, ncols - 1) * lda;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) a[q][u] = Ac[ro[u]]; // unconditional (clamped rows repeat the last one, x = 0 there): a predicate here serialises the loads
+    }
+    double acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      acc[q] = (double)a[q][0] * xa[0];
+#pragma unroll
+      for (int u = 1; u < PER; ++u) acc[q] += (double)a[q][u] * xa[u];
+    }
+    const double sum = wave_sum16(acc, lane);
+    const int c = c0 + wave_sum16_col(lane);
+    if ((lane & 15) < 4 && c < ncols) unsafeAtomicAdd(&yc[c], -sum);
+  }
+}
+
 // rows of a wide separator under a span that one workgroup of k_solve_panel folds / gathers.  The spans of the top separators are the solve's chain and
 // at the root there is ONE separator: with 512-row chunks a span step of the 10^4-column root kept 10 CUs busy on average
 #ifndef SPANEL_BW_ROWS
@@ -2712,12 +2788,12 @@ __global__ __launch_bounds__(256) void k_solve_panel(const TL *__restrict__ base
     const int r = r0 + blockIdx.y * 256 + tid;
     const TL *A = Lm + min(r, n - 1) + (int64_t)col0 * lda;
     double acc = 0.0;
-    for (int k = 0; k < SSPAN; k += 16) { // sixteen loads in flight per thread
-      TL a[16];
+    for (int k = 0; k < SSPAN; k += 32) { // thirty-two loads in flight per thread
+      TL a[32];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) a[u] = A[(int64_t)(k + u) * lda];
+      for (int u = 0; u < 32; ++u) a[u] = A[(int64_t)(k + u) * lda];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) acc += (double)a[u] * sx[k + u];
+      for (int u = 0; u < 32; ++u) acc += (double)a[u] * sx[k + u];
     }
     if (r < n) x[r] -= acc;
   } else {
@@ -2730,48 +2806,37 @@ __global__ __launch_bounds__(256) void k_solve_panel(const TL *__restrict__ base
       const int i = row0 + lane + 64 * u;
       xa[u] = i < n ? x[i] : 0.0;
     }
-    constexpr int CPR = 32 / PER; // columns per round: 32 loads in flight per lane (one column at a time was one memory round trip per column, sixty-four
-                                  // in a row per wave)
-    static_assert(SSPAN % (4 * CPR) == 0, "columns per round");
-    for (int c = wave; c < SSPAN; c += 4 * CPR) {
-      TL a[CPR][PER];
-#pragma unroll
-      for (int q = 0; q < CPR; ++q) {
-        const TL *Ac = Lm + (int64_t)(col0 + c + 4 * q) * lda;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) a[q][u] = Ac[min(row0 + lane + 64 * u, n - 1)];
-      }
-#pragma unroll
-      for (int q = 0; q < CPR; ++q) {
-        double acc = 0.0;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) acc += (double)a[q][u] * xa[u];
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-        if (lane == 0) unsafeAtomicAdd(&x[col0 + c + 4 * q], -acc);
-      }
-    }
+    gather_columns<PER>(Lm + row0 + (int64_t)col0 * lda, lda, min(n - row0, SPANEL_BW_ROWS), SSPAN, xa, x + col0, lane, wave);
   }
 }
 
-// forward: y_anc[rows] -= A(rows, :) y_s for one row chunk of the block A = (anc, s); y_s staged through LDS
+// forward: y_anc[rows] -= A(rows, cols) y_s for one (row chunk, column chunk) of the block A = (anc, s); y_s staged through LDS.  items = (block, first
+// row, first column) triples: the column chunks (CHOL_SOLVE_COLS) give the few tall blocks of the top levels enough workgroups to fill the chip
 template <class TL>
 __global__ __launch_bounds__(256) void k_solve_gemv_fwd(const TL *__restrict__ base, const chol_gemv_desc *__restrict__ blocks, const int *__restrict__ items,
                                                         double *__restrict__ y)
 {
   __shared__ double sx[256];
-  const chol_gemv_desc d = blocks[items[2 * blockIdx.x]];
-  const int r = items[2 * blockIdx.x + 1] + threadIdx.x;
+  const chol_gemv_desc d = blocks[items[3 * blockIdx.x]];
+  const int r = items[3 * blockIdx.x + 1] + threadIdx.x, c0 = items[3 * blockIdx.x + 2], c1 = min(d.n, c0 + CHOL_SOLVE_COLS);
   const TL *A = base + d.a_off + min(r, d.m - 1);
   const double *xs = y + d.y_off; // the separator's (already solved) part
   double acc = 0.0;
-  for (int k0 = 0; k0 < d.n; k0 += 256) {
-    const int kb = min(256, d.n - k0);
+  for (int k0 = c0; k0 < c1; k0 += 256) {
+    const int kb = min(256, c1 - k0);
     __syncthreads();
     if ((int)threadIdx.x < kb) sx[threadIdx.x] = xs[k0 + threadIdx.x];
     __syncthreads();
     const TL *Ak = A + (int64_t)k0 * d.lda;
     int k = 0;
-    for (; k + 16 <= kb; k += 16) { // sixteen loads in flight per thread
+    for (; k + 32 <= kb; k += 32) { // thirty-two loads in flight per thread: with sixteen, 32 waves x 256 B x (the ~60 % of lanes a leaf's blocks fill) is
+      TL a[32];                     // under the ~90 KB a CU must keep in flight for its share of HBM
+#pragma unroll
+      for (int u = 0; u < 32; ++u) a[u] = Ak[(int64_t)(k + u) * d.lda];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) acc += (double)a[u] * sx[k + u];
+    }
+    for (; k + 16 <= kb; k += 16) {
       TL a[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) a[u] = Ak[(int64_t)(k + u) * d.lda];
@@ -2790,52 +2855,54 @@ __global__ __launch_bounds__(256) void k_solve_gemv_fwd(const TL *__restrict__ b
   if (r < d.m) unsafeAtomicAdd(&y[d.x_off + r], -acc);
 }
 
-// backward: y_s[c] -= A(rows, c)^T y_anc[rows] for one row chunk of the block; every lane keeps its rows' y_anc in
-// registers, wave w takes the columns w, w+4, ...
+// backward: y_s[c] -= sum over the rows of the separator's panel below its diagonal block of A(i, c) y_anc(i).  One workgroup = 64 columns of ONE separator
+// and a run of its row-run descriptors (q0 .. q1: all of them, unless the level has too few separators to fill the chip): the sums stay in registers
+// over every block the separator has into its ancestors and reach y with ONE atomic per column per workgroup.  (Per (block, 512-row chunk) the leaf
+// level of 100^3 issued 7 M fp64 atomics -- several row chunks and ~8 ancestor blocks per column, device-scope read-modify-writes that bounded the level at
+// 1.47 ms whatever the reduction cost: swapping the shuffles for the swap-based sums above without merging changed nothing, more chunks made it worse.)
 template <class TL>
 __global__ __launch_bounds__(256) void k_solve_gather_bwd(const TL *__restrict__ base, const chol_gemv_desc *__restrict__ blocks, const int *__restrict__ items,
                                                           double *__restrict__ y)
 {
-  const chol_gemv_desc d = blocks[items[2 * blockIdx.x]];
-  const int row0 = items[2 * blockIdx.x + 1];
+  const int q0 = items[4 * blockIdx.x], q1 = items[4 * blockIdx.x + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int PER = CHOL_SOLVE_BW_ROWS / 64;
-  double ya[PER];
-  const TL *A = base + d.a_off;
+  const int cw = items[4 * blockIdx.x + 2] + 16 * wave, n = blocks[q0].n;
+  if (cw >= n) return; // no barrier in this kernel
+  const int ncol = min(16, n - cw);
+  constexpr int PER = 4;
+  double acc[16];
 #pragma unroll
-  for (int u = 0; u < PER; ++u) {
-    const int i = row0 + lane + 64 * u;
-    ya[u] = i < d.m ? y[d.x_off + i] : 0.0;
-  }
-  int c = wave;
-  for (; c + 12 < d.n; c += 16) { // four columns per round: 4 PER loads in flight per lane (one column at a time is PER loads per memory round trip)
-    TL a[4][PER];
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0;
+  for (int b = q0; b < q1; ++b) {
+    const chol_gemv_desc d = blocks[b];
+    const TL *A = base + d.a_off + (int64_t)cw * d.lda;
+    const double *xs = y + d.x_off;
+    for (int r0 = 0; r0 < d.m; r0 += 64 * PER) {
+      const int mrows = min(d.m - r0, 64 * PER);
+      int ro[PER];
+      double xa[PER];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const TL *Ac = A + (int64_t)(c + 4 * q) * d.lda;
+      for (int u = 0; u < PER; ++u) {
+        ro[u] = r0 + min(lane + 64 * u, mrows - 1);
+        xa[u] = (lane + 64 * u < mrows) ? xs[ro[u]] : 0.0;
+      }
+      TL a[16][PER];
 #pragma unroll
-      for (int u = 0; u < PER; ++u) a[q][u] = Ac[min(row0 + lane + 64 * u, d.m - 1)];
+      for (int q = 0; q < 16; ++q) {
+        const TL *Ac = A + (int64_t)min(q, ncol - 1) * d.lda;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) a[q][u] = Ac[ro[u]]; // unconditional (clamped rows repeat the last one, x = 0 there): a predicate here serialises the loads
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) acc[q] += (double)a[q][u] * xa[u];
+      }
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      double acc = 0.0;
-#pragma unroll
-      for (int u = 0; u < PER; ++u) acc += (double)a[q][u] * ya[u];
-      for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-      if (lane == 0) unsafeAtomicAdd(&y[d.y_off + c + 4 * q], -acc);
-    }
   }
-  for (; c < d.n; c += 4) {
-    const TL *Ac = A + (int64_t)c * d.lda;
-    double a[PER];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) a[u] = (double)Ac[min(row0 + lane + 64 * u, d.m - 1)];
-    double acc = 0.0;
-#pragma unroll
-    for (int u = 0; u < PER; ++u) acc += a[u] * ya[u];
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if (lane == 0) unsafeAtomicAdd(&y[d.y_off + c], -acc);
-  }
+  const double sum = wave_sum16(acc, lane);
+  const int c = wave_sum16_col(lane);
+  if ((lane & 15) < 4 && c < ncol) unsafeAtomicAdd(&y[blocks[q0].y_off + cw + c], -sum);
 }
 
 template <class TL> static int launch_solve_dinv_t(const TL *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st)

@@ -363,13 +363,19 @@ typedef struct {
   int n_grp; int *grp_start; int *grp_rows;         /* grp_start[n_grp+1]; grp_rows = (row0, y_off) pairs */
   int n_bw; chol_gemv_desc *bw; int *bw_start;      /* backward sources per separator: bw_start[n_trsv+1] */
   /* driver-level solve (cholamd_solve): the (ancestor, separator) blocks `bw` cut into row chunks, one workgroup each:
-   * (block index, first row) pairs; forward chunks of CHOL_SOLVE_FW_ROWS rows, backward of CHOL_SOLVE_BW_ROWS */
+   * forward: (block index, first row, first column) triples, chunks of CHOL_SOLVE_FW_ROWS rows x CHOL_SOLVE_COLS columns (the tall blocks of the top
+   * levels are few: without the column cut 40 workgroups carried a level); backward: (first run, end run, first column, 0) quadruples -- 64 columns of
+   * one separator over a range of its row runs `bw` (runs are cut at CHOL_SOLVE_BW_ROWS rows; the range is all of the separator's runs unless the level
+   * then has fewer than CHOL_SOLVE_BW_ITEMS workgroups) */
   int n_ifw; int *ifw;
   int n_ibw; int *ibw;
   int max_n;                                        /* widest separator of the level */
 } chol_solve_level;
 #define CHOL_SOLVE_FW_ROWS 256
-#define CHOL_SOLVE_BW_ROWS 512
+#define CHOL_SOLVE_BW_ROWS 1024
+#define CHOL_SOLVE_BW_COLS 64
+#define CHOL_SOLVE_BW_ITEMS 4096
+#define CHOL_SOLVE_COLS 1024
 int chol_build_solve_level(const struct cholamd_plan *p, int level, chol_solve_level *out);
 int chol_build_solve_level_part(const struct cholamd_plan *p, int level, int rank, int world, chol_solve_level *out);
 void chol_solve_level_free(chol_solve_level *w);

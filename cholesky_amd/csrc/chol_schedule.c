@@ -1906,11 +1906,13 @@ int chol_build_solve_level_part(const plan_t *p, int level, int rank, int world,
       const chol_block *B = &p->blk[BIDX(p, par, s)];
       if (B->rows == 0 || B->cols == 0) continue;
       blk_run *rr; const int nr = block_runs(B, 0, B->rows, &rr); /* one descriptor per stored row run */
-      for (int q = 0; q < nr; q++) {
-        if (w->n_bw == capb) { capb *= 2; w->bw = realloc(w->bw, (size_t)capb * sizeof(chol_gemv_desc)); }
-        chol_gemv_desc g = { rr[q].off, rr[q].m, B->cols, B->ld, p->sep_off[par] + rr[q].row0, p->sep_off[s] };
-        w->bw[w->n_bw++] = g;
-      }
+      for (int q = 0; q < nr; q++)
+        for (int r0 = 0; r0 < rr[q].m; r0 += CHOL_SOLVE_BW_ROWS) { /* rows of a run are consecutive in memory and in the ancestor's vector */
+          if (w->n_bw == capb) { capb *= 2; w->bw = realloc(w->bw, (size_t)capb * sizeof(chol_gemv_desc)); }
+          const int m = rr[q].m - r0 < CHOL_SOLVE_BW_ROWS ? rr[q].m - r0 : CHOL_SOLVE_BW_ROWS;
+          chol_gemv_desc g = { rr[q].off + r0, m, B->cols, B->ld, p->sep_off[par] + rr[q].row0 + r0, p->sep_off[s] };
+          w->bw[w->n_bw++] = g;
+        }
       free(rr);
     }
   }
@@ -1947,13 +1949,42 @@ int chol_build_solve_level_part(const plan_t *p, int level, int rank, int world,
     }
   w->grp_start[w->n_grp] = w->n_fw;
   /* row chunks of the blocks for the source-centric kernels of the driver-level solve */
-  for (int pass = 0; pass < 2; pass++) {
+  { /* backward: per separator, 64-column chunks x ranges of its row runs holding about R rows; R as large as keeps CHOL_SOLVE_BW_ITEMS workgroups */
+    int64_t R = (int64_t)1 << 30;
+    int n = 0, *it = NULL;
+    for (;;) {
+      n = 0;
+      for (int pass = 0; pass < 2; pass++) { /* count, then fill */
+        int k = 0;
+        for (int t = 0; t < w->n_trsv; t++) {
+          const int nc = (w->trsv[t].n + CHOL_SOLVE_BW_COLS - 1) / CHOL_SOLVE_BW_COLS;
+          for (int q0 = w->bw_start[t]; q0 < w->bw_start[t + 1];) {
+            int q1 = q0; int64_t rows = 0;
+            while (q1 < w->bw_start[t + 1] && (q1 == q0 || rows + w->bw[q1].m <= R)) rows += w->bw[q1++].m;
+            if (pass) for (int c = 0; c < nc; c++) { it[4 * k] = q0; it[4 * k + 1] = q1; it[4 * k + 2] = c * CHOL_SOLVE_BW_COLS; it[4 * k + 3] = 0; k++; }
+            else k += nc;
+            q0 = q1;
+          }
+        }
+        if (!pass) {
+          n = k;
+          if (n < CHOL_SOLVE_BW_ITEMS && R > CHOL_SOLVE_BW_ROWS) break; /* too few: halve R and count again */
+          it = malloc((size_t)(n > 0 ? 4 * n : 4) * sizeof(int));
+        }
+      }
+      if (it) break;
+      R = R > ((int64_t)1 << 20) ? ((int64_t)1 << 20) : R / 2;
+    }
+    w->ibw = it; w->n_ibw = n;
+  }
+  for (int pass = 0; pass < 1; pass++) {
     const int rows = pass ? CHOL_SOLVE_BW_ROWS : CHOL_SOLVE_FW_ROWS;
     int n = 0;
-    for (int i = 0; i < w->n_bw; i++) n += (w->bw[i].m + rows - 1) / rows;
-    int *it = malloc((size_t)(n > 0 ? 2 * n : 2) * sizeof(int)), k = 0;
+    for (int i = 0; i < w->n_bw; i++) n += ((w->bw[i].m + rows - 1) / rows) * ((w->bw[i].n + CHOL_SOLVE_COLS - 1) / CHOL_SOLVE_COLS);
+    int *it = malloc((size_t)(n > 0 ? 3 * n : 3) * sizeof(int)), k = 0;
     for (int i = 0; i < w->n_bw; i++)
-      for (int r0 = 0; r0 < w->bw[i].m; r0 += rows) { it[2 * k] = i; it[2 * k + 1] = r0; k++; }
+      for (int c0 = 0; c0 < w->bw[i].n; c0 += CHOL_SOLVE_COLS)
+        for (int r0 = 0; r0 < w->bw[i].m; r0 += rows) { it[3 * k] = i; it[3 * k + 1] = r0; it[3 * k + 2] = c0; k++; }
     if (pass) { w->ibw = it; w->n_ibw = n; } else { w->ifw = it; w->n_ifw = n; }
   }
 #undef SOLVE_MINE
