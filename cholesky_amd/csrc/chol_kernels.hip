@@ -2611,7 +2611,7 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void k_solve_span32(const float *__restrict__ base, const chol_trsv_desc *__restrict__ descs, const double *__restrict__ Wall,
                                                       double *__restrict__ y, int col0)
 {
-  __shared__ double sx[SSPAN];
+  __shared__ __attribute__((aligned(16))) double sx[SSPAN];
   const chol_trsv_desc d = descs[blockIdx.x];
   if (d.n <= col0) return;
   const int lda = d.lda, tid = threadIdx.x, myb = tid >> 4, l16 = tid & 15;
@@ -2675,14 +2675,19 @@ __global__ __launch_bounds__(256) void k_solve_span32(const float *__restrict__ 
       }
       __syncthreads();
       if (BWD ? myb < j : myb > j) {
-        double acc = 0.0;
+        double xv[TS], acc0 = 0.0, acc1 = 0.0; // the block's solution in eight 16-byte LDS reads, all in flight at once; two chains of eight multiply-adds
+#pragma unroll
+        for (int k = 0; k < TS; k += 2) {
+          const double2 t = *(const double2 *)&sx[j * TS + k];
+          xv[k] = t.x; xv[k + 1] = t.y;
+        }
 #pragma unroll
         for (int k = 0; k < TS; ++k) { // the value stays a float in its register until here: a conversion hoisted to the load would wait for it there
           float v = (BWD && j == nfull) ? ltail[k] : lrow[(BWD ? j - 1 : j) * TS + k];
-          asm volatile("" : "+v"(v));
-          acc += (double)v * sx[j * TS + k];
+          asm("" : "+v"(v));
+          if (k & 1) acc1 += (double)v * xv[k]; else acc0 += (double)v * xv[k];
         }
-        r -= acc;
+        r -= acc0 + acc1;
       }
     }
   }
