@@ -57,6 +57,8 @@ struct cholamd_device {
   int *zr_sub = nullptr; int n_zr_sub = 0; // distributed solve: (offset, length) ranges of the permuted vector this rank starts from zero in (other ranks' subtrees; the shared top on ranks other than 0)
   double *ws = nullptr;
   double *ws_solve = nullptr; // 16x16 inverses of the diagonal blocks of the arena being solved with
+  int *step_flags = nullptr;  // flags of the step launches of the wide top separators' span chains (k_solve_step32): one per separator of a level, 64 ints
+  int step_gen = 0;           // ... and the number of the last such launch (a flag equal to it: the launch's span is solved)
   int *info = nullptr;      // [0] first failing column, [1] separator; two slots of two ints: the program launch alternates between them (each launch clears the other
                             // one for the next: no memset node per factorisation), every other path uses slot 0
   int *info_last = nullptr; // the slot of the most recent factorisation (cholamd_factor_info)
@@ -265,7 +267,7 @@ extern "C" void cholamd_device_destroy(cholamd_device *d)
   free_solve_lists(d);
   (void)hipFree(d->ws32); (void)hipFree(d->csr_ptr); (void)hipFree(d->csr_col); (void)hipFree(d->csr_val); (void)hipFree(d->rvec); (void)hipFree(d->dxvec); (void)hipFree(d->partial);
   (void)hipFree(d->xstage); (void)hipFree(d->xdesc);
-  (void)hipFree(d->ws); (void)hipFree(d->ws_solve); (void)hipFree(d->info); (void)hipFree(d->progress); (void)hipFree(d->a_dst); (void)hipFree(d->a_val); (void)hipFree(d->perm); (void)hipFree(d->ytmp);
+  (void)hipFree(d->ws); (void)hipFree(d->ws_solve); (void)hipFree(d->step_flags); (void)hipFree(d->info); (void)hipFree(d->progress); (void)hipFree(d->a_dst); (void)hipFree(d->a_val); (void)hipFree(d->perm); (void)hipFree(d->ytmp);
   for (int q = 0; q < 2; q++) { (void)hipFree(d->top_dst[q]); (void)hipFree(d->top_val[q]); }
   for (auto &t : d->tl) { d->pool.push_back(t.a); d->pool.push_back(t.b); }
   for (auto e : d->pool) (void)hipEventDestroy(e);
@@ -751,6 +753,7 @@ static int build_solve(cholamd_device *d, int rank = 0, int world = 1)
   }
   if (!d->ytmp) HIPCHK(hipMalloc((void **)&d->ytmp, (size_t)d->plan->n * sizeof(double)));
   if (!d->ws_solve) HIPCHK(hipMalloc((void **)&d->ws_solve, (size_t)(d->plan->ws_doubles > 0 ? d->plan->ws_doubles : 1) * sizeof(double)));
+  if (!d->step_flags) { HIPCHK(hipMalloc((void **)&d->step_flags, 64 * sizeof(int))); HIPCHK(hipMemset(d->step_flags, 0, 64 * sizeof(int))); }
   d->solve_ready = true;
   return 0;
 }
@@ -760,8 +763,8 @@ static int64_t top_vec_offset(const cholamd_device *d) { return d->solve_world >
 // the streamed solve (every panel read once) with a factor of element type TL; vectors and arithmetic are fp64
 static int lsolve_dinv(const double *a, const chol_trsv_desc *t, int n, int mx, double *W, hipStream_t st) { return chol_launch_solve_dinv(a, t, n, mx, W, st); }
 static int lsolve_dinv(const float *a, const chol_trsv_desc *t, int n, int mx, double *W, hipStream_t st) { return chol32_launch_solve_dinv(a, t, n, mx, W, st); }
-static int lsolve_trsv(const double *a, const chol_trsv_desc *t, int n, int mx, const double *W, double *y, int bw, hipStream_t st) { return chol_launch_solve_trsv(a, t, n, mx, W, y, bw, st); }
-static int lsolve_trsv(const float *a, const chol_trsv_desc *t, int n, int mx, const double *W, double *y, int bw, hipStream_t st) { return chol32_launch_solve_trsv(a, t, n, mx, W, y, bw, st); }
+static int lsolve_trsv(cholamd_device *, const double *a, const chol_trsv_desc *t, int n, int mx, const double *W, double *y, int bw, hipStream_t st) { return chol_launch_solve_trsv(a, t, n, mx, W, y, bw, st); }
+static int lsolve_trsv(cholamd_device *d, const float *a, const chol_trsv_desc *t, int n, int mx, const double *W, double *y, int bw, hipStream_t st) { return chol32_launch_solve_trsv(a, t, n, mx, W, y, bw, d->step_flags, &d->step_gen, st); }
 static int lsolve_off(const double *a, const chol_gemv_desc *g, const int *it, int n, double *y, int bw, hipStream_t st) { return chol_launch_solve_offdiag(a, g, it, n, y, bw, st); }
 static int lsolve_off(const float *a, const chol_gemv_desc *g, const int *it, int n, double *y, int bw, hipStream_t st) { return chol32_launch_solve_offdiag(a, g, it, n, y, bw, st); }
 // The streamed solve in three phases, so that a partitioned device can put the two vector reductions of the distributed solve between them:
@@ -788,7 +791,7 @@ template <class TL> static int solve_phase(cholamd_device *d, const TL *d_arena,
     const int hi = phase == 0 ? L - 1 : cut - 1, lo = phase == 0 ? cut : 0;
     for (int lvl = hi; lvl >= lo; lvl--) { // forward, mmat.rg:1395-1435: TRSV per separator, then its panel into the ancestors
       const solve_dev &s = d->sv[lvl];
-      HIPCHK((hipError_t)lsolve_trsv(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, y, 0, st));
+      HIPCHK((hipError_t)lsolve_trsv(d, d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, y, 0, st));
       HIPCHK((hipError_t)lsolve_off(d_arena, s.bw, s.ifw, s.n_ifw, y, 0, st));
     }
   }
@@ -796,7 +799,7 @@ template <class TL> static int solve_phase(cholamd_device *d, const TL *d_arena,
     for (int lvl = 0; lvl < L; lvl++) { // backward, mmat.rg:1438-1479: gather from the ancestors, then TRSV^T
       const solve_dev &s = d->sv[lvl];
       HIPCHK((hipError_t)lsolve_off(d_arena, s.bw, s.ibw, s.n_ibw, y, 1, st));
-      HIPCHK((hipError_t)lsolve_trsv(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, y, 1, st));
+      HIPCHK((hipError_t)lsolve_trsv(d, d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, y, 1, st));
     }
     if (d->solve_world > 1 && d->solve_rank != 0) { // the top's part of the solution is counted once in the sum that follows: rank 0's
       const int64_t t0 = top_vec_offset(d);

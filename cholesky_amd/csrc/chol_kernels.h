@@ -38,7 +38,9 @@ int chol32_launch_trsm_wt(float *base, const float *ws, const chol_trsm_desc *de
 int chol32_launch_update(float *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, hipStream_t st);
 int chol32_launch_update_mt(float *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, int64_t arena_elems, hipStream_t st);
 int chol32_launch_solve_dinv(const float *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st);
-int chol32_launch_solve_trsv(const float *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, hipStream_t st);
+/* flags / gen: STEP flags of the device object (one int per separator of a top level, zero at allocation) and its launch counter (host) -- the step launches
+ * of the wide top separators (k_solve_step32); NULL: launch by launch */
+int chol32_launch_solve_trsv(const float *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st);
 int chol32_launch_solve_offdiag(const float *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st);
 int chol_launch_residual(const int64_t *ptr, const int *col, const double *val, const double *b, const double *x, double *r, int n, double *partial, hipStream_t st);
 int chol_launch_axpy1(double *x, const double *dx, int n, hipStream_t st);

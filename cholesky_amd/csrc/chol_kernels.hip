@@ -2607,13 +2607,10 @@ __global__ __launch_bounds__(256) void k_solve_trsv(const TL *__restrict__ base,
 // lanes that hold block j's right-hand side form x_j = Linv_j r_j in registers (sixteen DPP multiply-adds: lane k of the row supplies r_k), publish it in
 // LDS, and every thread on the far side of the block subtracts its sixteen products.  No triangle in LDS, no shuffles, no second barrier: the next block's
 // lanes go on from their own registers.
-template <bool BWD>
-__global__ __launch_bounds__(256) void k_solve_span32(const float *__restrict__ base, const chol_trsv_desc *__restrict__ descs, const double *__restrict__ Wall,
-                                                      double *__restrict__ y, int col0)
+// PUB: the solution is written with agent-scope stores -- workgroups of the same launch read it (k_solve_step32)
+template <bool BWD, bool PUB>
+__device__ __forceinline__ void span32_body(const float *__restrict__ base, const chol_trsv_desc &d, const double *__restrict__ Wall, double *__restrict__ y, int col0, double *sx)
 {
-  __shared__ __attribute__((aligned(16))) double sx[SSPAN];
-  const chol_trsv_desc d = descs[blockIdx.x];
-  if (d.n <= col0) return;
   const int lda = d.lda, tid = threadIdx.x, myb = tid >> 4, l16 = tid & 15;
   const int ns = min(d.n - col0, SSPAN), nb = (ns + TS - 1) / TS;
   const float *Lm = base + d.a_off + col0 + (int64_t)col0 * lda; // element (0, 0) of the span's diagonal block
@@ -2691,7 +2688,16 @@ __global__ __launch_bounds__(256) void k_solve_span32(const float *__restrict__ 
       }
     }
   }
-  if (live) x[tid] = r;
+  if (live) gstore<PUB>(&x[tid], r);
+}
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_solve_span32(const float *__restrict__ base, const chol_trsv_desc *__restrict__ descs, const double *__restrict__ Wall,
+                                                      double *__restrict__ y, int col0)
+{
+  __shared__ __attribute__((aligned(16))) double sx[SSPAN];
+  const chol_trsv_desc d = descs[blockIdx.x];
+  if (d.n <= col0) return;
+  span32_body<BWD, false>(base, d, Wall, y, col0, sx);
 }
 
 // ---- column sums over a wave without the LDS crossbar (round 4) ----
@@ -2815,6 +2821,129 @@ __global__ __launch_bounds__(256) void k_solve_panel(const TL *__restrict__ base
   }
 }
 
+// One step of the span chain of the few wide separators at the top of the tree (fp32 factor) in ONE launch.  Launch by launch a step was: solve span k (one
+// workgroup, ~10 us), then its whole panel (all CUs, ~12 us) -- but the next span needs only SSPAN rows of that panel.  Roles by blockIdx.y:
+//   0                 the solve of span k (span32_body; publishes x_k with agent-scope stores, then the separator's flag = gen)
+//   1 .. STEP_NB      the SSPAN rows / columns the NEXT span needs of span k's panel: their L entries are requested first, then the workgroup waits for the
+//                     flag (the producer has the lowest block index of the launch and waits for nobody; the spin is bounded all the same: it poisons its
+//                     part of the vector with NaN if it gives up), reads x_k with agent-scope loads and adds its part atomically
+//   STEP_NB + 1 ..    the rest of the PREVIOUS span's panel (forward: rows behind span k under span k - 1; backward: the rows behind span k into the columns of
+//                     span k - 1): everything it reads was final before the launch, it runs beside the solve
+// so the chain per step is solve + flag + 1/16 of a SSPAN x SSPAN block instead of solve + launch + panel.
+#define STEP_NB 16
+#define STEP_MAX_SEPS 8
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_solve_step32(const float *__restrict__ base, const chol_trsv_desc *__restrict__ descs, const double *__restrict__ Wall,
+                                                      double *__restrict__ y, int col0, int *__restrict__ flags, int gen)
+{
+  __shared__ __attribute__((aligned(16))) double sx[SSPAN];
+  const chol_trsv_desc d = descs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lda = d.lda, n = d.n;
+  const int role = blockIdx.y;
+  if (n <= col0) return; // (every role of a separator without this span)
+  const float *Lm = base + d.a_off;
+  double *x = y + d.x_off;
+  if (role == 0) {
+    span32_body<BWD, true>(base, d, Wall, y, col0, sx);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&flags[blockIdx.x], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (role <= STEP_NB) {
+    const int part = role - 1;
+    bool ok = true;
+    if (!BWD) { // rows col0 + SSPAN + 16 part .. + 15 under the columns of span k: thread (row, sixteenth of the columns)
+      const int r = tid & 15, kp = tid >> 4, row = col0 + SSPAN + TS * part + r;
+      if (col0 + SSPAN + TS * part >= n) return;
+      const float *A = Lm + min(row, n - 1) + (int64_t)(col0 + TS * kp) * lda;
+      float a[TS];
+#pragma unroll
+      for (int u = 0; u < TS; ++u) a[u] = A[(int64_t)u * lda];
+      if (tid < 64) {
+        int v = 0, it = 0;
+        for (; it < (1 << 22); ++it) {
+          v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&flags[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          if (v == gen) break;
+          __builtin_amdgcn_s_sleep(4);
+        }
+        if (tid == 0) ((int *)sx)[0] = v == gen;
+      }
+      __syncthreads();
+      ok = ((volatile int *)sx)[0] != 0;
+      __syncthreads();
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < TS; ++u) acc += (double)a[u] * gload<true>(&x[col0 + TS * kp + u]);
+      sx[kp * TS + r] = acc;
+      __syncthreads();
+      if (tid < TS) {
+        double sum = 0.0;
+#pragma unroll
+        for (int q = 0; q < TS; ++q) sum += sx[q * TS + tid];
+        if (!ok) sum = __builtin_nan("");
+        if (row < n) unsafeAtomicAdd(&x[row], -sum);
+      }
+    } else { // the rows of span k into the columns col0 - SSPAN + 16 part .. + 15 of span k - 1: wave w the rows 64 w .. 64 w + 63
+      if (col0 == 0) return;
+      const int c0 = col0 - SSPAN + TS * part, ns = min(n - col0, SSPAN), row = 64 * wave + lane;
+      const float *A = Lm + col0 + min(row, ns - 1) + (int64_t)c0 * lda;
+      float a[TS];
+#pragma unroll
+      for (int q = 0; q < TS; ++q) a[q] = A[(int64_t)q * lda];
+      if (tid < 64) {
+        int v = 0, it = 0;
+        for (; it < (1 << 22); ++it) {
+          v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&flags[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          if (v == gen) break;
+          __builtin_amdgcn_s_sleep(4);
+        }
+        if (tid == 0) ((int *)sx)[0] = v == gen;
+      }
+      __syncthreads();
+      ok = ((volatile int *)sx)[0] != 0;
+      const double xr = row < ns ? gload<true>(&x[col0 + row]) : 0.0;
+      double acc[TS];
+#pragma unroll
+      for (int q = 0; q < TS; ++q) acc[q] = (double)a[q] * xr;
+      double sum = wave_sum16(acc, lane);
+      if (!ok) sum = __builtin_nan("");
+      if ((lane & 15) < 4) unsafeAtomicAdd(&x[c0 + wave_sum16_col(lane)], -sum);
+    }
+    return;
+  }
+  // the rest of the previous span's panel
+  if (col0 == 0) return;
+  const int chunk = role - STEP_NB - 1, pc0 = col0 - SSPAN, r0 = col0 + SSPAN;
+  if (!BWD) {
+    if (n <= r0 + chunk * SPANEL_FW_ROWS) return;
+    sx[tid] = x[pc0 + tid];
+    __syncthreads();
+    const int r = r0 + chunk * SPANEL_FW_ROWS + tid;
+    const float *A = Lm + min(r, n - 1) + (int64_t)pc0 * lda;
+    double acc = 0.0;
+    for (int k = 0; k < SSPAN; k += 32) {
+      float a[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) a[u] = A[(int64_t)(k + u) * lda];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) acc += (double)a[u] * sx[k + u];
+    }
+    if (r < n) unsafeAtomicAdd(&x[r], -acc); // (the rows of the next span also receive the middle role's sums)
+  } else {
+    constexpr int PER = SPANEL_BW_ROWS / 64;
+    const int row0 = r0 + chunk * SPANEL_BW_ROWS;
+    if (n <= row0) return;
+    double xa[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = row0 + lane + 64 * u;
+      xa[u] = i < n ? x[i] : 0.0;
+    }
+    gather_columns<PER>(Lm + row0 + (int64_t)pc0 * lda, lda, min(n - row0, SPANEL_BW_ROWS), SSPAN, xa, x + pc0, lane, wave);
+  }
+}
+
 // forward: y_anc[rows] -= A(rows, cols) y_s for one (row chunk, column chunk) of the block A = (anc, s); y_s staged through LDS.  items = (block, first
 // row, first column) triples: the column chunks (CHOL_SOLVE_COLS) give the few tall blocks of the top levels enough workgroups to fill the chip
 template <class TL>
@@ -2928,9 +3057,32 @@ template <bool BWD> static void launch_span(const float *base, const chol_trsv_d
   if (SOLVE_SPAN32) hipLaunchKernelGGL((k_solve_span32<BWD>), dim3(n), dim3(256), 0, st, base, descs, W, y, col0);
   else hipLaunchKernelGGL((k_solve_trsv<BWD, float>), dim3(n), dim3(256), 0, st, base, descs, W, y, col0);
 }
-template <class TL> static int launch_solve_trsv_t(const TL *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, hipStream_t st)
+#ifndef SOLVE_STEP32
+#define SOLVE_STEP32 1 /* 0: span and panel launch by launch at every level (A/B) */
+#endif
+static bool launch_steps(const double *, const chol_trsv_desc *, int, int, const double *, double *, int, int *, int *, hipStream_t) { return false; }
+static bool launch_steps(const float *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st)
+{ // the few wide separators of a top level: one launch per span step (k_solve_step32)
+  if (!SOLVE_STEP32 || !flags || n > STEP_MAX_SEPS || max_n <= SSPAN) return false;
+  const int nspan = (max_n + SSPAN - 1) / SSPAN;
+  for (int i = 0; i < nspan; i++) {
+    const int sp = backward ? nspan - 1 - i : i, col0 = sp * SSPAN;
+    const int behind = sp > 0 ? max_n - (col0 + SSPAN) : 0; // rows behind span sp: the previous span's rest
+    const int rows = backward ? SPANEL_BW_ROWS : SPANEL_FW_ROWS;
+    const int nrest = behind > 0 ? (behind + rows - 1) / rows : 0;
+    const bool mid = backward ? sp > 0 : max_n > col0 + SSPAN;
+    const dim3 grid(n, nrest > 0 ? 1 + STEP_NB + nrest : mid ? 1 + STEP_NB : 1);
+    *gen = *gen == 0x7fffffff ? 1 : *gen + 1;
+    if (backward) hipLaunchKernelGGL((k_solve_step32<true>), grid, dim3(256), 0, st, base, descs, W, y, col0, flags, *gen);
+    else hipLaunchKernelGGL((k_solve_step32<false>), grid, dim3(256), 0, st, base, descs, W, y, col0, flags, *gen);
+  }
+  return true;
+}
+template <class TL>
+static int launch_solve_trsv_t(const TL *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st)
 { // all separators of a level; wide ones in spans of SSPAN columns: diagonal span by one workgroup each, the rows below by all CUs
   if (n <= 0) return 0;
+  if (launch_steps(base, descs, n, max_n, W, y, backward, flags, gen, st)) return (int)hipGetLastError();
   const int nspan = (max_n + SSPAN - 1) / SSPAN;
   for (int i = 0; i < nspan; i++) {
     const int sp = backward ? nspan - 1 - i : i, col0 = sp * SSPAN;
@@ -3051,10 +3203,10 @@ int chol_launch_permute(const double *in, const int *perm, double *out, int n, i
   return (int)hipGetLastError();
 }
 int chol_launch_solve_dinv(const double *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st) { return launch_solve_dinv_t(base, descs, n, max_n, W, st); }
-int chol_launch_solve_trsv(const double *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, hipStream_t st) { return launch_solve_trsv_t(base, descs, n, max_n, W, y, backward, st); }
+int chol_launch_solve_trsv(const double *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, hipStream_t st) { return launch_solve_trsv_t(base, descs, n, max_n, W, y, backward, nullptr, nullptr, st); }
 int chol_launch_solve_offdiag(const double *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st) { return launch_solve_offdiag_t(base, blocks, items, n_items, y, backward, st); }
 int chol32_launch_solve_dinv(const float *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st) { return launch_solve_dinv_t(base, descs, n, max_n, W, st); }
-int chol32_launch_solve_trsv(const float *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, hipStream_t st) { return launch_solve_trsv_t(base, descs, n, max_n, W, y, backward, st); }
+int chol32_launch_solve_trsv(const float *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st) { return launch_solve_trsv_t(base, descs, n, max_n, W, y, backward, flags, gen, st); }
 int chol32_launch_solve_offdiag(const float *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st) { return launch_solve_offdiag_t(base, blocks, items, n_items, y, backward, st); }
 int chol_launch_trsv_fwd(const double *base, const chol_trsv_desc *descs, int n, double *y, hipStream_t st)
 {
