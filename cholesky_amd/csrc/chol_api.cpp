@@ -57,7 +57,7 @@ struct cholamd_device {
   int *zr_sub = nullptr; int n_zr_sub = 0; // distributed solve: (offset, length) ranges of the permuted vector this rank starts from zero in (other ranks' subtrees; the shared top on ranks other than 0)
   double *ws = nullptr;
   double *ws_solve = nullptr; // 16x16 inverses of the diagonal blocks of the arena being solved with
-  int *step_flags = nullptr;  // flags of the step launches of the wide top separators' span chains (k_solve_step32): one per separator of a level, 64 ints
+  int *step_flags = nullptr;  // flags of the step launches of the wide top separators' span chains (k_solve_step): one per separator of a level, 64 ints
   int step_gen = 0;           // ... and the number of the last such launch (a flag equal to it: the launch's span is solved)
   int *info = nullptr;      // [0] first failing column, [1] separator; two slots of two ints: the program launch alternates between them (each launch clears the other
                             // one for the next: no memset node per factorisation), every other path uses slot 0
@@ -763,7 +763,7 @@ static int64_t top_vec_offset(const cholamd_device *d) { return d->solve_world >
 // the streamed solve (every panel read once) with a factor of element type TL; vectors and arithmetic are fp64
 static int lsolve_dinv(const double *a, const chol_trsv_desc *t, int n, int mx, double *W, hipStream_t st) { return chol_launch_solve_dinv(a, t, n, mx, W, st); }
 static int lsolve_dinv(const float *a, const chol_trsv_desc *t, int n, int mx, double *W, hipStream_t st) { return chol32_launch_solve_dinv(a, t, n, mx, W, st); }
-static int lsolve_trsv(cholamd_device *, const double *a, const chol_trsv_desc *t, int n, int mx, const double *W, double *y, int bw, hipStream_t st) { return chol_launch_solve_trsv(a, t, n, mx, W, y, bw, st); }
+static int lsolve_trsv(cholamd_device *d, const double *a, const chol_trsv_desc *t, int n, int mx, const double *W, double *y, int bw, hipStream_t st) { return chol_launch_solve_trsv(a, t, n, mx, W, y, bw, d->step_flags, &d->step_gen, st); }
 static int lsolve_trsv(cholamd_device *d, const float *a, const chol_trsv_desc *t, int n, int mx, const double *W, double *y, int bw, hipStream_t st) { return chol32_launch_solve_trsv(a, t, n, mx, W, y, bw, d->step_flags, &d->step_gen, st); }
 static int lsolve_off(const double *a, const chol_gemv_desc *g, const int *it, int n, double *y, int bw, hipStream_t st) { return chol_launch_solve_offdiag(a, g, it, n, y, bw, st); }
 static int lsolve_off(const float *a, const chol_gemv_desc *g, const int *it, int n, double *y, int bw, hipStream_t st) { return chol32_launch_solve_offdiag(a, g, it, n, y, bw, st); }

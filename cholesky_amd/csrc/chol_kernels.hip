@@ -2489,14 +2489,12 @@ __global__ __launch_bounds__(64) void k_solve_dinv(const TL *__restrict__ base, 
 // in (forward) / gathered (backward) by k_solve_panel over all CUs, so a wide separator's triangle is not streamed by
 // one workgroup.
 #define SSPAN 256
-template <bool BWD, class TL>
-__global__ __launch_bounds__(256) void k_solve_trsv(const TL *__restrict__ base, const chol_trsv_desc *__restrict__ descs, const double *__restrict__ Wall,
-                                                    double *__restrict__ y, int col0)
+// sL: [r][c] of the current diagonal block; sxs: the span's part of the vector, in LDS from the first block to the last.  PUB: the solution is written with
+// agent-scope stores (workgroups of the same launch read it: k_solve_step)
+template <bool BWD, class TL, bool PUB>
+__device__ __forceinline__ void trsv_body(const TL *__restrict__ base, const chol_trsv_desc &d, const double *__restrict__ Wall, double *__restrict__ y, int col0,
+                                          double (*sL)[SNB + 1], double (*sW)[TS * TS], double *sxs)
 {
-  __shared__ double sL[SNB][SNB + 1]; // [r][c] of the current diagonal block
-  __shared__ double sW[SNB / TS][TS * TS];
-  __shared__ double sxs[SSPAN]; // the span's part of the vector: lives in LDS from the first block to the last
-  const chol_trsv_desc d = descs[blockIdx.x];
   const TL *Lm = base + d.a_off;
   const double *W = Wall + d.dinv_off;
   double *x = y + d.x_off;
@@ -2598,7 +2596,16 @@ __global__ __launch_bounds__(256) void k_solve_trsv(const TL *__restrict__ base,
     }
     __syncthreads(); // the block's folds are in LDS (the next block's right-hand side), sL / sW may be rewritten
   }
-  if (col0 + tid < n) x[col0 + tid] = sxs[tid];
+  if (col0 + tid < n) gstore<PUB>(&x[col0 + tid], sxs[tid]);
+}
+template <bool BWD, class TL>
+__global__ __launch_bounds__(256) void k_solve_trsv(const TL *__restrict__ base, const chol_trsv_desc *__restrict__ descs, const double *__restrict__ Wall,
+                                                    double *__restrict__ y, int col0)
+{
+  __shared__ double sL[SNB][SNB + 1];
+  __shared__ double sW[SNB / TS][TS * TS];
+  __shared__ double sxs[SSPAN];
+  trsv_body<BWD, TL, false>(base, descs[blockIdx.x], Wall, y, col0, sL, sW, sxs);
 }
 // The diagonal solve of one 256-column span out of an fp32 factor (round 4; the spans of the wide top separators are two thirds of a solve at 100^3: 101 per
 // direction, 23 / 26 us each in k_solve_trsv).  One thread per row (forward) / column (backward) of the span; EVERY entry of the span's triangle the thread
@@ -2607,7 +2614,7 @@ __global__ __launch_bounds__(256) void k_solve_trsv(const TL *__restrict__ base,
 // lanes that hold block j's right-hand side form x_j = Linv_j r_j in registers (sixteen DPP multiply-adds: lane k of the row supplies r_k), publish it in
 // LDS, and every thread on the far side of the block subtracts its sixteen products.  No triangle in LDS, no shuffles, no second barrier: the next block's
 // lanes go on from their own registers.
-// PUB: the solution is written with agent-scope stores -- workgroups of the same launch read it (k_solve_step32)
+// PUB: the solution is written with agent-scope stores -- workgroups of the same launch read it (k_solve_step)
 template <bool BWD, bool PUB>
 __device__ __forceinline__ void span32_body(const float *__restrict__ base, const chol_trsv_desc &d, const double *__restrict__ Wall, double *__restrict__ y, int col0, double *sx)
 {
@@ -2832,19 +2839,31 @@ __global__ __launch_bounds__(256) void k_solve_panel(const TL *__restrict__ base
 // so the chain per step is solve + flag + 1/16 of a SSPAN x SSPAN block instead of solve + launch + panel.
 #define STEP_NB 16
 #define STEP_MAX_SEPS 8
-template <bool BWD>
-__global__ __launch_bounds__(256) void k_solve_step32(const float *__restrict__ base, const chol_trsv_desc *__restrict__ descs, const double *__restrict__ Wall,
-                                                      double *__restrict__ y, int col0, int *__restrict__ flags, int gen)
+template <bool BWD, class TL> struct step_span;
+template <bool BWD> struct step_span<BWD, float> {
+  static __device__ __forceinline__ void run(const float *base, const chol_trsv_desc &d, const double *Wall, double *y, int col0, double *sx) { span32_body<BWD, true>(base, d, Wall, y, col0, sx); }
+};
+template <bool BWD> struct step_span<BWD, double> { // the fp64 factor's span: the 64-column block chain of k_solve_trsv
+  static __device__ __forceinline__ void run(const double *base, const chol_trsv_desc &d, const double *Wall, double *y, int col0, double *sx)
+  {
+    __shared__ double sL[SNB][SNB + 1];
+    __shared__ double sW[SNB / TS][TS * TS];
+    trsv_body<BWD, double, true>(base, d, Wall, y, col0, sL, sW, sx);
+  }
+};
+template <bool BWD, class TL>
+__global__ __launch_bounds__(256) void k_solve_step(const TL *__restrict__ base, const chol_trsv_desc *__restrict__ descs, const double *__restrict__ Wall,
+                                                    double *__restrict__ y, int col0, int *__restrict__ flags, int gen)
 {
   __shared__ __attribute__((aligned(16))) double sx[SSPAN];
   const chol_trsv_desc d = descs[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lda = d.lda, n = d.n;
   const int role = blockIdx.y;
   if (n <= col0) return; // (every role of a separator without this span)
-  const float *Lm = base + d.a_off;
+  const TL *Lm = base + d.a_off;
   double *x = y + d.x_off;
   if (role == 0) {
-    span32_body<BWD, true>(base, d, Wall, y, col0, sx);
+    step_span<BWD, TL>::run(base, d, Wall, y, col0, sx);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(&flags[blockIdx.x], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2856,8 +2875,8 @@ __global__ __launch_bounds__(256) void k_solve_step32(const float *__restrict__ 
     if (!BWD) { // rows col0 + SSPAN + 16 part .. + 15 under the columns of span k: thread (row, sixteenth of the columns)
       const int r = tid & 15, kp = tid >> 4, row = col0 + SSPAN + TS * part + r;
       if (col0 + SSPAN + TS * part >= n) return;
-      const float *A = Lm + min(row, n - 1) + (int64_t)(col0 + TS * kp) * lda;
-      float a[TS];
+      const TL *A = Lm + min(row, n - 1) + (int64_t)(col0 + TS * kp) * lda;
+      TL a[TS];
 #pragma unroll
       for (int u = 0; u < TS; ++u) a[u] = A[(int64_t)u * lda];
       if (tid < 64) {
@@ -2887,8 +2906,8 @@ __global__ __launch_bounds__(256) void k_solve_step32(const float *__restrict__ 
     } else { // the rows of span k into the columns col0 - SSPAN + 16 part .. + 15 of span k - 1: wave w the rows 64 w .. 64 w + 63
       if (col0 == 0) return;
       const int c0 = col0 - SSPAN + TS * part, ns = min(n - col0, SSPAN), row = 64 * wave + lane;
-      const float *A = Lm + col0 + min(row, ns - 1) + (int64_t)c0 * lda;
-      float a[TS];
+      const TL *A = Lm + col0 + min(row, ns - 1) + (int64_t)c0 * lda;
+      TL a[TS];
 #pragma unroll
       for (int q = 0; q < TS; ++q) a[q] = A[(int64_t)q * lda];
       if (tid < 64) {
@@ -2920,10 +2939,10 @@ __global__ __launch_bounds__(256) void k_solve_step32(const float *__restrict__ 
     sx[tid] = x[pc0 + tid];
     __syncthreads();
     const int r = r0 + chunk * SPANEL_FW_ROWS + tid;
-    const float *A = Lm + min(r, n - 1) + (int64_t)pc0 * lda;
+    const TL *A = Lm + min(r, n - 1) + (int64_t)pc0 * lda;
     double acc = 0.0;
     for (int k = 0; k < SSPAN; k += 32) {
-      float a[32];
+      TL a[32];
 #pragma unroll
       for (int u = 0; u < 32; ++u) a[u] = A[(int64_t)(k + u) * lda];
 #pragma unroll
@@ -3060,9 +3079,9 @@ template <bool BWD> static void launch_span(const float *base, const chol_trsv_d
 #ifndef SOLVE_STEP32
 #define SOLVE_STEP32 1 /* 0: span and panel launch by launch at every level (A/B) */
 #endif
-static bool launch_steps(const double *, const chol_trsv_desc *, int, int, const double *, double *, int, int *, int *, hipStream_t) { return false; }
-static bool launch_steps(const float *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st)
-{ // the few wide separators of a top level: one launch per span step (k_solve_step32)
+template <class TL>
+static bool launch_steps(const TL *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st)
+{ // the few wide separators of a top level: one launch per span step (k_solve_step)
   if (!SOLVE_STEP32 || !flags || n > STEP_MAX_SEPS || max_n <= SSPAN) return false;
   const int nspan = (max_n + SSPAN - 1) / SSPAN;
   for (int i = 0; i < nspan; i++) {
@@ -3073,8 +3092,8 @@ static bool launch_steps(const float *base, const chol_trsv_desc *descs, int n, 
     const bool mid = backward ? sp > 0 : max_n > col0 + SSPAN;
     const dim3 grid(n, nrest > 0 ? 1 + STEP_NB + nrest : mid ? 1 + STEP_NB : 1);
     *gen = *gen == 0x7fffffff ? 1 : *gen + 1;
-    if (backward) hipLaunchKernelGGL((k_solve_step32<true>), grid, dim3(256), 0, st, base, descs, W, y, col0, flags, *gen);
-    else hipLaunchKernelGGL((k_solve_step32<false>), grid, dim3(256), 0, st, base, descs, W, y, col0, flags, *gen);
+    if (backward) hipLaunchKernelGGL((k_solve_step<true, TL>), grid, dim3(256), 0, st, base, descs, W, y, col0, flags, *gen);
+    else hipLaunchKernelGGL((k_solve_step<false, TL>), grid, dim3(256), 0, st, base, descs, W, y, col0, flags, *gen);
   }
   return true;
 }
@@ -3203,7 +3222,7 @@ int chol_launch_permute(const double *in, const int *perm, double *out, int n, i
   return (int)hipGetLastError();
 }
 int chol_launch_solve_dinv(const double *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st) { return launch_solve_dinv_t(base, descs, n, max_n, W, st); }
-int chol_launch_solve_trsv(const double *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, hipStream_t st) { return launch_solve_trsv_t(base, descs, n, max_n, W, y, backward, nullptr, nullptr, st); }
+int chol_launch_solve_trsv(const double *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st) { return launch_solve_trsv_t(base, descs, n, max_n, W, y, backward, flags, gen, st); }
 int chol_launch_solve_offdiag(const double *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st) { return launch_solve_offdiag_t(base, blocks, items, n_items, y, backward, st); }
 int chol32_launch_solve_dinv(const float *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st) { return launch_solve_dinv_t(base, descs, n, max_n, W, st); }
 int chol32_launch_solve_trsv(const float *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st) { return launch_solve_trsv_t(base, descs, n, max_n, W, y, backward, flags, gen, st); }
