@@ -66,6 +66,29 @@ def profile_numbers(kernel, case, mixed, options=()):
         return {}
 
 
+def profile_solve_numbers(case, mixed, n_solves_timed, alg_bytes_factor):
+    """The solve's kernels in the committed rocprofv3 passes of this case (a mixed-precision pass runs the refinement after its factorisations): HBM
+    bytes and kernel time per solve = sums over the k_solve_* kernels / the solves of the pass (one k_permute_in launch each); the achieved rate
+    against HBM peak, and the same time against the ALGORITHMIC bytes of a solve (the factor's non-zeros read once per sweep: two sweeps)."""
+    try:
+        from cholesky_amd import benchline
+        with open(PROFILE_SUMMARY) as f:
+            runs = json.load(f)["runs"]
+        ks = runs[case + (":mixed" if mixed else "")]["kernels"]
+        sel = [v for k, v in ks.items() if k.startswith("k_solve_")]
+        n_t, n_c = ks["k_permute_in"]["launches"], ks["k_permute_in"].get("pmc_launches")
+        us = sum(v["avg_launch_us"] * v["launches"] for v in sel) / n_t
+        byt = sum(v["hbm_bytes_per_launch_corrected"] * v["pmc_launches"] for v in sel if v.get("hbm_bytes_per_launch_corrected") is not None) / n_c
+        alg = 2.0 * alg_bytes_factor
+        return {"solve_kernels_ms_rocprof": round(us * 1e-3, 3), "hbm_bytes_per_solve_rocprof": int(byt), "hbm_GBs": round(byt / us * 1e-3, 1),
+                "hbm_frac_of_peak": round(byt / us * 1e-3 / benchline.PEAK_HBM_GBS, 4), "alg_bytes_per_solve": int(alg), "alg_GBs": round(alg / us * 1e-3, 1),
+                "note": "stored panels are dense blocks: the sweeps read every stored entry (structural zeros inside the kept tiles included), "
+                        "alg_bytes counts the factor's non-zeros at the factor's element size, twice",
+                "solves_in_timed_refinement": n_solves_timed, "source": f"profiles/{PROFILE_ROUND}/summary.json: k_solve_* of this case"}
+    except Exception:
+        return {}
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -157,6 +180,7 @@ def large_front(ca, torch, stream, specs=LARGE_FRONT, steps=2, warmup=1):
             it, rel = dev.solve_refine(a, bvec, xvec, 30, 1e-11, stream)
             torch.cuda.synchronize()
             refine = {"corrections": it, "relres": rel, "ms": round((time.perf_counter() - t0) * 1e3, 3), "tol": 1e-11}
+            refine["traffic"] = profile_solve_numbers(f"gen:{gn}:{glv}" + (f":{gtile}" if gtile != 64 else ""), True, it + 1, (plan.alg_bytes // 8) * 4)
         else:
             dev.solve(a, bvec, xvec, stream)
             torch.cuda.synchronize()

@@ -55,7 +55,7 @@ lapl_3375|--case lapl_3375x3375 --in-flight 0|20|SQ_INSTS_VALU_MFMA_MOPS_F64|1
 lapl_3375_levels|--case lapl_3375x3375 --option program=0 --in-flight 0|20|SQ_INSTS_VALU_MFMA_MOPS_F64|1
 gen_40_6|--case gen:40:6|5|SQ_INSTS_VALU_MFMA_MOPS_F64|0
 gen_60_8|--case gen:60:8|3|SQ_INSTS_VALU_MFMA_MOPS_F64|1
-gen_60_8_mixed|--case gen:60:8 --precision mixed|3|SQ_INSTS_VALU_MFMA_MOPS_F32|0
+gen_60_8_mixed|--case gen:60:8 --precision mixed|3|SQ_INSTS_VALU_MFMA_MOPS_F32|1
 gen_100_10_mixed|--case gen:100:10 --precision mixed|2|SQ_INSTS_VALU_MFMA_MOPS_F32|1
 gen_100_10|--case gen:100:10|2|SQ_INSTS_VALU_MFMA_MOPS_F64|1
 LIST

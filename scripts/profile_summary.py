@@ -46,11 +46,12 @@ def one_run(d, suffix=""):
                                     f"printed under the profiler is bench_under_rocprof.json (scripts/gpu_batch.sh profiles)"}
     ks = out["kernels"]
     for f in sorted(glob.glob(os.path.join(d, f"stats{suffix}", "*kernel_stats.csv")) + glob.glob(os.path.join(d, "kernel_stats.csv"))):
-        for r in csv.DictReader(open(f)):
+        for r in csv.DictReader(open(f)):  # (the instances of a template -- k_solve_panel<true, float>, <false, float> -- are summed under the short name)
             k = ks.setdefault(short(r["Name"]), {})
-            k["launches"] = int(r["Calls"])
-            k["avg_launch_us"] = round(float(r["AverageNs"]) * 1e-3, 3)
-            k["share_of_device_time_pct"] = float(r["Percentage"])
+            tot = k.get("avg_launch_us", 0.0) * k.get("launches", 0) + float(r["AverageNs"]) * 1e-3 * int(r["Calls"])
+            k["launches"] = k.get("launches", 0) + int(r["Calls"])
+            k["avg_launch_us"] = round(tot / k["launches"], 3)
+            k["share_of_device_time_pct"] = round(k.get("share_of_device_time_pct", 0.0) + float(r["Percentage"]), 6)
     for f in sorted(glob.glob(os.path.join(d, f"pmc_SQ*{suffix}", "*counter_collection.csv")) + glob.glob(os.path.join(d, "pmc_SQ*_by_kernel.csv"))):
         for kn, c in counters(f).items():
             k = ks.setdefault(kn, {})
