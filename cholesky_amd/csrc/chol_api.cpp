@@ -39,7 +39,7 @@ struct solve_dev {
   chol_trsv_desc *trsv = nullptr;
   chol_gemv_desc *fw = nullptr, *bw = nullptr;
   int *grp_start = nullptr, *grp_rows = nullptr, *bw_start = nullptr;
-  int n_ifw = 0, n_ibw = 0, max_n = 0;
+  int n_ifw = 0, n_ibw = 0, max_n = 0, max_under = 0;
   int *ifw = nullptr, *ibw = nullptr;
 };
 struct timed_launch { hipEvent_t a, b; int kind; };
@@ -745,7 +745,7 @@ static int build_solve(cholamd_device *d, int rank = 0, int world = 1)
     if (!rc) rc = upload_vec(&s.grp_start, w.grp_start, (size_t)w.n_grp + 1);
     if (!rc) rc = upload_vec(&s.grp_rows, w.grp_rows, (size_t)2 * w.n_grp);
     if (!rc) rc = upload_vec(&s.bw_start, w.bw_start, (size_t)w.n_trsv + 1);
-    s.n_ifw = w.n_ifw; s.n_ibw = w.n_ibw; s.max_n = w.max_n;
+    s.n_ifw = w.n_ifw; s.n_ibw = w.n_ibw; s.max_n = w.max_n; s.max_under = w.max_rows_under_span;
     if (!rc) rc = upload_vec(&s.ifw, w.ifw, (size_t)3 * w.n_ifw);
     if (!rc) rc = upload_vec(&s.ibw, w.ibw, (size_t)4 * w.n_ibw);
     chol_solve_level_free(&w);
@@ -763,8 +763,8 @@ static int64_t top_vec_offset(const cholamd_device *d) { return d->solve_world >
 // the streamed solve (every panel read once) with a factor of element type TL; vectors and arithmetic are fp64
 static int lsolve_dinv(const double *a, const chol_trsv_desc *t, int n, int mx, double *W, hipStream_t st) { return chol_launch_solve_dinv(a, t, n, mx, W, st); }
 static int lsolve_dinv(const float *a, const chol_trsv_desc *t, int n, int mx, double *W, hipStream_t st) { return chol32_launch_solve_dinv(a, t, n, mx, W, st); }
-static int lsolve_trsv(cholamd_device *d, const double *a, const chol_trsv_desc *t, int n, int mx, const double *W, double *y, int bw, hipStream_t st) { return chol_launch_solve_trsv(a, t, n, mx, W, y, bw, d->step_flags, &d->step_gen, st); }
-static int lsolve_trsv(cholamd_device *d, const float *a, const chol_trsv_desc *t, int n, int mx, const double *W, double *y, int bw, hipStream_t st) { return chol32_launch_solve_trsv(a, t, n, mx, W, y, bw, d->step_flags, &d->step_gen, st); }
+static int lsolve_trsv(cholamd_device *d, const double *a, const chol_trsv_desc *t, int n, int mx, int mu, const double *W, double *y, int bw, hipStream_t st) { return chol_launch_solve_trsv(a, t, n, mx, mu, W, y, bw, d->step_flags, &d->step_gen, st); }
+static int lsolve_trsv(cholamd_device *d, const float *a, const chol_trsv_desc *t, int n, int mx, int mu, const double *W, double *y, int bw, hipStream_t st) { return chol32_launch_solve_trsv(a, t, n, mx, mu, W, y, bw, d->step_flags, &d->step_gen, st); }
 static int lsolve_off(const double *a, const chol_gemv_desc *g, const int *it, int n, double *y, int bw, hipStream_t st) { return chol_launch_solve_offdiag(a, g, it, n, y, bw, st); }
 static int lsolve_off(const float *a, const chol_gemv_desc *g, const int *it, int n, double *y, int bw, hipStream_t st) { return chol32_launch_solve_offdiag(a, g, it, n, y, bw, st); }
 // The streamed solve in three phases, so that a partitioned device can put the two vector reductions of the distributed solve between them:
@@ -791,7 +791,7 @@ template <class TL> static int solve_phase(cholamd_device *d, const TL *d_arena,
     const int hi = phase == 0 ? L - 1 : cut - 1, lo = phase == 0 ? cut : 0;
     for (int lvl = hi; lvl >= lo; lvl--) { // forward, mmat.rg:1395-1435: TRSV per separator, then its panel into the ancestors
       const solve_dev &s = d->sv[lvl];
-      HIPCHK((hipError_t)lsolve_trsv(d, d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, y, 0, st));
+      HIPCHK((hipError_t)lsolve_trsv(d, d_arena, s.trsv, s.n_trsv, s.max_n, s.max_under, d->ws_solve, y, 0, st));
       HIPCHK((hipError_t)lsolve_off(d_arena, s.bw, s.ifw, s.n_ifw, y, 0, st));
     }
   }
@@ -799,7 +799,7 @@ template <class TL> static int solve_phase(cholamd_device *d, const TL *d_arena,
     for (int lvl = 0; lvl < L; lvl++) { // backward, mmat.rg:1438-1479: gather from the ancestors, then TRSV^T
       const solve_dev &s = d->sv[lvl];
       HIPCHK((hipError_t)lsolve_off(d_arena, s.bw, s.ibw, s.n_ibw, y, 1, st));
-      HIPCHK((hipError_t)lsolve_trsv(d, d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, y, 1, st));
+      HIPCHK((hipError_t)lsolve_trsv(d, d_arena, s.trsv, s.n_trsv, s.max_n, s.max_under, d->ws_solve, y, 1, st));
     }
     if (d->solve_world > 1 && d->solve_rank != 0) { // the top's part of the solution is counted once in the sum that follows: rank 0's
       const int64_t t0 = top_vec_offset(d);

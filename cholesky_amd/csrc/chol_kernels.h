@@ -25,7 +25,7 @@ int chol_launch_update(double *base, const chol_upd_task *tasks, const chol_upd_
 int chol_launch_update_mt(double *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, int64_t arena_elems, hipStream_t st);
 int chol_launch_permute(const double *in, const int *perm, double *out, int n, int inverse, hipStream_t st);
 int chol_launch_solve_dinv(const double *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st);
-int chol_launch_solve_trsv(const double *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st);
+int chol_launch_solve_trsv(const double *base, const chol_trsv_desc *descs, int n, int max_n, int max_under, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st);
 int chol_launch_solve_offdiag(const double *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st);
 int chol_launch_trsv_fwd(const double *base, const chol_trsv_desc *descs, int n, double *y, hipStream_t st);
 int chol_launch_gemv_fwd(const double *base, const chol_gemv_desc *descs, const int *grp_start, const int *grp_rows, int ngroups, double *y, hipStream_t st);
@@ -40,7 +40,7 @@ int chol32_launch_update_mt(float *base, const chol_upd_task *tasks, const chol_
 int chol32_launch_solve_dinv(const float *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st);
 /* flags / gen: STEP flags of the device object (one int per separator of a top level, zero at allocation) and its launch counter (host) -- the step launches
  * of the wide top separators (k_solve_step); NULL: launch by launch */
-int chol32_launch_solve_trsv(const float *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st);
+int chol32_launch_solve_trsv(const float *base, const chol_trsv_desc *descs, int n, int max_n, int max_under, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st);
 int chol32_launch_solve_offdiag(const float *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st);
 int chol_launch_residual(const int64_t *ptr, const int *col, const double *val, const double *b, const double *x, double *r, int n, double *partial, hipStream_t st);
 int chol_launch_axpy1(double *x, const double *dx, int n, hipStream_t st);

@@ -2796,10 +2796,11 @@ __global__ __launch_bounds__(256) void k_solve_panel(const TL *__restrict__ base
   const chol_trsv_desc d = descs[blockIdx.x];
   const int r0 = col0 + SSPAN;
   const int rows = BWD ? SPANEL_BW_ROWS : SPANEL_FW_ROWS;
-  if (d.n <= r0 + (int)blockIdx.y * rows) return;
+  const int n = d.band > 0 ? min(d.n, r0 + d.band) : d.n; // a banded (leaf) block: the rows from r0 + band on are zero under these columns
+  if (n <= r0 + (int)blockIdx.y * rows) return;
   const TL *Lm = base + d.a_off;
   double *x = y + d.x_off;
-  const int n = d.n, lda = d.lda, tid = threadIdx.x;
+  const int lda = d.lda, tid = threadIdx.x;
   if (!BWD) {
     sx[tid] = x[col0 + tid];
     __syncthreads();
@@ -3098,14 +3099,16 @@ static bool launch_steps(const TL *base, const chol_trsv_desc *descs, int n, int
   return true;
 }
 template <class TL>
-static int launch_solve_trsv_t(const TL *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st)
-{ // all separators of a level; wide ones in spans of SSPAN columns: diagonal span by one workgroup each, the rows below by all CUs
+static int launch_solve_trsv_t(const TL *base, const chol_trsv_desc *descs, int n, int max_n, int max_under, const double *W, double *y, int backward, int *flags, int *gen,
+                               hipStream_t st)
+{ // all separators of a level; wide ones in spans of SSPAN columns: diagonal span by one workgroup each, the rows below by all CUs (max_under: the most
+  // rows any separator of the level has to read under a span -- its band if it is a leaf)
   if (n <= 0) return 0;
   if (launch_steps(base, descs, n, max_n, W, y, backward, flags, gen, st)) return (int)hipGetLastError();
   const int nspan = (max_n + SSPAN - 1) / SSPAN;
   for (int i = 0; i < nspan; i++) {
     const int sp = backward ? nspan - 1 - i : i, col0 = sp * SSPAN;
-    const int below = max_n - (col0 + SSPAN); // rows under the span in the widest separator
+    const int below = min(max_n - (col0 + SSPAN), max_under); // rows under the span in the widest separator
     if (backward) {
       if (below > 0) hipLaunchKernelGGL((k_solve_panel<true, TL>), dim3(n, (below + SPANEL_BW_ROWS - 1) / SPANEL_BW_ROWS), dim3(256), 0, st, base, descs, y, col0);
       launch_span<true>(base, descs, n, W, y, col0, st);
@@ -3222,10 +3225,10 @@ int chol_launch_permute(const double *in, const int *perm, double *out, int n, i
   return (int)hipGetLastError();
 }
 int chol_launch_solve_dinv(const double *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st) { return launch_solve_dinv_t(base, descs, n, max_n, W, st); }
-int chol_launch_solve_trsv(const double *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st) { return launch_solve_trsv_t(base, descs, n, max_n, W, y, backward, flags, gen, st); }
+int chol_launch_solve_trsv(const double *base, const chol_trsv_desc *descs, int n, int max_n, int max_under, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st) { return launch_solve_trsv_t(base, descs, n, max_n, max_under, W, y, backward, flags, gen, st); }
 int chol_launch_solve_offdiag(const double *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st) { return launch_solve_offdiag_t(base, blocks, items, n_items, y, backward, st); }
 int chol32_launch_solve_dinv(const float *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st) { return launch_solve_dinv_t(base, descs, n, max_n, W, st); }
-int chol32_launch_solve_trsv(const float *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st) { return launch_solve_trsv_t(base, descs, n, max_n, W, y, backward, flags, gen, st); }
+int chol32_launch_solve_trsv(const float *base, const chol_trsv_desc *descs, int n, int max_n, int max_under, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st) { return launch_solve_trsv_t(base, descs, n, max_n, max_under, W, y, backward, flags, gen, st); }
 int chol32_launch_solve_offdiag(const float *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st) { return launch_solve_offdiag_t(base, blocks, items, n_items, y, backward, st); }
 int chol_launch_trsv_fwd(const double *base, const chol_trsv_desc *descs, int n, double *y, hipStream_t st)
 {

@@ -300,6 +300,8 @@ typedef struct {
 typedef struct {
   int64_t a_off; int n, lda; int x_off; int sep;
   int64_t dinv_off; /* the separator's 16x16 diagonal-block inverses in the solve workspace */
+  int band;         /* > 0: L(i, j) = 0 inside the separator's diagonal block for i - j > band (a LEAF's factor stays inside the envelope of A: the solve does not
+                     * read the rows of a span's panel beyond it); 0: dense */
 } chol_trsv_desc;
 typedef struct {
   int64_t a_off; int m, n, lda; int x_off, y_off; /* y(m) -= A x(n)  or  y(n) -= A^T x(m); one descriptor per stored row run of a block.  Forward sources of the
@@ -370,6 +372,7 @@ typedef struct {
   int n_ifw; int *ifw;
   int n_ibw; int *ibw;
   int max_n;                                        /* widest separator of the level */
+  int max_rows_under_span;                          /* most rows any separator of the level has to read under a 256-column span (band / dense) */
 } chol_solve_level;
 #define CHOL_SOLVE_FW_ROWS 256
 #define CHOL_SOLVE_BW_ROWS 1024

@@ -1897,7 +1897,7 @@ int chol_build_solve_level_part(const plan_t *p, int level, int rank, int world,
   for (int h = h0; h <= h1; h++) {
     int s = p->tree[h];
     if (!SOLVE_MINE(s)) continue;
-    chol_trsv_desc t = { p->panel_off[s], p->sep_size[s], p->panel_ld[s], p->sep_off[s], s, p->dinv_off[s] };
+    chol_trsv_desc t = { p->panel_off[s], p->sep_size[s], p->panel_ld[s], p->sep_off[s], s, p->dinv_off[s], 0 };
     if (p->sep_size[s] > w->max_n) w->max_n = p->sep_size[s];
     w->bw_start[w->n_trsv] = w->n_bw;
     w->trsv[w->n_trsv++] = t;
@@ -1917,6 +1917,24 @@ int chol_build_solve_level_part(const plan_t *p, int level, int rank, int world,
     }
   }
   w->bw_start[w->n_trsv] = w->n_bw;
+  w->max_rows_under_span = w->max_n;
+  if (level == p->levels - 1 && w->n_trsv > 0 && !getenv("CHOLAMD_SOLVE_NO_BAND")) { /* leaves: the element band of the tile skyline (a tile (ti, tj) with tj < sky[ti] is zero) */
+    unsigned char **sky = leaf_skylines(p);
+    w->max_rows_under_span = 0;
+    for (int t = 0; t < w->n_trsv; t++) {
+      const int s = w->trsv[t].sep, n = w->trsv[t].n;
+      int band = 0;
+      if (sky[s]) {
+        int md = 0;
+        for (int i = 0; i * CHOL_NB < n; i++) if (i - sky[s][i] > md) md = i - sky[s][i];
+        band = CHOL_NB * md + CHOL_NB - 1;
+        if (band >= n) band = 0;
+      }
+      w->trsv[t].band = band;
+      if ((band > 0 ? band : n) > w->max_rows_under_span) w->max_rows_under_span = band > 0 ? band : n;
+    }
+    free_skylines(sky, p->nsep);
+  }
   /* forward: for every ancestor separator `par` (levels above), chunks of 256 rows; a source = the stored rows of a block inside the
    * chunk (y_off = first row of the run, relative to the target separator) */
   int cap = 16, capg = 16;
