@@ -2971,8 +2971,9 @@ __global__ __launch_bounds__(256) void k_solve_gemv_fwd(const TL *__restrict__ b
                                                         double *__restrict__ y)
 {
   __shared__ double sx[256];
-  const chol_gemv_desc d = blocks[items[3 * blockIdx.x]];
-  const int r = items[3 * blockIdx.x + 1] + threadIdx.x, c0 = items[3 * blockIdx.x + 2], c1 = min(d.n, c0 + CHOL_SOLVE_COLS);
+  const chol_gemv_desc d = blocks[items[4 * blockIdx.x]];
+  const int r = items[4 * blockIdx.x + 1] + threadIdx.x, c0 = max(items[4 * blockIdx.x + 2], items[4 * blockIdx.x + 3]), c1 = min(d.n, items[4 * blockIdx.x + 2] + CHOL_SOLVE_COLS);
+  if (c0 >= c1) return; // (the rows of a leaf's panel are zero in front of their first entry of A: items[.. + 3])
   const TL *A = base + d.a_off + min(r, d.m - 1);
   const double *xs = y + d.y_off; // the separator's (already solved) part
   double acc = 0.0;
@@ -3029,6 +3030,7 @@ __global__ __launch_bounds__(256) void k_solve_gather_bwd(const TL *__restrict__
   for (int q = 0; q < 16; ++q) acc[q] = 0.0;
   for (int b = q0; b < q1; ++b) {
     const chol_gemv_desc d = blocks[b];
+    if (d.c_lo >= cw + 16) continue; // the run's rows are zero in the wave's columns
     const TL *A = base + d.a_off + (int64_t)cw * d.lda;
     const double *xs = y + d.x_off;
     for (int r0 = 0; r0 < d.m; r0 += 64 * PER) {

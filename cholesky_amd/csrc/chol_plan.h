@@ -306,6 +306,7 @@ typedef struct {
 typedef struct {
   int64_t a_off; int m, n, lda; int x_off, y_off; /* y(m) -= A x(n)  or  y(n) -= A^T x(m); one descriptor per stored row run of a block.  Forward sources of the
                                                    * target-centric level solve (chol_solve_level.fw): y_off = the run's first row inside the target separator */
+  int c_lo;                                       /* the run's rows are zero in the columns [0, c_lo) (rows of a LEAF's panel start at their first entry of A); 0: unknown */
 } chol_gemv_desc;
 
 struct cholamd_plan {
@@ -365,7 +366,7 @@ typedef struct {
   int n_grp; int *grp_start; int *grp_rows;         /* grp_start[n_grp+1]; grp_rows = (row0, y_off) pairs */
   int n_bw; chol_gemv_desc *bw; int *bw_start;      /* backward sources per separator: bw_start[n_trsv+1] */
   /* driver-level solve (cholamd_solve): the (ancestor, separator) blocks `bw` cut into row chunks, one workgroup each:
-   * forward: (block index, first row, first column) triples, chunks of CHOL_SOLVE_FW_ROWS rows x CHOL_SOLVE_COLS columns (the tall blocks of the top
+   * forward: (block index, first row, first column, first non-zero column of these rows) quadruples, chunks of CHOL_SOLVE_FW_ROWS rows x CHOL_SOLVE_COLS columns (the tall blocks of the top
    * levels are few: without the column cut 40 workgroups carried a level); backward: (first run, end run, first column, 0) quadruples -- 64 columns of
    * one separator over a range of its row runs `bw` (runs are cut at CHOL_SOLVE_BW_ROWS rows; the range is all of the separator's runs unless the level
    * then has fewer than CHOL_SOLVE_BW_ITEMS workgroups) */

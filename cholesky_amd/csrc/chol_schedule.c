@@ -966,6 +966,30 @@ static unsigned char **leaf_skylines(const plan_t *p)
   return sky;
 }
 static void free_skylines(unsigned char **sky, int ns) { if (!sky) return; for (int s = 1; s <= ns; s++) free(sky[s]); free(sky); }
+/* first[s][r] for every row r of a LEAF's panel (diagonal block and the rows into the ancestors): the first column with an entry of tril(P A P^T) --
+ * the row of L is zero in front of it (nothing reaches a leaf from below); n for a row without entries.  NULL for other separators. */
+static int **leaf_row_first(const plan_t *p)
+{
+  const int ns = p->nsep, L = p->levels;
+  int **first = calloc(ns + 1, sizeof(int *));
+  for (int h = 1 << (L - 1); h <= ns; h++) {
+    const int s = p->tree[h], n = p->sep_size[s], ld = p->panel_ld[s];
+    if (n <= 0) continue;
+    first[s] = malloc((size_t)ld * sizeof(int));
+    for (int r = 0; r < ld; r++) first[s][r] = r < n ? r : n;
+  }
+  for (int64_t e = 0; e < p->nnz_a; e++) {
+    const int64_t off = p->a_dst[e];
+    int lo = 1, hi = ns;
+    while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (p->panel_off[mid] <= off) lo = mid; else hi = mid - 1; }
+    const int s = lo;
+    if (!first[s]) continue;
+    const int64_t rel = off - p->panel_off[s];
+    const int ld = p->panel_ld[s], row = (int)(rel % ld), col = (int)(rel / ld);
+    if (col < first[s][row]) first[s][row] = col;
+  }
+  return first;
+}
 
 /* Early part of a wide follower's sources: dense 16x16 cell tasks  C(I, J) -= sum over the sources of E_I E_J^T  over the lower
  * triangle of the lim x lim target block at c_off, E = rows of the target in a source panel (off = row 0 in the first of k
@@ -1910,7 +1934,7 @@ int chol_build_solve_level_part(const plan_t *p, int level, int rank, int world,
         for (int r0 = 0; r0 < rr[q].m; r0 += CHOL_SOLVE_BW_ROWS) { /* rows of a run are consecutive in memory and in the ancestor's vector */
           if (w->n_bw == capb) { capb *= 2; w->bw = realloc(w->bw, (size_t)capb * sizeof(chol_gemv_desc)); }
           const int m = rr[q].m - r0 < CHOL_SOLVE_BW_ROWS ? rr[q].m - r0 : CHOL_SOLVE_BW_ROWS;
-          chol_gemv_desc g = { rr[q].off + r0, m, B->cols, B->ld, p->sep_off[par] + rr[q].row0 + r0, p->sep_off[s] };
+          chol_gemv_desc g = { rr[q].off + r0, m, B->cols, B->ld, p->sep_off[par] + rr[q].row0 + r0, p->sep_off[s], 0 };
           w->bw[w->n_bw++] = g;
         }
       free(rr);
@@ -1918,7 +1942,19 @@ int chol_build_solve_level_part(const plan_t *p, int level, int rank, int world,
   }
   w->bw_start[w->n_trsv] = w->n_bw;
   w->max_rows_under_span = w->max_n;
+  int **rfirst = NULL; /* leaf level: first entry of every panel row */
   if (level == p->levels - 1 && w->n_trsv > 0 && !getenv("CHOLAMD_SOLVE_NO_BAND")) { /* leaves: the element band of the tile skyline (a tile (ti, tj) with tj < sky[ti] is zero) */
+    rfirst = leaf_row_first(p);
+    for (int t = 0; t < w->n_trsv; t++) { /* ... and the first non-zero column of every row run into the ancestors */
+      const int s = w->trsv[t].sep;
+      if (!rfirst[s]) continue;
+      for (int q = w->bw_start[t]; q < w->bw_start[t + 1]; q++) {
+        const int pr = (int)((w->bw[q].a_off - p->panel_off[s]) % p->panel_ld[s]);
+        int f = w->bw[q].n;
+        for (int r = 0; r < w->bw[q].m; r++) if (rfirst[s][pr + r] < f) f = rfirst[s][pr + r];
+        w->bw[q].c_lo = f & ~15;
+      }
+    }
     unsigned char **sky = leaf_skylines(p);
     w->max_rows_under_span = 0;
     for (int t = 0; t < w->n_trsv; t++) {
@@ -1958,7 +1994,7 @@ int chol_build_solve_level_part(const plan_t *p, int level, int rank, int world,
           blk_run *rr; const int nr = block_runs(B, row0, row0 + 256, &rr);
           for (int q = 0; q < nr; q++) {
             if (w->n_fw == cap) { cap *= 2; w->fw = realloc(w->fw, cap * sizeof(chol_gemv_desc)); }
-            chol_gemv_desc g = { rr[q].off, rr[q].m, B->cols, B->ld, p->sep_off[s], rr[q].row0 };
+            chol_gemv_desc g = { rr[q].off, rr[q].m, B->cols, B->ld, p->sep_off[s], rr[q].row0, 0 };
             w->fw[w->n_fw++] = g;
           }
           free(rr);
@@ -1999,12 +2035,25 @@ int chol_build_solve_level_part(const plan_t *p, int level, int rank, int world,
     const int rows = pass ? CHOL_SOLVE_BW_ROWS : CHOL_SOLVE_FW_ROWS;
     int n = 0;
     for (int i = 0; i < w->n_bw; i++) n += ((w->bw[i].m + rows - 1) / rows) * ((w->bw[i].n + CHOL_SOLVE_COLS - 1) / CHOL_SOLVE_COLS);
-    int *it = malloc((size_t)(n > 0 ? 3 * n : 3) * sizeof(int)), k = 0;
-    for (int i = 0; i < w->n_bw; i++)
-      for (int c0 = 0; c0 < w->bw[i].n; c0 += CHOL_SOLVE_COLS)
-        for (int r0 = 0; r0 < w->bw[i].m; r0 += rows) { it[3 * k] = i; it[3 * k + 1] = r0; it[3 * k + 2] = c0; k++; }
+    int *it = malloc((size_t)(n > 0 ? 4 * n : 4) * sizeof(int)), k = 0;
+    for (int t = 0; t < w->n_trsv; t++) {
+      const int s = w->trsv[t].sep;
+      for (int i = w->bw_start[t]; i < w->bw_start[t + 1]; i++)
+        for (int c0 = 0; c0 < w->bw[i].n; c0 += CHOL_SOLVE_COLS)
+          for (int r0 = 0; r0 < w->bw[i].m; r0 += rows) {
+            int f = 0;
+            if (rfirst && rfirst[s]) { /* the first non-zero column of these rows */
+              const int pr = (int)((w->bw[i].a_off - p->panel_off[s]) % p->panel_ld[s]);
+              f = w->bw[i].n;
+              for (int r = r0; r < r0 + rows && r < w->bw[i].m; r++) if (rfirst[s][pr + r] < f) f = rfirst[s][pr + r];
+              f &= ~15;
+            }
+            it[4 * k] = i; it[4 * k + 1] = r0; it[4 * k + 2] = c0; it[4 * k + 3] = f; k++;
+          }
+    }
     if (pass) { w->ibw = it; w->n_ibw = n; } else { w->ifw = it; w->n_ifw = n; }
   }
+  if (rfirst) { for (int s = 1; s <= p->nsep; s++) free(rfirst[s]); free(rfirst); }
 #undef SOLVE_MINE
   return 0;
 }
