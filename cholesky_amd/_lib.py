@@ -123,6 +123,7 @@ def load():
     L.cholamd_plan_exchange_volume.argtypes = [vp, ci, ci, ci, vp]
     L.cholamd_plan_exchange_pieces.argtypes = [vp, ci, ci, ci, vp]
     L.cholamd_plan_solve_counts.argtypes = [vp, ci, ci, ci, vp]
+    L.cholamd_plan_solve_skips.argtypes = [vp, ci, vp, vp]
     L.cholamd_solve_sharded.argtypes = [vp, vp, vp, vp, vp, vp]
     L.cholamd_solve_sharded_f32.argtypes = [vp, vp, vp, vp, vp, vp]
     L.cholamd_solve_refine_sharded.argtypes = [vp, vp, vp, vp, ci, C.c_double, vp, vp, vp, vp]

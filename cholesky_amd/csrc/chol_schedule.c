@@ -1905,6 +1905,17 @@ int cholamd_plan_solve_counts(const cholamd_plan *p, int level, int rank, int wo
   return 0;
 }
 int chol_build_solve_level(const plan_t *p, int level, chol_solve_level *w) { return chol_build_solve_level_part(p, level, 0, 1, w); }
+int cholamd_plan_solve_skips(const cholamd_plan *p, int level, int *seps, int *runs)
+{
+  if (!p || level < 0 || level >= p->levels || !seps || !runs) { chol_set_error("solve_skips: bad arguments"); return CHOLAMD_ERR_ARG; }
+  chol_solve_level w;
+  int rc = chol_build_solve_level(p, level, &w);
+  if (rc) return rc;
+  for (int t = 0; t < w.n_trsv; t++) { seps[3 * t] = w.trsv[t].x_off; seps[3 * t + 1] = w.trsv[t].n; seps[3 * t + 2] = w.trsv[t].band; }
+  for (int q = 0; q < w.n_bw; q++) { runs[5 * q] = w.bw[q].x_off; runs[5 * q + 1] = w.bw[q].m; runs[5 * q + 2] = w.bw[q].y_off; runs[5 * q + 3] = w.bw[q].n; runs[5 * q + 4] = w.bw[q].c_lo; }
+  chol_solve_level_free(&w);
+  return 0;
+}
 /* the same for rank `rank` of `world` (distributed solve, mmat.rg:1394-1479 sharded like the factorisation): below the cut only the separators of
  * the rank's own subtrees -- their TRSVs and their panels into every ancestor, the shared top included; the levels above the cut complete (every
  * rank holds the whole factored top and solves it redundantly: only vectors travel) */

@@ -162,6 +162,15 @@ class Plan:
         check(self.L.cholamd_plan_solve_counts(self.h, level, rank, world, out.ctypes.data), "cholamd_plan_solve_counts")
         return tuple(int(v) for v in out)
 
+    def solve_skips(self, level):
+        """(seps, runs) of cholamd_plan_solve_skips: rows (first position, columns, band) per separator and (first row position, rows, first column
+        position, columns, c_lo) per (ancestor, separator) row run of the level's solve lists."""
+        cnt = self.solve_counts(level)
+        seps = np.zeros((max(cnt[0], 1), 3), dtype=np.int32)
+        runs = np.zeros((max(cnt[1], 1), 5), dtype=np.int32)
+        check(self.L.cholamd_plan_solve_skips(self.h, level, seps.ctypes.data, runs.ctypes.data), "cholamd_plan_solve_skips")
+        return seps[:cnt[0]], runs[:cnt[1]]
+
     def exchange_pieces(self, world, dist_top=2):
         """The column-block pieces of that exchange as rows (arena offset, elements, owner rank, heap index of the top separator)."""
         out = np.zeros((4096, 4), dtype=np.int64)

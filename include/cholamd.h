@@ -438,6 +438,12 @@ int cholamd_gather_factor_f32(cholamd_device *const *devs, float *const *arenas3
 /* host-side view of rank's share of the solve lists of one tree level: out = { separators, (ancestor, separator) row runs, forward row chunks, backward row
  * chunks, columns solved }; below the cut the ranks' shares tile the undivided lists, above it every rank holds them whole */
 int cholamd_plan_solve_counts(const cholamd_plan *p, int level, int rank, int world, int64_t out[5]);
+/* what the solve does not read of a level's panels (the structural zeros of the LEAVES: nothing reaches a leaf from below, so its factor stays inside
+ * the envelope of A).  seps: 3 ints per separator of the level's list -- first position in the permuted vector, columns, band (L(i, j) = 0 inside the
+ * diagonal block for i - j > band; 0: read whole); runs: 5 ints per (ancestor, separator) row run -- first position of the run's rows in the permuted
+ * vector, rows, first position of the separator's columns, columns, c_lo (the run's rows are zero in the separator's columns [0, c_lo)).  Counts as in
+ * cholamd_plan_solve_counts(p, level, 0, 1, .): out[0] separators, out[1] runs. */
+int cholamd_plan_solve_skips(const cholamd_plan *p, int level, int *seps, int *runs);
 int cholamd_solve_sharded(cholamd_device *d, const double *d_arena, const double *d_b, double *d_x, cholamd_comm *c, void *stream);
 int cholamd_solve_sharded_f32(cholamd_device *d, const float *d_arena32, const double *d_b, double *d_x, cholamd_comm *c, void *stream);
 int cholamd_solve_refine_sharded(cholamd_device *d, const float *d_arena32, const double *d_b, double *d_x, int max_iter, double tol,

@@ -432,3 +432,29 @@ def test_potrf_role_table(n, band):
     T = (n + 15) // 16
     owned = sorted(int(v) for v in got_ij.ravel() if v != 0xFFFF)
     assert owned == sorted(i | (j << 8) for j in range(2, T) for i in range(j, T))
+
+
+@pytest.mark.parametrize("case", ["lapl_400x400", "lapl_3375x3375"])
+def test_what_the_solve_skips_is_zero_in_the_reference_factor(case, plans, oracles):
+    """The solve does not read a leaf's rows beyond its band under a span, nor a leaf panel row in front of its first entry of A
+    (cholamd_plan_solve_skips).  In the oracle's factor (the reference's algorithm on dense blocks) every such entry is exactly zero, and
+    above the leaves nothing is skipped."""
+    P, O = plans[case], oracles[case]
+    Ld = np.tril(O.dense())
+    skipped = 0
+    for level in range(P.levels):
+        seps, runs = P.solve_skips(level)
+        if level < P.levels - 1:
+            assert not seps[:, 2].any() and not runs[:, 4].any()
+            continue
+        for off, n, band in seps:
+            if band > 0:
+                D = Ld[off:off + n, off:off + n]
+                i, j = np.indices(D.shape)
+                assert not D[i - j > band].any()
+                skipped += int((i - j > band).sum())
+        for x_off, m, y_off, n, c_lo in runs:
+            assert 0 <= c_lo <= n and c_lo % 16 == 0
+            assert not Ld[x_off:x_off + m, y_off:y_off + c_lo].any()
+            skipped += m * c_lo
+    assert skipped > 0
