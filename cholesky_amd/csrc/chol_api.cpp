@@ -745,7 +745,7 @@ static int build_solve(cholamd_device *d, int rank = 0, int world = 1)
     if (!rc) rc = upload_vec(&s.grp_start, w.grp_start, (size_t)w.n_grp + 1);
     if (!rc) rc = upload_vec(&s.grp_rows, w.grp_rows, (size_t)2 * w.n_grp);
     if (!rc) rc = upload_vec(&s.bw_start, w.bw_start, (size_t)w.n_trsv + 1);
-    s.n_ifw = w.n_ifw; s.n_ibw = w.n_ibw; s.max_n = w.max_n; s.max_under = w.max_rows_under_span;
+    s.n_ifw = w.n_ifw; s.n_ibw = w.n_ibw; s.max_n = w.max_n; s.max_under = w.banded && w.max_rows_under_span > 0 ? -w.max_rows_under_span : w.max_rows_under_span;
     if (!rc) rc = upload_vec(&s.ifw, w.ifw, (size_t)4 * w.n_ifw);
     if (!rc) rc = upload_vec(&s.ibw, w.ibw, (size_t)4 * w.n_ibw);
     chol_solve_level_free(&w);

@@ -2614,8 +2614,9 @@ __global__ __launch_bounds__(256) void k_solve_trsv(const TL *__restrict__ base,
 // lanes that hold block j's right-hand side form x_j = Linv_j r_j in registers (sixteen DPP multiply-adds: lane k of the row supplies r_k), publish it in
 // LDS, and every thread on the far side of the block subtracts its sixteen products.  No triangle in LDS, no shuffles, no second barrier: the next block's
 // lanes go on from their own registers.
-// PUB: the solution is written with agent-scope stores -- workgroups of the same launch read it (k_solve_step)
-template <bool BWD, bool PUB>
+// PUB: the solution is written with agent-scope stores -- workgroups of the same launch read it (k_solve_step); XAG: the right-hand side is read with
+// agent-scope loads -- atomics of this launch have touched it (k_solve_leaf32)
+template <bool BWD, bool PUB, bool XAG = false>
 __device__ __forceinline__ void span32_body(const float *__restrict__ base, const chol_trsv_desc &d, const double *__restrict__ Wall, double *__restrict__ y, int col0, double *sx)
 {
   const int lda = d.lda, tid = threadIdx.x, myb = tid >> 4, l16 = tid & 15;
@@ -2629,7 +2630,7 @@ __device__ __forceinline__ void span32_body(const float *__restrict__ base, cons
   const int nfull = ns / TS; // blocks of sixteen whole rows; block nfull (if nfull < nb) is the ragged one
 #pragma unroll
   for (int k = 0; k < TS; ++k) wl[k] = BWD ? Wb[l16 * TS + k] : Wb[k * TS + l16]; // forward: Linv(l, k); backward: Linv(k, l)
-  double r = live ? x[tid] : 0.0;
+  double r = live ? gload<XAG>(&x[tid]) : 0.0;
   if (!BWD) { // row tid: the columns of the blocks in front of its own
     const float *Lr = Lm + tid;
 #pragma unroll
@@ -2840,6 +2841,54 @@ __global__ __launch_bounds__(256) void k_solve_panel(const TL *__restrict__ base
 // so the chain per step is solve + flag + 1/16 of a SSPAN x SSPAN block instead of solve + launch + panel.
 #define STEP_NB 16
 #define STEP_MAX_SEPS 8
+// A level of banded LEAVES (fp32 factor): the whole triangle of a leaf by ONE workgroup in ONE launch.  A leaf's factor stays inside the envelope of A, and
+// with a band of at most SSPAN rows the panel under a span is a corner of the NEXT span's rows only: span by span the workgroup solves the span out of
+// registers (span32_body) and folds it into / gathers from those <= 256 rows itself.  Launch by launch the 512 leaves of 100^3 took 6 span launches (512
+// workgroups of one per CU: two rounds each) and 5 panel launches per sweep: 1.1 of the 7.1 ms of a solve.  Inside the launch the vector is written with
+// agent-scope stores and read with agent-scope loads (the gather's atomics are performed in L2: a plain load could hit a line the CU cached before them).
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_solve_leaf32(const float *__restrict__ base, const chol_trsv_desc *__restrict__ descs, const double *__restrict__ Wall,
+                                                      double *__restrict__ y)
+{
+  __shared__ __attribute__((aligned(16))) double sx[SSPAN];
+  const chol_trsv_desc d = descs[blockIdx.x];
+  const int n = d.n, lda = d.lda, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nspan = (n + SSPAN - 1) / SSPAN, band = d.band > 0 ? d.band : n;
+  const float *Lm = base + d.a_off;
+  double *x = y + d.x_off;
+  for (int i = 0; i < nspan; ++i) {
+    const int sp = BWD ? nspan - 1 - i : i, col0 = sp * SSPAN, r0 = col0 + SSPAN;
+    const int nr = min(n, r0 + band) - r0; // rows under the span inside the band (<= SSPAN; <= 0: none)
+    if (BWD && nr > 0) { // x(span) -= L(rows under it, span)^T x(rows): the rows are the head of the span solved before this one
+      double xa[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xa[u] = lane + 64 * u < nr ? gload<true>(&x[r0 + lane + 64 * u]) : 0.0;
+      gather_columns<4>(Lm + r0 + (int64_t)col0 * lda, lda, nr, SSPAN, xa, x + col0, lane, wave);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    span32_body<BWD, true, true>(base, d, Wall, y, col0, sx);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!BWD && nr > 0) { // x(rows under the span) -= L(rows, span) x(span)
+      sx[tid] = gload<true>(&x[col0 + tid]);
+      __syncthreads();
+      const float *A = Lm + r0 + min(tid, nr - 1) + (int64_t)col0 * lda;
+      double acc = 0.0;
+      for (int k = 0; k < SSPAN; k += 64) { // (the span's registers are free again: sixty-four loads in flight, four rounds)
+        float a[64];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) a[u] = A[(int64_t)(k + u) * lda];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) acc += (double)a[u] * sx[k + u];
+      }
+      if (tid < nr) gstore<true>(&x[r0 + tid], gload<true>(&x[r0 + tid]) - acc);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+}
+
 template <bool BWD, class TL> struct step_span;
 template <bool BWD> struct step_span<BWD, float> {
   static __device__ __forceinline__ void run(const float *base, const chol_trsv_desc &d, const double *Wall, double *y, int col0, double *sx) { span32_body<BWD, true>(base, d, Wall, y, col0, sx); }
@@ -3100,12 +3149,27 @@ static bool launch_steps(const TL *base, const chol_trsv_desc *descs, int n, int
   }
   return true;
 }
+#ifndef SOLVE_LEAF32
+#define SOLVE_LEAF32 1 /* 0: banded leaves span by span, launch by launch (A/B) */
+#endif
+static bool launch_leaves(const double *, const chol_trsv_desc *, int, const double *, double *, int, hipStream_t) { return false; }
+static bool launch_leaves(const float *base, const chol_trsv_desc *descs, int n, const double *W, double *y, int backward, hipStream_t st)
+{
+  if (!SOLVE_LEAF32) return false;
+  if (backward) hipLaunchKernelGGL((k_solve_leaf32<true>), dim3(n), dim3(256), 0, st, base, descs, W, y);
+  else hipLaunchKernelGGL((k_solve_leaf32<false>), dim3(n), dim3(256), 0, st, base, descs, W, y);
+  return true;
+}
 template <class TL>
 static int launch_solve_trsv_t(const TL *base, const chol_trsv_desc *descs, int n, int max_n, int max_under, const double *W, double *y, int backward, int *flags, int *gen,
                                hipStream_t st)
 { // all separators of a level; wide ones in spans of SSPAN columns: diagonal span by one workgroup each, the rows below by all CUs (max_under: the most
-  // rows any separator of the level has to read under a span -- its band if it is a leaf)
+  // rows any separator of the level has to read under a span -- its band if it is a leaf; negative: every separator of the level is banded within one span)
   if (n <= 0) return 0;
+  if (max_under < 0) {
+    if (max_n > SSPAN && launch_leaves(base, descs, n, W, y, backward, st)) return (int)hipGetLastError();
+    max_under = -max_under;
+  }
   if (launch_steps(base, descs, n, max_n, W, y, backward, flags, gen, st)) return (int)hipGetLastError();
   const int nspan = (max_n + SSPAN - 1) / SSPAN;
   for (int i = 0; i < nspan; i++) {

@@ -374,6 +374,8 @@ typedef struct {
   int n_ibw; int *ibw;
   int max_n;                                        /* widest separator of the level */
   int max_rows_under_span;                          /* most rows any separator of the level has to read under a 256-column span (band / dense) */
+  int banded;                                       /* every separator of the level is at most one span wide or a leaf with a band of at most one span: its whole
+                                                     * triangle can be solved by one workgroup in one launch (k_solve_leaf32) */
 } chol_solve_level;
 #define CHOL_SOLVE_FW_ROWS 256
 #define CHOL_SOLVE_BW_ROWS 1024

@@ -1980,6 +1980,7 @@ int chol_build_solve_level_part(const plan_t *p, int level, int rank, int world,
       w->trsv[t].band = band;
       if ((band > 0 ? band : n) > w->max_rows_under_span) w->max_rows_under_span = band > 0 ? band : n;
     }
+    w->banded = w->max_rows_under_span <= 256; /* (SSPAN of chol_kernels.hip) */
     free_skylines(sky, p->nsep);
   }
   /* forward: for every ancestor separator `par` (levels above), chunks of 256 rows; a source = the stored rows of a block inside the
