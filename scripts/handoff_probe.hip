@@ -13,7 +13,8 @@ template <int SCOPE> __device__ __forceinline__ double ld64(const double *p)
 {
   if (SCOPE == 0) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   double v;
-  asm volatile("global_load_dwordx2 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  if (SCOPE == 1) asm volatile("global_load_dwordx2 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  else asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); // (behind the flag load's buffer_inv)
   return v;
 }
 template <int SCOPE> __device__ __forceinline__ void sti(int *p, int v)
@@ -25,7 +26,9 @@ template <int SCOPE> __device__ __forceinline__ int ldi(const int *p)
 {
   if (SCOPE == 0) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int v;
-  asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  if (SCOPE == 1) asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  else if (SCOPE == 2) asm volatile("buffer_inv sc0\n\tglobal_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); // L1 invalidate, then a plain load
+  else asm volatile("buffer_inv sc1\n\tglobal_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
 template <int SCOPE> __global__ __launch_bounds__(256) void k(double *buf, int *flags, int prod, int cons, int iters, unsigned long long *out, int *bad)
@@ -64,16 +67,18 @@ int main()
   double *buf; int *flags, *bad; unsigned long long *out, h;
   hipMalloc(&buf, 4096); hipMalloc(&flags, 1024); hipMalloc(&out, 8); hipMalloc(&bad, 4);
   const int iters = 2000;
-  for (int scope = 0; scope < 2; scope++)
+  for (int scope = 0; scope < 4; scope++)
     for (int cons : { 8, 16, 1, 4 }) {
-      if (scope == 1 && cons % 8 != 0 && cons != 1) continue; // one cross-XCD run of the L2 scope only: it is not coherent there (shown, bounded)
+      if (scope >= 1 && cons % 8 != 0 && cons != 1) continue; // one cross-XCD run of the L2 scopes only: they are not coherent there (shown, bounded)
       hipMemset(flags, 0, 1024); hipMemset(bad, 0, 4); hipMemset(buf, 0, 4096);
       if (scope == 0) hipLaunchKernelGGL(k<0>, dim3(32), dim3(256), 0, 0, buf, flags, 0, cons, iters, out, bad);
-      else hipLaunchKernelGGL(k<1>, dim3(32), dim3(256), 0, 0, buf, flags, 0, cons, iters, out, bad);
+      else if (scope == 1) hipLaunchKernelGGL(k<1>, dim3(32), dim3(256), 0, 0, buf, flags, 0, cons, iters, out, bad);
+      else if (scope == 2) hipLaunchKernelGGL(k<2>, dim3(32), dim3(256), 0, 0, buf, flags, 0, cons, iters, out, bad);
+      else hipLaunchKernelGGL(k<3>, dim3(32), dim3(256), 0, 0, buf, flags, 0, cons, iters, out, bad);
       hipDeviceSynchronize();
       int hb; hipMemcpy(&h, out, 8, hipMemcpyDeviceToHost); hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost);
       printf("%s, producer workgroup 0 -> consumer workgroup %2d (%s): %.2f us per round trip (data 2 KB + flag there, flag back), %d mismatches\n",
-             scope == 0 ? "agent scope (sc1)" : "L2 scope (plain stores, sc0 loads)", cons, cons % 8 == 0 ? "same XCD" : "other XCD", (double)h * 0.01 / iters, hb);
+             scope == 0 ? "agent scope (sc1)" : scope == 1 ? "L2 scope (plain stores, sc0 loads)" : scope == 2 ? "plain stores, buffer_inv sc0 + plain loads" : "plain stores, buffer_inv sc1 + plain loads", cons, cons % 8 == 0 ? "same XCD" : "other XCD", (double)h * 0.01 / iters, hb);
       fflush(stdout);
     }
   return 0;
