@@ -211,3 +211,39 @@ def test_mixed_precision_sharded_over_the_local_communicator(dims, world, dist_t
     iters, rel = devs[0].solve_refine(arenas[0], d_b, d_x, max_iter=20, tol=1e-13)
     assert rel <= 1e-12 and iters <= 8, (iters, rel)
     assert np.abs(d_x.cpu().numpy() - xo).max() <= TOL_X * max(1.0, np.abs(xo).max())
+
+
+def test_the_leaf_skips_of_the_solve_change_nothing(monkeypatch):
+    """16 leaves of 864 columns with a band of 159 rows (24^3, 5 levels): the solve reads `band` rows under a span and a panel row from its
+    first entry of A on, and an fp32 factor takes every leaf's triangle in ONE launch (k_solve_leaf32).  CHOLAMD_SOLVE_NO_BAND=1 (read when a
+    device object builds its solve lists) switches all of that off: same x from the same factor, fp64 and fp32."""
+    import torch
+    import cholesky_amd as ca
+    prob = ca.Problem(24, 24, 24, 5, 32)
+    plan = prob.plan()
+    seps, runs = plan.solve_skips(plan.levels - 1)
+    assert len(seps) == 16 and (seps[:, 1] > 256).all() and (seps[:, 2] > 0).all() and (seps[:, 2] <= 256).all() and runs[:, 4].any()
+    d_b = torch.from_numpy(prob.rhs()).cuda()
+    xs = {}
+    for skip in (True, False):
+        if skip:
+            monkeypatch.delenv("CHOLAMD_SOLVE_NO_BAND", raising=False)
+        else:
+            monkeypatch.setenv("CHOLAMD_SOLVE_NO_BAND", "1")
+        dev = ca.Device(plan, 0)
+        a = dev.new_arena()
+        dev.fill(a)
+        dev.factor(a)
+        a32 = dev.new_arena_f32()
+        dev.fill_f32(a32)
+        dev.factor_f32(a32)
+        dev.sync()
+        assert dev.info() == (0, 0)
+        x64, x32 = torch.empty_like(d_b), torch.empty_like(d_b)
+        dev.solve(a, d_b, x64)
+        dev.solve_f32(a32, d_b, x32)
+        dev.sync()
+        assert dev.residual(d_b, x64) <= 1e-12
+        xs[skip] = (x64.cpu().numpy(), x32.cpu().numpy())
+    for k in (0, 1):  # (the sums are atomic: equal to rounding, not bit for bit)
+        assert np.abs(xs[True][k] - xs[False][k]).max() <= 1e-12 * np.abs(xs[False][k]).max()
