@@ -40,6 +40,7 @@ struct solve_dev {
   chol_gemv_desc *fw = nullptr, *bw = nullptr;
   int *grp_start = nullptr, *grp_rows = nullptr, *bw_start = nullptr;
   int n_ifw = 0, n_ibw = 0, max_n = 0, max_under = 0;
+  int64_t w256_off = -1; // this level's explicit span inverses in cholamd_device::w256 (levels of at most 8 separators wider than a span); -1: none
   int *ifw = nullptr, *ibw = nullptr;
 };
 struct timed_launch { hipEvent_t a, b; int kind; };
@@ -59,6 +60,9 @@ struct cholamd_device {
   double *ws_solve = nullptr; // 16x16 inverses of the diagonal blocks of the arena being solved with
   int *step_flags = nullptr;  // flags of the step launches of the wide top separators' span chains (k_solve_step): one per separator of a level, 64 ints
   int step_gen = 0;           // ... and the number of the last such launch (a flag equal to it: the launch's span is solved)
+  double *w256 = nullptr;     // explicit inverses of the 256-column diagonal spans of the wide top separators (k_solve_inv256, recomputed with the 16x16 inverses)
+  double *step_xt = nullptr;  // 8 x 256 doubles: a step launch's x_k before it replaces the right-hand side
+  bool keep_inverses = false; // the correction solves of a refinement: same factor as the solve before them, its diagonal inverses (16x16, spans) are kept
   int *info = nullptr;      // [0] first failing column, [1] separator; two slots of two ints: the program launch alternates between them (each launch clears the other
                             // one for the next: no memset node per factorisation), every other path uses slot 0
   int *info_last = nullptr; // the slot of the most recent factorisation (cholamd_factor_info)
@@ -133,6 +137,7 @@ static void free_solve_lists(cholamd_device *d)
 {
   for (auto &s : d->sv) { (void)hipFree(s.trsv); (void)hipFree(s.fw); (void)hipFree(s.bw); (void)hipFree(s.grp_start); (void)hipFree(s.grp_rows); (void)hipFree(s.bw_start); (void)hipFree(s.ifw); (void)hipFree(s.ibw); }
   d->sv.clear();
+  (void)hipFree(d->w256); d->w256 = nullptr;
   (void)hipFree(d->zr_sub); d->zr_sub = nullptr; d->n_zr_sub = 0;
   d->solve_ready = false;
 }
@@ -267,7 +272,7 @@ extern "C" void cholamd_device_destroy(cholamd_device *d)
   free_solve_lists(d);
   (void)hipFree(d->ws32); (void)hipFree(d->csr_ptr); (void)hipFree(d->csr_col); (void)hipFree(d->csr_val); (void)hipFree(d->rvec); (void)hipFree(d->dxvec); (void)hipFree(d->partial);
   (void)hipFree(d->xstage); (void)hipFree(d->xdesc);
-  (void)hipFree(d->ws); (void)hipFree(d->ws_solve); (void)hipFree(d->step_flags); (void)hipFree(d->info); (void)hipFree(d->progress); (void)hipFree(d->a_dst); (void)hipFree(d->a_val); (void)hipFree(d->perm); (void)hipFree(d->ytmp);
+  (void)hipFree(d->ws); (void)hipFree(d->ws_solve); (void)hipFree(d->step_flags); (void)hipFree(d->w256); (void)hipFree(d->step_xt); (void)hipFree(d->info); (void)hipFree(d->progress); (void)hipFree(d->a_dst); (void)hipFree(d->a_val); (void)hipFree(d->perm); (void)hipFree(d->ytmp);
   for (int q = 0; q < 2; q++) { (void)hipFree(d->top_dst[q]); (void)hipFree(d->top_val[q]); }
   for (auto &t : d->tl) { d->pool.push_back(t.a); d->pool.push_back(t.b); }
   for (auto e : d->pool) (void)hipEventDestroy(e);
@@ -753,7 +758,17 @@ static int build_solve(cholamd_device *d, int rank = 0, int world = 1)
   }
   if (!d->ytmp) HIPCHK(hipMalloc((void **)&d->ytmp, (size_t)d->plan->n * sizeof(double)));
   if (!d->ws_solve) HIPCHK(hipMalloc((void **)&d->ws_solve, (size_t)(d->plan->ws_doubles > 0 ? d->plan->ws_doubles : 1) * sizeof(double)));
-  if (!d->step_flags) { HIPCHK(hipMalloc((void **)&d->step_flags, 64 * sizeof(int))); HIPCHK(hipMemset(d->step_flags, 0, 64 * sizeof(int))); }
+  if (!d->step_flags) { HIPCHK(hipMalloc((void **)&d->step_flags, 256 * sizeof(int))); HIPCHK(hipMemset(d->step_flags, 0, 256 * sizeof(int))); }
+  if (!d->step_xt) HIPCHK(hipMalloc((void **)&d->step_xt, 8 * 256 * sizeof(double)));
+  int64_t w256 = 0; // explicit inverses of the diagonal spans where the span chain is the solve's critical path: the levels of at most 8 separators
+  if (!std::getenv("CHOLAMD_SOLVE_NO_INV256"))
+    for (int lvl = 0; lvl < L; lvl++) {
+      solve_dev &s = d->sv[lvl];
+      if (s.n_trsv < 1 || s.n_trsv > 8 || s.max_n <= 256) continue;
+      s.w256_off = w256;
+      w256 += (int64_t)s.n_trsv * ((s.max_n + 255) / 256) * 65536;
+    }
+  if (w256 > 0) HIPCHK(hipMalloc((void **)&d->w256, (size_t)w256 * sizeof(double)));
   d->solve_ready = true;
   return 0;
 }
@@ -761,10 +776,17 @@ static int build_solve(cholamd_device *d, int rank = 0, int world = 1)
 // first position of the shared top of the tree in the permuted vector (the separators above the cut are the last labels: a contiguous tail, as in the arena)
 static int64_t top_vec_offset(const cholamd_device *d) { return d->solve_world > 1 ? d->plan->sep_off[d->plan->nsep - (d->solve_world - 1) + 1] : d->plan->n; }
 // the streamed solve (every panel read once) with a factor of element type TL; vectors and arithmetic are fp64
+struct keep_inverses_scope { // set on the devices of a refinement after its first solve, cleared on every way out
+  cholamd_device *const *devs; int n;
+  keep_inverses_scope(cholamd_device *const *devs_, int n_) : devs(devs_), n(n_) { for (int g = 0; g < n; g++) devs[g]->keep_inverses = true; }
+  ~keep_inverses_scope() { for (int g = 0; g < n; g++) devs[g]->keep_inverses = false; }
+};
 static int lsolve_dinv(const double *a, const chol_trsv_desc *t, int n, int mx, double *W, hipStream_t st) { return chol_launch_solve_dinv(a, t, n, mx, W, st); }
 static int lsolve_dinv(const float *a, const chol_trsv_desc *t, int n, int mx, double *W, hipStream_t st) { return chol32_launch_solve_dinv(a, t, n, mx, W, st); }
-static int lsolve_trsv(cholamd_device *d, const double *a, const chol_trsv_desc *t, int n, int mx, int mu, const double *W, double *y, int bw, hipStream_t st) { return chol_launch_solve_trsv(a, t, n, mx, mu, W, y, bw, d->step_flags, &d->step_gen, st); }
-static int lsolve_trsv(cholamd_device *d, const float *a, const chol_trsv_desc *t, int n, int mx, int mu, const double *W, double *y, int bw, hipStream_t st) { return chol32_launch_solve_trsv(a, t, n, mx, mu, W, y, bw, d->step_flags, &d->step_gen, st); }
+static int lsolve_trsv(cholamd_device *d, const double *a, const chol_trsv_desc *t, int n, int mx, int mu, const double *W, double *y, int bw, const double *W256, hipStream_t st) { return chol_launch_solve_trsv(a, t, n, mx, mu, W, y, bw, d->step_flags, &d->step_gen, W256, d->step_xt, st); }
+static int lsolve_trsv(cholamd_device *d, const float *a, const chol_trsv_desc *t, int n, int mx, int mu, const double *W, double *y, int bw, const double *W256, hipStream_t st) { return chol32_launch_solve_trsv(a, t, n, mx, mu, W, y, bw, d->step_flags, &d->step_gen, W256, d->step_xt, st); }
+static int lsolve_inv256(const double *a, const chol_trsv_desc *t, int n, int mx, const double *W16, double *W256, hipStream_t st) { return chol_launch_solve_inv256(a, t, n, mx, W16, W256, st); }
+static int lsolve_inv256(const float *a, const chol_trsv_desc *t, int n, int mx, const double *W16, double *W256, hipStream_t st) { return chol32_launch_solve_inv256(a, t, n, mx, W16, W256, st); }
 static int lsolve_off(const double *a, const chol_gemv_desc *g, const int *it, int n, double *y, int bw, hipStream_t st) { return chol_launch_solve_offdiag(a, g, it, n, y, bw, st); }
 static int lsolve_off(const float *a, const chol_gemv_desc *g, const int *it, int n, double *y, int bw, hipStream_t st) { return chol32_launch_solve_offdiag(a, g, it, n, y, bw, st); }
 // The streamed solve in three phases, so that a partitioned device can put the two vector reductions of the distributed solve between them:
@@ -782,16 +804,17 @@ template <class TL> static int solve_phase(cholamd_device *d, const TL *d_arena,
     HIPCHK((hipError_t)chol_launch_permute(d_b, d->perm, y, n, 0, st));
     if (d->n_zr_sub > 0) { hipLaunchKernelGGL(k_zero_ranges, dim3(16, d->n_zr_sub), dim3(256), 0, st, y, d->zr_sub, d->n_zr_sub); HIPCHK(hipGetLastError()); }
     // the 16x16 inverses of this arena's diagonal blocks (the factorisation's workspace belongs to the last arena factored)
-    for (int lvl = 0; lvl < L; lvl++) {
+    for (int lvl = 0; lvl < L && !d->keep_inverses; lvl++) {
       const solve_dev &s = d->sv[lvl];
       HIPCHK((hipError_t)lsolve_dinv(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, st));
+      if (s.w256_off >= 0 && d->w256) HIPCHK((hipError_t)lsolve_inv256(d_arena, s.trsv, s.n_trsv, s.max_n, d->ws_solve, d->w256 + s.w256_off, st));
     }
   }
   if (phase <= 1) {
     const int hi = phase == 0 ? L - 1 : cut - 1, lo = phase == 0 ? cut : 0;
     for (int lvl = hi; lvl >= lo; lvl--) { // forward, mmat.rg:1395-1435: TRSV per separator, then its panel into the ancestors
       const solve_dev &s = d->sv[lvl];
-      HIPCHK((hipError_t)lsolve_trsv(d, d_arena, s.trsv, s.n_trsv, s.max_n, s.max_under, d->ws_solve, y, 0, st));
+      HIPCHK((hipError_t)lsolve_trsv(d, d_arena, s.trsv, s.n_trsv, s.max_n, s.max_under, d->ws_solve, y, 0, s.w256_off >= 0 && d->w256 ? d->w256 + s.w256_off : nullptr, st));
       HIPCHK((hipError_t)lsolve_off(d_arena, s.bw, s.ifw, s.n_ifw, y, 0, st));
     }
   }
@@ -799,7 +822,7 @@ template <class TL> static int solve_phase(cholamd_device *d, const TL *d_arena,
     for (int lvl = 0; lvl < L; lvl++) { // backward, mmat.rg:1438-1479: gather from the ancestors, then TRSV^T
       const solve_dev &s = d->sv[lvl];
       HIPCHK((hipError_t)lsolve_off(d_arena, s.bw, s.ibw, s.n_ibw, y, 1, st));
-      HIPCHK((hipError_t)lsolve_trsv(d, d_arena, s.trsv, s.n_trsv, s.max_n, s.max_under, d->ws_solve, y, 1, st));
+      HIPCHK((hipError_t)lsolve_trsv(d, d_arena, s.trsv, s.n_trsv, s.max_n, s.max_under, d->ws_solve, y, 1, s.w256_off >= 0 && d->w256 ? d->w256 + s.w256_off : nullptr, st));
     }
     if (d->solve_world > 1 && d->solve_rank != 0) { // the top's part of the solution is counted once in the sum that follows: rank 0's
       const int64_t t0 = top_vec_offset(d);
@@ -968,6 +991,7 @@ extern "C" int cholamd_solve_refine(cholamd_device *d, const float *d_arena32, c
   // x0 = M^-1 b with M = L32 L32^T; then x += M^-1 (b - A x) until ||b - A x|| <= tol ||b||
   rc = solve_streamed(d, d_arena32, d_b, d_x, st);
   if (rc) return rc;
+  keep_inverses_scope keep(&d, 1);
   double rel = 0.0;
   int it = 0;
   for (;; ++it) {
@@ -2144,6 +2168,7 @@ extern "C" int cholamd_solve_refine_sharded(cholamd_device *d, const float *d_ar
   const int n = d->plan->n;
   if (max_iter < 0) max_iter = 0;
   if ((rc = solve_sharded_t<float>(d, d_arena32, d_b, d_x, c, st))) return rc;
+  keep_inverses_scope keep(&d, 1);
   double rel = 0.0;
   int it = 0;
   for (;; ++it) {
@@ -2231,6 +2256,7 @@ extern "C" int cholamd_solve_refine_multi(cholamd_device *const *devs, const flo
   std::vector<const double *> rv(n);
   std::vector<double *> dx(n);
   for (int g = 0; g < n; g++) { rv[g] = devs[g]->rvec; dx[g] = devs[g]->dxvec; }
+  keep_inverses_scope keep(devs, n);
   double rel = 0.0;
   int it = 0;
   for (;; ++it) {

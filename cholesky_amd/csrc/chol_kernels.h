@@ -25,7 +25,12 @@ int chol_launch_update(double *base, const chol_upd_task *tasks, const chol_upd_
 int chol_launch_update_mt(double *base, const chol_upd_task *tasks, const chol_upd_src *srcs, int ntask, int64_t arena_elems, hipStream_t st);
 int chol_launch_permute(const double *in, const int *perm, double *out, int n, int inverse, hipStream_t st);
 int chol_launch_solve_dinv(const double *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st);
-int chol_launch_solve_trsv(const double *base, const chol_trsv_desc *descs, int n, int max_n, int max_under, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st);
+int chol_launch_solve_trsv(const double *base, const chol_trsv_desc *descs, int n, int max_n, int max_under, const double *W, double *y, int backward, int *flags, int *gen, const double *W256, double *xt, hipStream_t st);
+/* explicit inverses of the 256-column diagonal spans of a level's separators (levels of at most 8 separators wider than a span): W256[(separator * spans + span) * 65536
+ * + column * 256 + row], from the 16x16 inverses W16 of chol_launch_solve_dinv; passed to chol_launch_solve_trsv (with xt: 8 x 256 doubles of scratch) they turn
+ * the span solve of the step launches into a matrix-vector product over sixteen workgroups (k_solve_stepw); NULL: k_solve_step */
+int chol_launch_solve_inv256(const double *base, const chol_trsv_desc *descs, int n, int max_n, const double *W16, double *W256, hipStream_t st);
+int chol32_launch_solve_inv256(const float *base, const chol_trsv_desc *descs, int n, int max_n, const double *W16, double *W256, hipStream_t st);
 int chol_launch_solve_offdiag(const double *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st);
 int chol_launch_trsv_fwd(const double *base, const chol_trsv_desc *descs, int n, double *y, hipStream_t st);
 int chol_launch_gemv_fwd(const double *base, const chol_gemv_desc *descs, const int *grp_start, const int *grp_rows, int ngroups, double *y, hipStream_t st);
@@ -40,7 +45,7 @@ int chol32_launch_update_mt(float *base, const chol_upd_task *tasks, const chol_
 int chol32_launch_solve_dinv(const float *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st);
 /* flags / gen: STEP flags of the device object (one int per separator of a top level, zero at allocation) and its launch counter (host) -- the step launches
  * of the wide top separators (k_solve_step); NULL: launch by launch */
-int chol32_launch_solve_trsv(const float *base, const chol_trsv_desc *descs, int n, int max_n, int max_under, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st);
+int chol32_launch_solve_trsv(const float *base, const chol_trsv_desc *descs, int n, int max_n, int max_under, const double *W, double *y, int backward, int *flags, int *gen, const double *W256, double *xt, hipStream_t st);
 int chol32_launch_solve_offdiag(const float *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st);
 int chol_launch_residual(const int64_t *ptr, const int *col, const double *val, const double *b, const double *x, double *r, int n, double *partial, hipStream_t st);
 int chol_launch_axpy1(double *x, const double *dx, int n, hipStream_t st);

@@ -3013,6 +3013,210 @@ __global__ __launch_bounds__(256) void k_solve_step(const TL *__restrict__ base,
   }
 }
 
+// ---- the span chain of the wide top separators with EXPLICIT inverses of the 256 x 256 diagonal spans (round 4) ----
+// k_solve_step's chain per span is the span solve itself: 10-15 us of sixteen dependent 16-column block steps in one workgroup.  With inv(L_kk) at hand
+// (k_solve_inv256, once per solve: the factor's 16x16 inverses doubled up block column by block column on the matrix cores) x_k = inv(L_kk) r_k is a
+// 256 x 256 triangular matrix-vector product with NO chain: sixteen workgroups take sixteen rows (forward) / columns (backward) each, reading a right-hand
+// side that was final before the launch.  Roles by blockIdx.y:
+//   0 .. 15    part p of x_k into the separator's scratch vector xt (the right-hand side must stay until every part has read it), then flag p = gen
+//   16 .. 31   wait for all sixteen flags; copy part p of xt into the vector; the SSPAN rows / columns the next span needs of span k's panel (as k_solve_step's
+//              middle role, with x_k from xt)
+//   32 ..      the rest of the previous span's panel (as k_solve_step)
+// W256: [column][row] (column-major, 256 x 256 doubles per span), lower triangle in 16 x 16 blocks; blocks above the diagonal are never written or read.
+template <class TL>
+__global__ __launch_bounds__(64) void k_solve_inv256(const TL *__restrict__ base, const chol_trsv_desc *__restrict__ descs, const double *__restrict__ W16all,
+                                                     double *__restrict__ W256, int nspan_max)
+{ // one wave per (separator, span, block column j): X(i, j) = -inv(L_ii) sum_{k = j .. i-1} L(i, k) X(k, j), X(j, j) = inv(L_jj); the column's blocks stay in the
+  // wave's registers in the fp64 MFMA result layout (register q of lane (n, g): row g + 4 q, column n), which is also the layout of the next product's second
+  // operand with k = g + 4 s in instruction s
+  const chol_trsv_desc d = descs[blockIdx.x];
+  const int sp = blockIdx.y, j = blockIdx.z, col0 = sp * SSPAN;
+  if (d.n <= col0) return;
+  const int ns = min(d.n - col0, SSPAN), nb = (ns + TS - 1) / TS;
+  if (j >= nb) return;
+  const int lane = threadIdx.x, n16 = lane & 15, g = lane >> 4, lda = d.lda;
+  const TL *Lm = base + d.a_off + col0 + (int64_t)col0 * lda;
+  const double *W16 = W16all + d.dinv_off + (int64_t)(col0 / TS) * TS * TS; // W16[b * 256 + c * 16 + r] = inv(L_bb)(r, c)
+  double *out = W256 + ((int64_t)blockIdx.x * nspan_max + sp) * (SSPAN * SSPAN) + (int64_t)(TS * j + n16) * SSPAN + g;
+  d4 X[SSPAN / TS];
+#pragma unroll
+  for (int i = 0; i < SSPAN / TS; ++i) X[i] = (d4){ 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+  for (int i = 0; i < SSPAN / TS; ++i) {
+    if (i == j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) X[i][q] = W16[i * TS * TS + n16 * TS + g + 4 * q];
+    } else if (i > j && i < nb) {
+      d4 S = { 0.0, 0.0, 0.0, 0.0 };
+      const int row = min(TS * i + n16, ns - 1); // (first operand: lane = row of L(i, k))
+#pragma unroll
+      for (int k = 0; k < SSPAN / TS; ++k) {
+        if (k >= j && k < i) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) S = __builtin_amdgcn_mfma_f64_16x16x4f64((double)Lm[row + (int64_t)(TS * k + g + 4 * s) * lda], X[k][s], S, 0, 0, 0);
+        }
+      }
+      d4 D = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+      for (int s = 0; s < 4; ++s) D = __builtin_amdgcn_mfma_f64_16x16x4f64(W16[i * TS * TS + (g + 4 * s) * TS + n16], S[s], D, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) X[i][q] = -D[q];
+    }
+    if (i >= j && i < nb) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) out[TS * i + 4 * q] = X[i][q];
+    }
+  }
+}
+// every one of the sixteen flags equals gen (bounded; false: gave up)
+__device__ __forceinline__ bool wait_parts16(const int *f, int gen, int tid, int *sflag)
+{
+  if (tid < 64) {
+    bool ok = false;
+    for (int it = 0; it < (1 << 22); ++it) {
+      const int v = tid < STEP_NB ? __hip_atomic_load(&f[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gen;
+      if (__all(v == gen)) { ok = true; break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    if (tid == 0) *sflag = ok;
+  }
+  __syncthreads();
+  const bool r = *(volatile int *)sflag != 0;
+  __syncthreads();
+  return r;
+}
+template <bool BWD, class TL>
+__global__ __launch_bounds__(256) void k_solve_stepw(const TL *__restrict__ base, const chol_trsv_desc *__restrict__ descs, const double *__restrict__ W256,
+                                                     int nspan_max, double *__restrict__ y, double *__restrict__ xtmp, int col0, int *__restrict__ flags, int gen)
+{
+  __shared__ __attribute__((aligned(16))) double sx[SSPAN];
+  const chol_trsv_desc d = descs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lda = d.lda, n = d.n;
+  const int role = blockIdx.y;
+  if (n <= col0) return; // (every role of a separator without this span)
+  const TL *Lm = base + d.a_off;
+  double *x = y + d.x_off, *xt = xtmp + blockIdx.x * SSPAN;
+  int *fl = flags + blockIdx.x * STEP_NB;
+  const int ns = min(n - col0, SSPAN);
+  if (role < STEP_NB) { // part `role` of x_k = inv(L_kk) r_k (forward: sixteen rows) / inv(L_kk)^T r_k (backward: sixteen columns)
+    const int p = role, r = tid & 15, kp = tid >> 4;
+    const double *W = W256 + ((int64_t)blockIdx.x * nspan_max + col0 / SSPAN) * (SSPAN * SSPAN);
+    if (TS * p < ns) {
+      double acc = 0.0;
+      if (!BWD) { // thread (row 16 p + r, columns 16 kp .. + 15), the blocks left of the diagonal one and it
+        if (kp <= p) {
+          double w[TS], v[TS];
+#pragma unroll
+          for (int u = 0; u < TS; ++u) { w[u] = W[(int64_t)(TS * kp + u) * SSPAN + TS * p + r]; v[u] = x[col0 + TS * kp + u]; } // (columns < ns: kp <= p)
+#pragma unroll
+          for (int u = 0; u < TS; ++u) acc += w[u] * v[u];
+        }
+        sx[kp * TS + r] = acc;
+        __syncthreads();
+        if (tid < TS) {
+          double sum = 0.0;
+#pragma unroll
+          for (int q = 0; q < TS; ++q) sum += sx[q * TS + tid];
+          if (TS * p + tid < ns) gstore<true>(&xt[TS * p + tid], sum);
+        }
+      } else { // thread (column 16 p + kp, rows 16 g + r of the blocks g >= p): sum over the sixteen lanes of a row
+        const int c = TS * p + kp;
+        if (c < ns) {
+          const double *Wc = W + (int64_t)c * SSPAN;
+#pragma unroll
+          for (int gq = 0; gq < SSPAN / TS; ++gq) {
+            const int row = TS * gq + r;
+            if (gq >= p && row < ns) acc += Wc[row] * x[col0 + row];
+          }
+        }
+        acc = row_sum16(acc);
+        if (r == 0 && c < ns) gstore<true>(&xt[c], acc);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&fl[p], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (role < 2 * STEP_NB) {
+    const int part = role - STEP_NB;
+    if (!BWD) { // rows col0 + SSPAN + 16 part .. + 15 under the columns of span k: thread (row, sixteenth of the columns)
+      const int r = tid & 15, kp = tid >> 4, row = col0 + SSPAN + TS * part + r;
+      const bool rows = col0 + SSPAN + TS * part < n;
+      TL a[TS];
+      if (rows) {
+        const TL *A = Lm + min(row, n - 1) + (int64_t)(col0 + TS * kp) * lda;
+#pragma unroll
+        for (int u = 0; u < TS; ++u) a[u] = A[(int64_t)u * lda];
+      }
+      const bool ok = wait_parts16(fl, gen, tid, (int *)sx);
+      if (tid < TS && TS * part + tid < ns) gstore<true>(&x[col0 + TS * part + tid], ok ? gload<true>(&xt[TS * part + tid]) : __builtin_nan(""));
+      if (!rows) return;
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < TS; ++u) acc += (double)a[u] * gload<true>(&xt[TS * kp + u]);
+      sx[kp * TS + r] = acc;
+      __syncthreads();
+      if (tid < TS) {
+        double sum = 0.0;
+#pragma unroll
+        for (int q = 0; q < TS; ++q) sum += sx[q * TS + tid];
+        if (!ok) sum = __builtin_nan("");
+        if (row < n) unsafeAtomicAdd(&x[row], -sum);
+      }
+    } else { // the rows of span k into the columns col0 - SSPAN + 16 part .. + 15 of span k - 1: wave w the rows 64 w .. 64 w + 63
+      const int c0 = col0 - SSPAN + TS * part, row = 64 * wave + lane;
+      TL a[TS];
+      if (col0 > 0) {
+        const TL *A = Lm + col0 + min(row, ns - 1) + (int64_t)c0 * lda;
+#pragma unroll
+        for (int q = 0; q < TS; ++q) a[q] = A[(int64_t)q * lda];
+      }
+      const bool ok = wait_parts16(fl, gen, tid, (int *)sx);
+      if (tid < TS && TS * part + tid < ns) gstore<true>(&x[col0 + TS * part + tid], ok ? gload<true>(&xt[TS * part + tid]) : __builtin_nan(""));
+      if (col0 == 0) return;
+      const double xr = row < ns ? gload<true>(&xt[row]) : 0.0;
+      double acc[TS];
+#pragma unroll
+      for (int q = 0; q < TS; ++q) acc[q] = (double)a[q] * xr;
+      double sum = wave_sum16(acc, lane);
+      if (!ok) sum = __builtin_nan("");
+      if ((lane & 15) < 4) unsafeAtomicAdd(&x[c0 + wave_sum16_col(lane)], -sum);
+    }
+    return;
+  }
+  // the rest of the previous span's panel, in (row chunk) x (half of the span's columns) pieces: the launch is as long as its longest workgroup
+  if (col0 == 0) return;
+  const int chunk = (role - 2 * STEP_NB) >> 1, kh = (role - 2 * STEP_NB) & 1, pc0 = col0 - SSPAN + (SSPAN / 2) * kh, r0 = col0 + SSPAN;
+  if (!BWD) {
+    if (n <= r0 + chunk * SPANEL_FW_ROWS) return;
+    if (tid < SSPAN / 2) sx[tid] = x[pc0 + tid];
+    __syncthreads();
+    const int r = r0 + chunk * SPANEL_FW_ROWS + tid;
+    const TL *A = Lm + min(r, n - 1) + (int64_t)pc0 * lda;
+    double acc = 0.0;
+    for (int k = 0; k < SSPAN / 2; k += 32) {
+      TL a[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) a[u] = A[(int64_t)(k + u) * lda];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) acc += (double)a[u] * sx[k + u];
+    }
+    if (r < n) unsafeAtomicAdd(&x[r], -acc);
+  } else {
+    constexpr int PER = SPANEL_BW_ROWS / 64;
+    const int row0 = r0 + chunk * SPANEL_BW_ROWS;
+    if (n <= row0) return;
+    double xa[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = row0 + lane + 64 * u;
+      xa[u] = i < n ? x[i] : 0.0;
+    }
+    gather_columns<PER>(Lm + row0 + (int64_t)pc0 * lda, lda, min(n - row0, SPANEL_BW_ROWS), SSPAN / 2, xa, x + pc0, lane, wave);
+  }
+}
+
 // forward: y_anc[rows] -= A(rows, cols) y_s for one (row chunk, column chunk) of the block A = (anc, s); y_s staged through LDS.  items = (block, first
 // row, first column) triples: the column chunks (CHOL_SOLVE_COLS) give the few tall blocks of the top levels enough workgroups to fill the chip
 template <class TL>
@@ -3132,9 +3336,23 @@ template <bool BWD> static void launch_span(const float *base, const chol_trsv_d
 #define SOLVE_STEP32 1 /* 0: span and panel launch by launch at every level (A/B) */
 #endif
 template <class TL>
-static bool launch_steps(const TL *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st)
-{ // the few wide separators of a top level: one launch per span step (k_solve_step)
+static bool launch_steps(const TL *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, int *flags, int *gen, const double *W256,
+                         double *xt, hipStream_t st)
+{ // the few wide separators of a top level: one launch per span step (k_solve_stepw with the spans' explicit inverses, else k_solve_step)
   if (!SOLVE_STEP32 || !flags || n > STEP_MAX_SEPS || max_n <= SSPAN) return false;
+  if (W256) {
+    const int nspan = (max_n + SSPAN - 1) / SSPAN;
+    for (int i = 0; i < nspan; i++) {
+      const int sp = backward ? nspan - 1 - i : i, col0 = sp * SSPAN;
+      const int behind = sp > 0 ? max_n - (col0 + SSPAN) : 0;
+      const int rows = backward ? SPANEL_BW_ROWS : SPANEL_FW_ROWS;
+      const dim3 grid(n, 2 * STEP_NB + (behind > 0 ? 2 * ((behind + rows - 1) / rows) : 0));
+      *gen = *gen == 0x7fffffff ? 1 : *gen + 1;
+      if (backward) hipLaunchKernelGGL((k_solve_stepw<true, TL>), grid, dim3(256), 0, st, base, descs, W256, nspan, y, xt, col0, flags, *gen);
+      else hipLaunchKernelGGL((k_solve_stepw<false, TL>), grid, dim3(256), 0, st, base, descs, W256, nspan, y, xt, col0, flags, *gen);
+    }
+    return true;
+  }
   const int nspan = (max_n + SSPAN - 1) / SSPAN;
   for (int i = 0; i < nspan; i++) {
     const int sp = backward ? nspan - 1 - i : i, col0 = sp * SSPAN;
@@ -3162,7 +3380,7 @@ static bool launch_leaves(const float *base, const chol_trsv_desc *descs, int n,
 }
 template <class TL>
 static int launch_solve_trsv_t(const TL *base, const chol_trsv_desc *descs, int n, int max_n, int max_under, const double *W, double *y, int backward, int *flags, int *gen,
-                               hipStream_t st)
+                               const double *W256, double *xt, hipStream_t st)
 { // all separators of a level; wide ones in spans of SSPAN columns: diagonal span by one workgroup each, the rows below by all CUs (max_under: the most
   // rows any separator of the level has to read under a span -- its band if it is a leaf; negative: every separator of the level is banded within one span)
   if (n <= 0) return 0;
@@ -3170,7 +3388,7 @@ static int launch_solve_trsv_t(const TL *base, const chol_trsv_desc *descs, int 
     if (max_n > SSPAN && launch_leaves(base, descs, n, W, y, backward, st)) return (int)hipGetLastError();
     max_under = -max_under;
   }
-  if (launch_steps(base, descs, n, max_n, W, y, backward, flags, gen, st)) return (int)hipGetLastError();
+  if (launch_steps(base, descs, n, max_n, W, y, backward, flags, gen, W256, xt, st)) return (int)hipGetLastError();
   const int nspan = (max_n + SSPAN - 1) / SSPAN;
   for (int i = 0; i < nspan; i++) {
     const int sp = backward ? nspan - 1 - i : i, col0 = sp * SSPAN;
@@ -3183,6 +3401,13 @@ static int launch_solve_trsv_t(const TL *base, const chol_trsv_desc *descs, int 
       if (below > 0) hipLaunchKernelGGL((k_solve_panel<false, TL>), dim3(n, (below + 255) / 256), dim3(256), 0, st, base, descs, y, col0);
     }
   }
+  return (int)hipGetLastError();
+}
+template <class TL> static int launch_solve_inv256_t(const TL *base, const chol_trsv_desc *descs, int n, int max_n, const double *W16, double *W256, hipStream_t st)
+{
+  if (n <= 0 || max_n <= SSPAN) return 0;
+  const int nspan = (max_n + SSPAN - 1) / SSPAN;
+  hipLaunchKernelGGL(k_solve_inv256<TL>, dim3(n, nspan, SSPAN / TS), dim3(64), 0, st, base, descs, W16, W256, nspan);
   return (int)hipGetLastError();
 }
 template <class TL> static int launch_solve_offdiag_t(const TL *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st)
@@ -3291,10 +3516,12 @@ int chol_launch_permute(const double *in, const int *perm, double *out, int n, i
   return (int)hipGetLastError();
 }
 int chol_launch_solve_dinv(const double *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st) { return launch_solve_dinv_t(base, descs, n, max_n, W, st); }
-int chol_launch_solve_trsv(const double *base, const chol_trsv_desc *descs, int n, int max_n, int max_under, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st) { return launch_solve_trsv_t(base, descs, n, max_n, max_under, W, y, backward, flags, gen, st); }
+int chol_launch_solve_trsv(const double *base, const chol_trsv_desc *descs, int n, int max_n, int max_under, const double *W, double *y, int backward, int *flags, int *gen, const double *W256, double *xt, hipStream_t st) { return launch_solve_trsv_t(base, descs, n, max_n, max_under, W, y, backward, flags, gen, W256, xt, st); }
+int chol_launch_solve_inv256(const double *base, const chol_trsv_desc *descs, int n, int max_n, const double *W16, double *W256, hipStream_t st) { return launch_solve_inv256_t(base, descs, n, max_n, W16, W256, st); }
+int chol32_launch_solve_inv256(const float *base, const chol_trsv_desc *descs, int n, int max_n, const double *W16, double *W256, hipStream_t st) { return launch_solve_inv256_t(base, descs, n, max_n, W16, W256, st); }
 int chol_launch_solve_offdiag(const double *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st) { return launch_solve_offdiag_t(base, blocks, items, n_items, y, backward, st); }
 int chol32_launch_solve_dinv(const float *base, const chol_trsv_desc *descs, int n, int max_n, double *W, hipStream_t st) { return launch_solve_dinv_t(base, descs, n, max_n, W, st); }
-int chol32_launch_solve_trsv(const float *base, const chol_trsv_desc *descs, int n, int max_n, int max_under, const double *W, double *y, int backward, int *flags, int *gen, hipStream_t st) { return launch_solve_trsv_t(base, descs, n, max_n, max_under, W, y, backward, flags, gen, st); }
+int chol32_launch_solve_trsv(const float *base, const chol_trsv_desc *descs, int n, int max_n, int max_under, const double *W, double *y, int backward, int *flags, int *gen, const double *W256, double *xt, hipStream_t st) { return launch_solve_trsv_t(base, descs, n, max_n, max_under, W, y, backward, flags, gen, W256, xt, st); }
 int chol32_launch_solve_offdiag(const float *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st) { return launch_solve_offdiag_t(base, blocks, items, n_items, y, backward, st); }
 int chol_launch_trsv_fwd(const double *base, const chol_trsv_desc *descs, int n, double *y, hipStream_t st)
 {
