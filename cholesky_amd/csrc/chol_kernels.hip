@@ -3123,11 +3123,11 @@ __global__ __launch_bounds__(256) void k_solve_stepw(const TL *__restrict__ base
         const int c = TS * p + kp;
         if (c < ns) {
           const double *Wc = W + (int64_t)c * SSPAN;
+          double w[SSPAN / TS], v[SSPAN / TS]; // unconditional loads (a predicate per load is a branch and a wait per load); what lies above the diagonal block
+#pragma unroll                          // row or past the span is never written: selected away, not multiplied by zero
+          for (int gq = 0; gq < SSPAN / TS; ++gq) { w[gq] = Wc[TS * gq + r]; v[gq] = x[col0 + min(TS * gq + r, ns - 1)]; }
 #pragma unroll
-          for (int gq = 0; gq < SSPAN / TS; ++gq) {
-            const int row = TS * gq + r;
-            if (gq >= p && row < ns) acc += Wc[row] * x[col0 + row];
-          }
+          for (int gq = 0; gq < SSPAN / TS; ++gq) acc += (gq >= p && TS * gq + r < ns) ? w[gq] * v[gq] : 0.0;
         }
         acc = row_sum16(acc);
         if (r == 0 && c < ns) gstore<true>(&xt[c], acc);
