@@ -758,13 +758,13 @@ static int build_solve(cholamd_device *d, int rank = 0, int world = 1)
   }
   if (!d->ytmp) HIPCHK(hipMalloc((void **)&d->ytmp, (size_t)d->plan->n * sizeof(double)));
   if (!d->ws_solve) HIPCHK(hipMalloc((void **)&d->ws_solve, (size_t)(d->plan->ws_doubles > 0 ? d->plan->ws_doubles : 1) * sizeof(double)));
-  if (!d->step_flags) { HIPCHK(hipMalloc((void **)&d->step_flags, 256 * sizeof(int))); HIPCHK(hipMemset(d->step_flags, 0, 256 * sizeof(int))); }
-  if (!d->step_xt) HIPCHK(hipMalloc((void **)&d->step_xt, 8 * 256 * sizeof(double)));
+  if (!d->step_flags) { HIPCHK(hipMalloc((void **)&d->step_flags, CHOL_STEPW_MAX_SEPS * 16 * sizeof(int))); HIPCHK(hipMemset(d->step_flags, 0, CHOL_STEPW_MAX_SEPS * 16 * sizeof(int))); }
+  if (!d->step_xt) HIPCHK(hipMalloc((void **)&d->step_xt, CHOL_STEPW_MAX_SEPS * 256 * sizeof(double)));
   int64_t w256 = 0; // explicit inverses of the diagonal spans where the span chain is the solve's critical path: the levels of at most 8 separators
   if (!std::getenv("CHOLAMD_SOLVE_NO_INV256"))
     for (int lvl = 0; lvl < L; lvl++) {
       solve_dev &s = d->sv[lvl];
-      if (s.n_trsv < 1 || s.n_trsv > 8 || s.max_n <= 256) continue;
+      if (s.n_trsv < 1 || s.n_trsv > CHOL_STEPW_MAX_SEPS || s.max_n <= 256 || s.max_under < 0) continue; // (a level of banded leaves: k_solve_leaf32 for an fp32 factor)
       s.w256_off = w256;
       w256 += (int64_t)s.n_trsv * ((s.max_n + 255) / 256) * 65536;
     }

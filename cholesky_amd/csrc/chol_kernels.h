@@ -29,6 +29,7 @@ int chol_launch_solve_trsv(const double *base, const chol_trsv_desc *descs, int 
 /* explicit inverses of the 256-column diagonal spans of a level's separators (levels of at most 8 separators wider than a span): W256[(separator * spans + span) * 65536
  * + column * 256 + row], from the 16x16 inverses W16 of chol_launch_solve_dinv; passed to chol_launch_solve_trsv (with xt: 8 x 256 doubles of scratch) they turn
  * the span solve of the step launches into a matrix-vector product over sixteen workgroups (k_solve_stepw); NULL: k_solve_step */
+#define CHOL_STEPW_MAX_SEPS 128 /* most separators of a level that takes the step launches with explicit span inverses: flags = 16 ints, xt = 256 doubles per separator */
 int chol_launch_solve_inv256(const double *base, const chol_trsv_desc *descs, int n, int max_n, const double *W16, double *W256, hipStream_t st);
 int chol32_launch_solve_inv256(const float *base, const chol_trsv_desc *descs, int n, int max_n, const double *W16, double *W256, hipStream_t st);
 int chol_launch_solve_offdiag(const double *base, const chol_gemv_desc *blocks, const int *items, int n_items, double *y, int backward, hipStream_t st);

@@ -2840,7 +2840,9 @@ __global__ __launch_bounds__(256) void k_solve_panel(const TL *__restrict__ base
 //                     span k - 1): everything it reads was final before the launch, it runs beside the solve
 // so the chain per step is solve + flag + 1/16 of a SSPAN x SSPAN block instead of solve + launch + panel.
 #define STEP_NB 16
-#define STEP_MAX_SEPS 8
+#define STEP_MAX_SEPS 8    /* k_solve_step: a 512-register workgroup per role */
+#define STEP_MAX_SEPS_W 128 /* k_solve_stepw (explicit span inverses): ordinary workgroups; = CHOL_STEPW_MAX_SEPS of chol_kernels.h (flags, scratch, inverses) */
+static_assert(STEP_MAX_SEPS_W == CHOL_STEPW_MAX_SEPS, "flags and scratch of the step launches are sized by chol_kernels.h");
 // A level of banded LEAVES (fp32 factor): the whole triangle of a leaf by ONE workgroup in ONE launch.  A leaf's factor stays inside the envelope of A, and
 // with a band of at most SSPAN rows the panel under a span is a corner of the NEXT span's rows only: span by span the workgroup solves the span out of
 // registers (span32_body) and folds it into / gathers from those <= 256 rows itself.  Launch by launch the 512 leaves of 100^3 took 6 span launches (512
@@ -3339,7 +3341,7 @@ template <class TL>
 static bool launch_steps(const TL *base, const chol_trsv_desc *descs, int n, int max_n, const double *W, double *y, int backward, int *flags, int *gen, const double *W256,
                          double *xt, hipStream_t st)
 { // the few wide separators of a top level: one launch per span step (k_solve_stepw with the spans' explicit inverses, else k_solve_step)
-  if (!SOLVE_STEP32 || !flags || n > STEP_MAX_SEPS || max_n <= SSPAN) return false;
+  if (!SOLVE_STEP32 || !flags || n > (W256 ? STEP_MAX_SEPS_W : STEP_MAX_SEPS) || max_n <= SSPAN) return false;
   if (W256) {
     const int nspan = (max_n + SSPAN - 1) / SSPAN;
     for (int i = 0; i < nspan; i++) {

@@ -342,9 +342,9 @@ int cholamd_device_bcast_phases(const cholamd_device *d);
  * rounding (~1e-16 relative), NOT bit for bit; option "solve_reference_shape" selects the deterministic per-call
  * kernels of the BLAS-level entry points instead (slow beyond ~10^5 unknowns).
  * What the streamed solve does NOT read: the structural zeros of the leaf panels (cholamd_plan_solve_skips; CHOLAMD_SOLVE_NO_BAND=1 in the environment
- * when the device object builds its solve lists reads everything).  The levels of at most 8 separators wider than 256 columns are solved with EXPLICIT
+ * when the device object builds its solve lists reads everything).  The levels of at most 128 separators wider than 256 columns are solved with EXPLICIT
  * inverses of their 256-column diagonal spans (formed from the factor at the start of a solve -- of a refinement: its corrections reuse them -- in
- * 512 KiB of device memory per span: 100 MB for a 100^3 grid; CHOLAMD_SOLVE_NO_INV256=1 keeps the substitution form).  Their span steps hand data
+ * 512 KiB of device memory per span: 0.4 GB for a 100^3 grid; CHOLAMD_SOLVE_NO_INV256=1 keeps the substitution form).  Their span steps hand data
  * between workgroups INSIDE a launch behind flags; the waits are bounded like the program launch's, and one that gives up poisons its part of the
  * vector with NaN (a residual or refinement then reports it) instead of hanging the device. */
 int cholamd_solve(cholamd_device *d, const double *d_arena, const double *d_b, double *d_x, void *stream);
