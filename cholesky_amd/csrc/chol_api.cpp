@@ -318,6 +318,7 @@ extern "C" int cholamd_device_set_option(cholamd_device *d, const char *name, in
   else if (n == "fine_upd") d->opt.fine_upd = value != 0;
   else if (n == "skyline") d->opt.skyline = value != 0;
   else if (n == "merge_targets") d->opt.merge_targets = value != 0;
+  else if (n == "leaf_envelope") d->opt.leaf_envelope = value != 0;
   else if (n == "trsm_wt_min") d->opt.trsm_wt_min = value < 0 ? 0 : value;
   else if (n == "stage_chunk") d->opt.stage_chunk = value < 0 ? 0 : value;
   else if (n == "dist_top") d->opt.dist_top = value;

@@ -269,6 +269,9 @@ typedef struct {
                              * itself; the columns before them reach its diagonal block through update jobs on other CUs (0: follows everything) */
   int merge_targets;        /* level schedule: extend-add targets (and the row runs of a panel) that are neighbours in storage are merged, so that the
                              * 64x64 macro tiles and the 16-row strips fill up (bit-identical sums) */
+  int leaf_envelope;        /* level schedule: a LEAF's factor stays inside the envelope of A (nothing reaches a leaf from below), so its TRSM strips, trailing
+                             * updates and extend-add sources leave out what is structurally zero: rows beyond the band of a column block, ancestor rows
+                             * in front of their first entry, the columns of a source in front of its rows' first entries (identical results) */
   int super_blocks;         /* column blocks per super-block of a wide pivot: the trailing matrix beyond a super-block gets one update of
                              * rank super_blocks * (block width) instead of one per block */
 } chol_sched_opts;

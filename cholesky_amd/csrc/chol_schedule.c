@@ -116,7 +116,7 @@ static int env_int(const char *name, int dflt) { const char *e = getenv(name); r
 void chol_sched_opts_default(chol_sched_opts *o)
 {
   o->split_min = CHOL_SPLIT_MIN; o->split_nb = CHOL_SPLIT_NB; o->fuse = 1; o->fuse_update_max = CHOL_FUSE_UPDATE_MAX;
-  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->trsm_wt_min = CHOL_TRSM_WT_MIN; o->trsm_group = 0; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL; o->follow_tail_split = CHOL_FOLLOW_TAIL; o->staged = 1; o->fine_upd = 1; o->skyline = 1; o->stage_chunk = CHOL_STAGE_CHUNK; o->merge_targets = 1;
+  o->mt_min_tiles = CHOL_MT_MIN_TILES; o->trsm_wt_min = CHOL_TRSM_WT_MIN; o->trsm_group = 0; o->cells = 1; o->program = 1; o->follow = 1; o->super_blocks = CHOL_SUPER_BLOCKS; o->dist_top = 2; o->follow_tail = CHOL_FOLLOW_TAIL; o->follow_tail_split = CHOL_FOLLOW_TAIL; o->staged = 1; o->fine_upd = 1; o->skyline = 1; o->stage_chunk = CHOL_STAGE_CHUNK; o->merge_targets = 1; o->leaf_envelope = 1;
 }
 void chol_sched_opts_from_env(chol_sched_opts *o)
 {
@@ -138,6 +138,7 @@ void chol_sched_opts_from_env(chol_sched_opts *o)
   o->fine_upd = !env_int("CHOLAMD_NO_FINE_UPD", 0);
   o->skyline = !env_int("CHOLAMD_NO_SKYLINE", 0);
   o->merge_targets = !env_int("CHOLAMD_NO_MERGE_TARGETS", 0);
+  o->leaf_envelope = !env_int("CHOLAMD_NO_LEAF_ENVELOPE", 0);
   o->stage_chunk = env_int("CHOLAMD_STAGE_CHUNK", o->stage_chunk);
 }
 static int split_nb(const chol_sched_opts *o) { int v = o->split_nb; if (v > CHOL_RR_MAXN) v = CHOL_RR_MAXN; v = (v + 15) / 16 * 16; if (v < 16) v = 16; return v; }
@@ -450,6 +451,14 @@ static int ancestor_runs(const plan_t *p, int h, int by_storage, const cholamd_f
   return ancestor_runs_of(p, h, 0, by_storage, snap, first, count, out);
 }
 
+static int **leaf_row_first(const plan_t *p);
+/* smallest first-entry column over the panel rows [pr, pr + m) of a leaf */
+static int rows_first(const int *first, int pr, int m, int n)
+{
+  int f = n;
+  for (int r = 0; r < m; r++) if (first[pr + r] < f) f = first[pr + r];
+  return f;
+}
 int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int level, int rank, int world, chol_level_work *w)
 {
   chol_sched_opts dflt;
@@ -477,6 +486,8 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
     if (pivot_blocks(opts, p->sep_size[s]) > steps) steps = pivot_blocks(opts, p->sep_size[s]);
   }
   if (steps == 0) steps = 1;
+  /* leaves: first entry of every panel row (leaf_envelope) */
+  int **rfirst = (level == L - 1 && L > 1 && opts->leaf_envelope && nh > 0) ? leaf_row_first(p) : NULL;
   /* distributed top level (world > 1, option dist_top): column block `st` of separator s is factored and solved by its owner,
    * broadcast, and every rank applies the updates into the column blocks IT owns (push_tasks / emit_cell_tasks cut and filter
    * the targets); every rank walks the same phase sequence */
@@ -516,6 +527,15 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
       const int below = n - c0 - nb;                                         /* pivot rows under the diagonal block */
       row_run *runs; const int nr = ancestor_runs(p, h, opts->merge_targets, snap, first, count, &runs);
       const int mine = !dist || dist_owner(p, s, st, world) == rank;
+      /* a leaf: L(i, k) = 0 for i - k > band inside the diagonal block, and an ancestor row is zero in front of its first entry of A */
+      int band = n, *run_first = NULL;
+      if (rfirst && rfirst[s]) {
+        band = 0;
+        for (int r = 0; r < n; r++) if (r - rfirst[s][r] > band) band = r - rfirst[s][r];
+        run_first = malloc((size_t)(nr > 0 ? nr : 1) * sizeof(int));
+        for (int r = 0; r < nr; r++) run_first[r] = rows_first(rfirst[s], (int)((runs[r].off - p->panel_off[s]) % ld), runs[r].m, n);
+      }
+#define RUN_LIVE(r_, col_end_) (!run_first || run_first[r_] < (col_end_)) /* the run has an entry in front of column col_end_ */
       if (dist) { /* the column block travels from its owner to every rank once it is factored and solved */
         if (w->n_bcast == B->cap_b) { B->cap_b = B->cap_b ? 2 * B->cap_b : 16; w->bcast = realloc(w->bcast, B->cap_b * sizeof(chol_bcast)); }
         chol_bcast bc = { p->panel_off[s] + colbase, (int64_t)nb * ld, dist_owner(p, s, st, world), h };
@@ -526,8 +546,8 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
         chol_potrf_desc pd = { diag, dinv, nb, ld, s, c0, 0, 0, { 0 } };
         push_potrf(B, pd);
         const int flag = w->n_potrf - 1 - p0; /* this block's POTRF descriptor within the step */
-        if (below > 0) push_trsm_run(B, diag, dinv, p->panel_off[s] + (c0 + nb) + colbase, nb, ld, below, flag);
-        for (int r = 0; r < nr; r++) push_trsm_run(B, diag, dinv, runs[r].off + colbase, nb, ld, runs[r].m, flag);
+        if (below > 0) push_trsm_run(B, diag, dinv, p->panel_off[s] + (c0 + nb) + colbase, nb, ld, below < band ? below : band, flag);
+        for (int r = 0; r < nr; r++) if (RUN_LIVE(r, c0 + nb)) push_trsm_run(B, diag, dinv, runs[r].off + colbase, nb, ld, runs[r].m, flag);
         if (thru) pad_trsm_group(B, t0, CHOL_TRSM_WT_GROUP, diag, dinv, diag, nb, ld, flag);
         else if (fuse) pad_trsm_group(B, t0, 3, diag, dinv, diag, nb, ld, flag);
         else if (opts->trsm_group > 0) pad_trsm_group(B, t0, opts->trsm_group, diag, dinv, diag, nb, ld, flag);
@@ -546,38 +566,46 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
         const int last_in_sb = (st % G == G - 1) || c0 + nb >= n || c0 + nb >= cse;
         /* (1) narrow: columns [c0+nb, cse) of the rows below, K = nb */
         const int ncol = cse - (c0 + nb);
+        const int ncol_e = ncol < band ? ncol : band;                           /* (a leaf: the columns the block's band reaches) */
         B->tgt_col0 = c0 + nb;
         if (ncol > 0) {
           const int64_t x_piv = p->panel_off[s] + (c0 + nb) + colbase;         /* solved pivot rows under the block, k = nb */
           chol_upd_src sp = { x_piv, x_piv, ld, ld, nb, 0, 0, 0 };
           const int sidx = push_src(B, sp);
-          push_tasks(B, p->panel_off[s] + (c0 + nb) + (int64_t)(c0 + nb) * ld, ld, ncol, ncol, 1, sidx, sidx + 1); /* rows inside the super-block: lower triangle */
-          if (below > ncol) { /* pivot rows beyond the super-block x its remaining columns */
+          push_tasks(B, p->panel_off[s] + (c0 + nb) + (int64_t)(c0 + nb) * ld, ld, ncol_e, ncol_e, 1, sidx, sidx + 1); /* rows inside the super-block: lower triangle */
+          const int beyond = below - ncol < band - ncol ? below - ncol : band - ncol; /* pivot rows beyond the super-block (inside the band) x its remaining columns */
+          if (beyond > 0) {
             chol_upd_src sq = { x_piv + ncol, x_piv, ld, ld, nb, 0, 0, 0 };
             const int si = push_src(B, sq);
-            push_tasks(B, p->panel_off[s] + cse + (int64_t)(c0 + nb) * ld, ld, below - ncol, ncol, 0, si, si + 1);
+            push_tasks(B, p->panel_off[s] + cse + (int64_t)(c0 + nb) * ld, ld, beyond, ncol_e, 0, si, si + 1);
           }
           for (int r = 0; r < nr; r++) {
+            if (!RUN_LIVE(r, c0 + nb)) continue;
             chol_upd_src sa = { runs[r].off + colbase, x_piv, ld, ld, nb, 0, 0, 0 };
             const int si = push_src(B, sa);
-            push_tasks(B, runs[r].off + (int64_t)(c0 + nb) * ld, ld, runs[r].m, ncol, 0, si, si + 1);
+            push_tasks(B, runs[r].off + (int64_t)(c0 + nb) * ld, ld, runs[r].m, ncol_e, 0, si, si + 1);
           }
         }
         /* (2) wide, at the end of the super-block: columns [cse, n), K = cse - cs0 */
         B->tgt_col0 = cse;
         if (last_in_sb && cse < n) {
-          const int K = cse - cs0, rest = n - cse;
-          const int64_t x_sb = p->panel_off[s] + cse + (int64_t)cs0 * ld;      /* pivot rows beyond the super-block, its columns */
+          /* (a leaf: only the last `band` columns of the super-block reach the columns beyond it, and only `band` of those) */
+          const int bk = (band + 15) / 16 * 16;
+          const int K = cse - cs0 < bk ? cse - cs0 : bk, ce0 = cse - K, rest = n - cse < band ? n - cse : band;
+          const int64_t x_sb = p->panel_off[s] + cse + (int64_t)ce0 * ld;      /* pivot rows beyond the super-block, its columns */
           chol_upd_src sp = { x_sb, x_sb, ld, ld, K, 0, 0, 0 };
           const int sidx = push_src(B, sp);
           push_tasks(B, p->panel_off[s] + cse + (int64_t)cse * ld, ld, rest, rest, 1, sidx, sidx + 1);
           for (int r = 0; r < nr; r++) {
-            chol_upd_src sa = { runs[r].off + (int64_t)cs0 * ld, x_sb, ld, ld, K, 0, 0, 0 };
+            if (!RUN_LIVE(r, cse)) continue;
+            chol_upd_src sa = { runs[r].off + (int64_t)ce0 * ld, x_sb, ld, ld, K, 0, 0, 0 };
             const int si = push_src(B, sa);
             push_tasks(B, runs[r].off + (int64_t)cse * ld, ld, runs[r].m, rest, 0, si, si + 1);
           }
         }
       }
+#undef RUN_LIVE
+      free(run_first);
       free(runs);
     }
     flush_targets(B);
@@ -708,6 +736,14 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
         const int sb = w->n_src;
         for (int q = G[a].i; q < G[a].e; q++) {
           chol_upd_src sd = { tu[q].a_off, tu[q].b_off, tu[q].lda, tu[q].ldb, tu[q].k, 0, 0, 0 };
+          if (rfirst && rfirst[tu[q].src_sep]) { /* a leaf's panel: the source starts at the first column both row sets have entries from */
+            const int s_ = tu[q].src_sep;
+            const int fa_ = rows_first(rfirst[s_], (int)((tu[q].a_off - p->panel_off[s_]) % tu[q].lda), G[a].m, tu[q].k);
+            const int fb_ = rows_first(rfirst[s_], (int)((tu[q].b_off - p->panel_off[s_]) % tu[q].ldb), G[a].n, tu[q].k);
+            int k0_ = (fa_ > fb_ ? fa_ : fb_) & ~15;
+            if (k0_ > ((tu[q].k - 1) & ~15)) k0_ = (tu[q].k - 1) & ~15; /* (at least the last sixteen columns: no empty source) */
+            if (k0_ > 0) { sd.a_off += (int64_t)k0_ * sd.lda; sd.b_off += (int64_t)k0_ * sd.ldb; sd.k -= k0_; }
+          }
           push_src(B, sd);
         }
         if (dist) { B->tgt_sep = p->blk[G[a].bc].c; B->tgt_col0 = G[a].ccol; }
@@ -725,6 +761,7 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
     } else push_phase(B, 2, k0, w->n_task - k0);
     push_phase(B, 3, km0, w->n_task_mt - km0);
   }
+  if (rfirst) { for (int s = 1; s <= p->nsep; s++) free(rfirst[s]); free(rfirst); }
   free(tu); free(first); free(count); free(hs); free(B->pend); B->pend = NULL; B->cap_pend = 0;
   return 0;
 }
@@ -1652,7 +1689,8 @@ int chol_program_check_built(const plan_t *p, const chol_sched_opts *opts, int w
 #define PUSHQ(V_, N_, C_, A_, B_, C2_, D_) do { if (N_ == C_) { C_ = C_ ? 2 * C_ : 4096; V_ = realloc(V_, C_ * sizeof(quad)); } quad q_ = { A_, B_, C2_, D_ }; V_[N_++] = q_; } while (0)
     for (int l = 0; l < p->levels && !rc; l++) {
       chol_level_work lw;
-      rc = chol_build_level_work(p, opts, l, 0, 1, &lw);
+      chol_sched_opts lo = *opts; lo.leaf_envelope = 0; /* (the program keeps the leaves' zero rows in its strips: compare with the lists that do too) */
+      rc = chol_build_level_work(p, &lo, l, 0, 1, &lw);
       if (rc) break;
       /* per 16-column tile (the program may factor a banded leaf as one block where the level lists split it): the diagonal tiles
        * factored, and per solved row the first element of every column tile */
@@ -1807,6 +1845,7 @@ int cholamd_plan_level_work_volume_opts(const cholamd_plan *p, int level, int me
   chol_sched_opts o;
   chol_sched_opts_default(&o);
   o.merge_targets = merge_targets != 0;
+  o.leaf_envelope = 0; /* (the dense work: a leaf's sources are cut at the first entry of the TARGET's rows, which depends on how targets are merged) */
   if (mt_min_tiles >= 0) o.mt_min_tiles = mt_min_tiles;
   return level_work_volume(p, &o, level, 0, 1, out, out + 6);
 }
