@@ -163,3 +163,34 @@ def test_merged_targets_and_row_compaction_keep_the_factor(dims):
     A = plan.arena_to_dense(plan.fill_host())
     A = A + np.tril(A, -1).T
     assert np.linalg.norm(L @ L.T - A) / np.linalg.norm(A) <= 1e-10
+
+
+@pytest.mark.parametrize("dims", [(24, 24, 24, 5, 32), (30, 30, 10, 3, 64), (12, 12, 12, 4, 16)])
+@pytest.mark.parametrize("f32", [False, True])
+def test_the_leaf_envelope_of_the_level_schedule_keeps_the_factor(dims, f32):
+    """Option leaf_envelope (level schedule): the leaves' TRSM strips, trailing updates and extend-add sources leave out what is structurally zero
+    (a leaf's factor stays inside the envelope of A).  The whole arena -- every stored entry, the skipped zeros included -- equals the arena of the
+    dense lists; fewer tasks and strips are launched."""
+    import cholesky_amd as ca
+    prob = ca.Problem(*dims)
+    plan = prob.plan()
+    res, counts = [], []
+    for env in (0, 1):
+        dev = ca.Device(plan, 0)
+        dev.set_option("program", 0)
+        dev.set_option("mt_min_tiles", 1)
+        dev.set_option("leaf_envelope", env)
+        if f32:
+            arena = dev.new_arena_f32()
+            dev.fill_f32(arena)
+            dev.factor_f32(arena)
+        else:
+            arena = dev.new_arena()
+            dev.fill(arena)
+            dev.factor(arena)
+        dev.sync()
+        assert dev.info() == (0, 0)
+        res.append(arena.cpu().numpy().astype(np.float64))
+    scale = np.abs(res[0]).max()
+    assert np.abs(res[0] - res[1]).max() <= (2e-6 if f32 else 1e-13) * scale  # (shorter sums: another rounding of the same values, no other difference)
+    assert np.array_equal(res[0] == 0.0, res[1] == 0.0)                         # the same zero pattern, entry by entry
