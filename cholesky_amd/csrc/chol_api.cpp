@@ -760,7 +760,7 @@ static int build_solve(cholamd_device *d, int rank = 0, int world = 1)
   if (!d->ytmp) HIPCHK(hipMalloc((void **)&d->ytmp, (size_t)d->plan->n * sizeof(double)));
   if (!d->ws_solve) HIPCHK(hipMalloc((void **)&d->ws_solve, (size_t)(d->plan->ws_doubles > 0 ? d->plan->ws_doubles : 1) * sizeof(double)));
   if (!d->step_flags) { HIPCHK(hipMalloc((void **)&d->step_flags, CHOL_STEPW_MAX_SEPS * 16 * sizeof(int))); HIPCHK(hipMemset(d->step_flags, 0, CHOL_STEPW_MAX_SEPS * 16 * sizeof(int))); }
-  if (!d->step_xt) HIPCHK(hipMalloc((void **)&d->step_xt, CHOL_STEPW_MAX_SEPS * 256 * sizeof(double)));
+  if (!d->step_xt) { HIPCHK(hipMalloc((void **)&d->step_xt, CHOL_STEPW_MAX_SEPS * 256 * sizeof(double))); HIPCHK(hipMemset(d->step_xt, 0, CHOL_STEPW_MAX_SEPS * 256 * sizeof(double))); }
   int64_t w256 = 0; // explicit inverses of the diagonal spans where the span chain is the solve's critical path: the levels of at most 8 separators
   if (!std::getenv("CHOLAMD_SOLVE_NO_INV256"))
     for (int lvl = 0; lvl < L; lvl++) {

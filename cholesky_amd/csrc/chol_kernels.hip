@@ -3109,9 +3109,9 @@ __global__ __launch_bounds__(256) void k_solve_stepw(const TL *__restrict__ base
         if (kp <= p) {
           double w[TS], v[TS];
 #pragma unroll
-          for (int u = 0; u < TS; ++u) { w[u] = W[(int64_t)(TS * kp + u) * SSPAN + TS * p + r]; v[u] = x[col0 + TS * kp + u]; } // (columns < ns: kp <= p)
-#pragma unroll
-          for (int u = 0; u < TS; ++u) acc += w[u] * v[u];
+          for (int u = 0; u < TS; ++u) { w[u] = W[(int64_t)(TS * kp + u) * SSPAN + TS * p + r]; v[u] = x[col0 + min(TS * kp + u, ns - 1)]; }
+#pragma unroll // (a ragged last block: the columns past the span are selected away, not multiplied by their zeros -- what lies behind the vector may be NaN)
+          for (int u = 0; u < TS; ++u) acc += TS * kp + u < ns ? w[u] * v[u] : 0.0;
         }
         sx[kp * TS + r] = acc;
         __syncthreads();
