@@ -733,6 +733,29 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
         qsort(G, ng, sizeof(tgt_group), cmp_group_first);
       }
       for (int a = 0; a < ng; a++) {
+        if (rfirst && !dist && !G[a].syrk && rfirst[tu[G[a].i].src_sep]) {
+          /* sources out of LEAF panels: the target in 64 x 64 pieces (the macro tiles it would be cut into anyway, in the same 8 x 8 block order), every
+           * piece with its own sources, each starting at the first column both of the piece's row sets have entries from */
+          for (int rb = 0; rb < G[a].m; rb += 64 * MT_ORDER)
+          for (int cb = 0; cb < G[a].n; cb += 64 * MT_ORDER)
+          for (int r0 = rb; r0 < G[a].m && r0 < rb + 64 * MT_ORDER; r0 += 64)
+          for (int c0 = cb; c0 < G[a].n && c0 < cb + 64 * MT_ORDER; c0 += 64) {
+            const int mm = G[a].m - r0 < 64 ? G[a].m - r0 : 64, nn = G[a].n - c0 < 64 ? G[a].n - c0 : 64;
+            const int sb = w->n_src;
+            for (int q = G[a].i; q < G[a].e; q++) {
+              chol_upd_src sd = { tu[q].a_off + r0, tu[q].b_off + c0, tu[q].lda, tu[q].ldb, tu[q].k, 0, 0, 0 };
+              const int s_ = tu[q].src_sep;
+              const int fa_ = rows_first(rfirst[s_], (int)((sd.a_off - p->panel_off[s_]) % sd.lda), mm, sd.k);
+              const int fb_ = rows_first(rfirst[s_], (int)((sd.b_off - p->panel_off[s_]) % sd.ldb), nn, sd.k);
+              int k0_ = (fa_ > fb_ ? fa_ : fb_) & ~15;
+              if (k0_ > ((sd.k - 1) & ~15)) k0_ = (sd.k - 1) & ~15; /* (at least the last sixteen columns: no empty source) */
+              if (k0_ > 0) { sd.a_off += (int64_t)k0_ * sd.lda; sd.b_off += (int64_t)k0_ * sd.ldb; sd.k -= k0_; }
+              push_src(B, sd);
+            }
+            push_tasks(B, G[a].c_off + r0 + (int64_t)c0 * G[a].ldc, G[a].ldc, mm, nn, 0, sb, w->n_src);
+          }
+          continue;
+        }
         const int sb = w->n_src;
         for (int q = G[a].i; q < G[a].e; q++) {
           chol_upd_src sd = { tu[q].a_off, tu[q].b_off, tu[q].lda, tu[q].ldb, tu[q].k, 0, 0, 0 };
