@@ -525,15 +525,28 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
       const int64_t dinv = p->dinv_off[s] + (int64_t)(c0 / CHOL_NB) * CHOL_NB * CHOL_NB;
       const int64_t colbase = (int64_t)c0 * ld;                              /* column c0 of the panel */
       const int below = n - c0 - nb;                                         /* pivot rows under the diagonal block */
-      row_run *runs; const int nr = ancestor_runs(p, h, opts->merge_targets, snap, first, count, &runs);
+      row_run *runs; const int nr_ = ancestor_runs(p, h, opts->merge_targets, snap, first, count, &runs);
       const int mine = !dist || dist_owner(p, s, st, world) == rank;
       /* a leaf: L(i, k) = 0 for i - k > band inside the diagonal block, and an ancestor row is zero in front of its first entry of A */
       int band = n, *run_first = NULL;
+      int nr = nr_;
       if (rfirst && rfirst[s]) {
         band = 0;
         for (int r = 0; r < n; r++) if (r - rfirst[s][r] > band) band = r - rfirst[s][r];
-        run_first = malloc((size_t)(nr > 0 ? nr : 1) * sizeof(int));
-        for (int r = 0; r < nr; r++) run_first[r] = rows_first(rfirst[s], (int)((runs[r].off - p->panel_off[s]) % ld), runs[r].m, n);
+        /* the ancestor row runs in pieces of 64 rows (a macro tile's height), each with the first entry of ITS rows: a run is live for a column block as a
+         * whole otherwise, though most of a face's rows start late */
+        int np_ = 0;
+        for (int r = 0; r < nr_; r++) np_ += (runs[r].m + 63) / 64;
+        row_run *pieces = malloc((size_t)(np_ > 0 ? np_ : 1) * sizeof(row_run));
+        run_first = malloc((size_t)(np_ > 0 ? np_ : 1) * sizeof(int));
+        np_ = 0;
+        for (int r = 0; r < nr_; r++)
+          for (int r0 = 0; r0 < runs[r].m; r0 += 64) {
+            row_run pc = { runs[r].off + r0, runs[r].m - r0 < 64 ? runs[r].m - r0 : 64, runs[r].pos + r0 };
+            run_first[np_] = rows_first(rfirst[s], (int)((pc.off - p->panel_off[s]) % ld), pc.m, n);
+            pieces[np_++] = pc;
+          }
+        free(runs); runs = pieces; nr = np_;
       }
 #define RUN_LIVE(r_, col_end_) (!run_first || run_first[r_] < (col_end_)) /* the run has an entry in front of column col_end_ */
       if (dist) { /* the column block travels from its owner to every rank once it is factored and solved */
@@ -598,7 +611,9 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
           push_tasks(B, p->panel_off[s] + cse + (int64_t)cse * ld, ld, rest, rest, 1, sidx, sidx + 1);
           for (int r = 0; r < nr; r++) {
             if (!RUN_LIVE(r, cse)) continue;
-            chol_upd_src sa = { runs[r].off + (int64_t)ce0 * ld, x_sb, ld, ld, K, 0, 0, 0 };
+            int cr0 = ce0; /* (a leaf: the piece's rows are zero in front of their first entry) */
+            if (run_first && (run_first[r] & ~15) > cr0) cr0 = run_first[r] & ~15;
+            chol_upd_src sa = { runs[r].off + (int64_t)cr0 * ld, x_sb + (int64_t)(cr0 - ce0) * ld, ld, ld, cse - cr0, 0, 0, 0 };
             const int si = push_src(B, sa);
             push_tasks(B, runs[r].off + (int64_t)cse * ld, ld, runs[r].m, rest, 0, si, si + 1);
           }
