@@ -332,7 +332,7 @@ int cholamd_factor_info(cholamd_device *d, int *sep_out);
  * leaf's columns reach the extend-add jobs in chunks of this many column tiles; 0 = the whole block at once, the default;
  * CHOLAMD_STAGE_CHUNK),
  * "leaf_envelope" (level schedule: a leaf's factor stays inside the envelope of A, so the strips, trailing updates and extend-add sources of the leaves
- * leave out what is structurally zero -- identical factors, 13-33 % less time on the generated grids; CHOLAMD_NO_LEAF_ENVELOPE),
+ * leave out what is structurally zero -- identical factors, 16-35 % less time on the generated grids; CHOLAMD_NO_LEAF_ENVELOPE),
  * "super_blocks", "dist_top" (0 / 1 / 2 = automatic: top levels of a partitioned run distributed by column
  * blocks, see Multi-GPU below; CHOLAMD_DIST_TOP).  Rebuilds the work lists. */
 int cholamd_device_set_option(cholamd_device *d, const char *name, int value);
