@@ -488,6 +488,11 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
   if (steps == 0) steps = 1;
   /* leaves: first entry of every panel row (leaf_envelope) */
   int **rfirst = (level == L - 1 && L > 1 && opts->leaf_envelope && nh > 0) ? leaf_row_first(p) : NULL;
+  /* ... their ancestor row runs in 64-row pieces where the level is throughput work (the generated grids); on a small problem (lapl_3375: 16 leaves, fused
+   * latency-bound launches) more runs are more padded strip groups: 210 -> 227 us */
+  int64_t level_rows = 0;
+  for (int q = 0; q < nh; q++) level_rows += p->panel_rows[p->tree[hs[q]]];
+  const int fine_pieces = level_rows >= 65536;
   /* distributed top level (world > 1, option dist_top): column block `st` of separator s is factored and solved by its owner,
    * broadcast, and every rank applies the updates into the column blocks IT owns (push_tasks / emit_cell_tasks cut and filter
    * the targets); every rank walks the same phase sequence */
@@ -535,14 +540,15 @@ int chol_build_level_work(const plan_t *p, const chol_sched_opts *opts, int leve
         for (int r = 0; r < n; r++) if (r - rfirst[s][r] > band) band = r - rfirst[s][r];
         /* the ancestor row runs in pieces of 64 rows (a macro tile's height), each with the first entry of ITS rows: a run is live for a column block as a
          * whole otherwise, though most of a face's rows start late */
+        const int ph = fine_pieces ? 64 : 1 << 30; /* piece height */
         int np_ = 0;
-        for (int r = 0; r < nr_; r++) np_ += (runs[r].m + 63) / 64;
+        for (int r = 0; r < nr_; r++) np_ += fine_pieces ? (runs[r].m + 63) / 64 : 1;
         row_run *pieces = malloc((size_t)(np_ > 0 ? np_ : 1) * sizeof(row_run));
         run_first = malloc((size_t)(np_ > 0 ? np_ : 1) * sizeof(int));
         np_ = 0;
         for (int r = 0; r < nr_; r++)
-          for (int r0 = 0; r0 < runs[r].m; r0 += 64) {
-            row_run pc = { runs[r].off + r0, runs[r].m - r0 < 64 ? runs[r].m - r0 : 64, runs[r].pos + r0 };
+          for (int r0 = 0; r0 < runs[r].m; r0 += ph) {
+            row_run pc = { runs[r].off + r0, runs[r].m - r0 < ph ? runs[r].m - r0 : ph, runs[r].pos + r0 };
             run_first[np_] = rows_first(rfirst[s], (int)((pc.off - p->panel_off[s]) % ld), pc.m, n);
             pieces[np_++] = pc;
           }
