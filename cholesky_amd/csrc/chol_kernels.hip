@@ -2491,7 +2491,7 @@ __global__ __launch_bounds__(64) void k_solve_dinv(const TL *__restrict__ base, 
 #define SSPAN 256
 // sL: [r][c] of the current diagonal block; sxs: the span's part of the vector, in LDS from the first block to the last.  PUB: the solution is written with
 // agent-scope stores (workgroups of the same launch read it: k_solve_step)
-template <bool BWD, class TL, bool PUB>
+template <bool BWD, class TL, bool PUB, bool XAG = false>
 __device__ __forceinline__ void trsv_body(const TL *__restrict__ base, const chol_trsv_desc &d, const double *__restrict__ Wall, double *__restrict__ y, int col0,
                                           double (*sL)[SNB + 1], double (*sW)[TS * TS], double *sxs)
 {
@@ -2544,7 +2544,7 @@ __device__ __forceinline__ void trsv_body(const TL *__restrict__ base, const cho
       }
     }
   }
-  sxs[tid] = col0 + tid < n ? x[col0 + tid] : 0.0;
+  sxs[tid] = col0 + tid < n ? gload<XAG>(&x[col0 + tid]) : 0.0;
 #pragma unroll
   for (int bi = 0; bi < NB4; ++bi) {
     if (bi >= nblk) break;
@@ -2848,15 +2848,27 @@ static_assert(STEP_MAX_SEPS_W == CHOL_STEPW_MAX_SEPS, "flags and scratch of the 
 // registers (span32_body) and folds it into / gathers from those <= 256 rows itself.  Launch by launch the 512 leaves of 100^3 took 6 span launches (512
 // workgroups of one per CU: two rounds each) and 5 panel launches per sweep: 1.1 of the 7.1 ms of a solve.  Inside the launch the vector is written with
 // agent-scope stores and read with agent-scope loads (the gather's atomics are performed in L2: a plain load could hit a line the CU cached before them).
-template <bool BWD>
-__global__ __launch_bounds__(256) void k_solve_leaf32(const float *__restrict__ base, const chol_trsv_desc *__restrict__ descs, const double *__restrict__ Wall,
+template <bool BWD, class TL> struct leaf_span;
+template <bool BWD> struct leaf_span<BWD, float> {
+  static __device__ __forceinline__ void run(const float *base, const chol_trsv_desc &d, const double *Wall, double *y, int col0, double *sx) { span32_body<BWD, true, true>(base, d, Wall, y, col0, sx); }
+};
+template <bool BWD> struct leaf_span<BWD, double> { // (the fp64 factor: the 64-column block chain of k_solve_trsv)
+  static __device__ __forceinline__ void run(const double *base, const chol_trsv_desc &d, const double *Wall, double *y, int col0, double *sx)
+  {
+    __shared__ double sL[SNB][SNB + 1];
+    __shared__ double sW[SNB / TS][TS * TS];
+    trsv_body<BWD, double, true, true>(base, d, Wall, y, col0, sL, sW, sx);
+  }
+};
+template <bool BWD, class TL>
+__global__ __launch_bounds__(256) void k_solve_leaf32(const TL *__restrict__ base, const chol_trsv_desc *__restrict__ descs, const double *__restrict__ Wall,
                                                       double *__restrict__ y)
 {
   __shared__ __attribute__((aligned(16))) double sx[SSPAN];
   const chol_trsv_desc d = descs[blockIdx.x];
   const int n = d.n, lda = d.lda, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nspan = (n + SSPAN - 1) / SSPAN, band = d.band > 0 ? d.band : n;
-  const float *Lm = base + d.a_off;
+  const TL *Lm = base + d.a_off;
   double *x = y + d.x_off;
   for (int i = 0; i < nspan; ++i) {
     const int sp = BWD ? nspan - 1 - i : i, col0 = sp * SSPAN, r0 = col0 + SSPAN;
@@ -2869,16 +2881,16 @@ __global__ __launch_bounds__(256) void k_solve_leaf32(const float *__restrict__ 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
-    span32_body<BWD, true, true>(base, d, Wall, y, col0, sx);
+    leaf_span<BWD, TL>::run(base, d, Wall, y, col0, sx);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!BWD && nr > 0) { // x(rows under the span) -= L(rows, span) x(span)
       sx[tid] = gload<true>(&x[col0 + tid]);
       __syncthreads();
-      const float *A = Lm + r0 + min(tid, nr - 1) + (int64_t)col0 * lda;
+      const TL *A = Lm + r0 + min(tid, nr - 1) + (int64_t)col0 * lda;
       double acc = 0.0;
       for (int k = 0; k < SSPAN; k += 64) { // (the span's registers are free again: sixty-four loads in flight, four rounds)
-        float a[64];
+        TL a[64];
 #pragma unroll
         for (int u = 0; u < 64; ++u) a[u] = A[(int64_t)(k + u) * lda];
 #pragma unroll
@@ -3372,12 +3384,11 @@ static bool launch_steps(const TL *base, const chol_trsv_desc *descs, int n, int
 #ifndef SOLVE_LEAF32
 #define SOLVE_LEAF32 1 /* 0: banded leaves span by span, launch by launch (A/B) */
 #endif
-static bool launch_leaves(const double *, const chol_trsv_desc *, int, const double *, double *, int, hipStream_t) { return false; }
-static bool launch_leaves(const float *base, const chol_trsv_desc *descs, int n, const double *W, double *y, int backward, hipStream_t st)
+template <class TL> static bool launch_leaves(const TL *base, const chol_trsv_desc *descs, int n, const double *W, double *y, int backward, hipStream_t st)
 {
   if (!SOLVE_LEAF32) return false;
-  if (backward) hipLaunchKernelGGL((k_solve_leaf32<true>), dim3(n), dim3(256), 0, st, base, descs, W, y);
-  else hipLaunchKernelGGL((k_solve_leaf32<false>), dim3(n), dim3(256), 0, st, base, descs, W, y);
+  if (backward) hipLaunchKernelGGL((k_solve_leaf32<true, TL>), dim3(n), dim3(256), 0, st, base, descs, W, y);
+  else hipLaunchKernelGGL((k_solve_leaf32<false, TL>), dim3(n), dim3(256), 0, st, base, descs, W, y);
   return true;
 }
 template <class TL>
