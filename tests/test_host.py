@@ -459,3 +459,18 @@ def test_what_the_solve_skips_is_zero_in_the_reference_factor(case, plans, oracl
             assert not Ld[x_off:x_off + m, y_off:y_off + c_lo].any()
             skipped += m * c_lo
     assert skipped > 0
+
+
+def test_leaf_envelope_shrinks_the_leaf_level_lists_only(ca):
+    """Level schedule, option leaf_envelope (default on): the leaves' TRSM strips and update tasks leave out the structural zeros -- less solved
+    elements and less update volume at the leaf level than the dense lists (cholamd_plan_level_work_volume_opts builds those), the same pivots, and
+    nothing changes above the leaves."""
+    plan = ca.Problem(24, 24, 24, 4, 32).plan()
+    for lvl in range(plan.levels):
+        on = plan.level_work_volume(lvl)                          # default options
+        off = plan.level_work_volume_opts(lvl, merge_targets=1)   # the same with leaf_envelope = 0
+        assert on[0] == off[0]                                    # POTRF columns
+        if lvl == plan.levels - 1:
+            assert on[1] < 0.8 * off[1] and on[2] < 0.8 * off[2], (on, off)
+        else:
+            assert tuple(on[:3]) == tuple(off[:3])
