@@ -192,6 +192,7 @@ def large_front(ca, torch, stream, specs=LARGE_FRONT, steps=2, warmup=1):
             dev.residual(bvec, xvec, r, stream)
             torch.cuda.synchronize()
             solve = {"ms": round(ms, 3), "relres": float(r.norm() / bvec.norm())}
+            solve["traffic"] = profile_solve_numbers(f"gen:{gn}:{glv}" + (f":{gtile}" if gtile != 64 else ""), False, 1, plan.alg_bytes)
         fill(a, stream)
         dev.sync(stream)
         dev.set_timing(1)
@@ -416,6 +417,21 @@ def main():
         it, rel = dev.solve_refine(arenas[(done + K - 1) % n_arenas] if K <= n_arenas else arenas[(K - 1) % n_arenas], bvec, xvec, 30, 1e-11, stream)
         torch.cuda.synchronize()
         refine = {"corrections": it, "relres": rel, "ms": round((time.perf_counter() - t0) * 1e3, 3), "tol": 1e-11}
+    solve = None
+    if not mixed and rank == 0 and world == 1:  # beside the metric: one right-hand side through the fp64 factor of the last step (the profiler passes of this command then hold the solve's kernels)
+        if generated:
+            bvec = torch.from_numpy(ca.Problem(gn, gn, gn, glv, gtile).rhs()).cuda()
+        else:
+            bvec = torch.from_numpy(ca.plan.read_vector(os.path.join(os.path.dirname(files[0]), f"B_{plan.n}x1.mtx"), plan.n)).cuda()
+        xvec = torch.empty_like(bvec)
+        last = arenas[(done + K - 1) % n_arenas] if K <= n_arenas else arenas[(K - 1) % n_arenas]
+        dev.solve(last, bvec, xvec, stream)  # warm-up (work lists)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dev.solve(last, bvec, xvec, stream)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        solve = {"ms": round(ms, 3), "relres": dev.residual(bvec, xvec)}
     # not the metric -- reported beside it: independent factorisations (a batch of matrices, a parameter sweep) kept TWO in
     # (--in-flight) in flight, each on a device object and stream of its own.  A factorisation of this size ends in a dependency chain that keeps a
     # handful of the 256 CUs busy; the next one's leaves fill the rest.  `value` above stays the one-after-the-other rate.
@@ -508,7 +524,7 @@ def main():
                          f"(rank 0 receives {xvol[0] * eb_x / 1e6:.2f} MB, sends {xvol[1] * eb_x / 1e6:.2f} MB of a {xvol[2] * eb_x / 1e6:.2f} MB tail)" if xvol[3] > 0 else
                          f"one in-place ncclAllReduce of the {xvol[2] * eb_x / 1e6:.2f} MB arena tail (top levels replicated)"),
             "profile": profile_numbers(kernel0, args.case, mixed, args.option) if world == 1 else {},
-            "refinement": refine, "concurrent": concurrent, "sustained": sustained,
+            "refinement": refine, "solve": solve, "concurrent": concurrent, "sustained": sustained,
             "fp64_mfma_sustained_measured": SUSTAINED_FP64_MFMA_TFLOPS,
             "fp64_mfma_sustained_note": SUSTAINED_NOTE,
         }

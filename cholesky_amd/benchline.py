@@ -170,6 +170,8 @@ def assemble(rec):
             out["roofline"][key] = rec[key]
     if rec.get("refinement") is not None:
         out["config"]["refinement"] = rec["refinement"]
+    if rec.get("solve") is not None:
+        out["config"]["solve"] = rec["solve"]
     if rec.get("sustained") is not None:
         out["sustained"] = rec["sustained"]
     if rec.get("concurrent") is not None:
